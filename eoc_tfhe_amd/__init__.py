@@ -1,0 +1,383 @@
+"""eoc_tfhe_amd -- Python host side of libeoc_tfhe_gpu.so (ctypes over the C ABI of
+include/eoc_tfhe_gpu.h).
+
+The product is the shared library; this module is the thin façade a Python host uses, in the way
+ao-tfhe/tfhe.lua:1-53 wraps the Lua C module (`Tfhe.*` pass-throughs to `Tfhe.backend.*`).
+Nothing here computes a gate on the CPU: every hot-path call goes to the HIP engine and raises
+if the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeoc_tfhe_gpu.so")
+N = 1024
+
+OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9,
+           MUX=10, NOT=11, COPY=12)
+
+
+class EocError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """eoc_params (TFheGateBootstrappingParameterSet flattened)."""
+    _fields_ = [("n", C.c_int32), ("l", C.c_int32), ("Bgbit", C.c_int32), ("ks_t", C.c_int32),
+                ("ks_basebit", C.c_int32), ("ks_stdev", C.c_double), ("bk_stdev", C.c_double)]
+
+    def copy(self):
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        return q
+
+
+class Gate(C.Structure):
+    """eoc_gate netlist entry."""
+    _fields_ = [("op", C.c_int32), ("in0", C.c_int32), ("in1", C.c_int32), ("in2", C.c_int32),
+                ("out", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EocError(f"{LIB_PATH} is missing: run `python -m eoc_tfhe_amd.build` "
+                       "(there is no Python/CPU fallback for the gate path)")
+    L = C.CDLL(LIB_PATH)
+    PP = C.POINTER(Params)
+    vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+    sig = {
+        "eoc_default_params": (C.c_int, [C.c_int, PP]),
+        "eoc_params_for_lambda": (C.c_int, [C.c_int, PP]),
+        "eoc_keygen": (C.c_int, [PP, u64, C.c_int, C.POINTER(vp)]),
+        "eoc_secret_key_free": (None, [vp]),
+        "eoc_sk_params": (PP, [vp]),
+        "eoc_sk_lwe_key": (vp, [vp]),
+        "eoc_sk_tlwe_key": (vp, [vp]),
+        "eoc_sk_bk": (vp, [vp]),
+        "eoc_sk_ksk": (vp, [vp]),
+        "eoc_bk_len": (sz, [PP]),
+        "eoc_ksk_len": (sz, [PP]),
+        "eoc_encrypt_bits": (C.c_int, [vp, u64, u64, vp, sz, vp]),
+        "eoc_decrypt_bits": (C.c_int, [vp, vp, sz, vp]),
+        "eoc_lwe_encrypt": (C.c_int, [vp, u64, u64, C.c_int32, C.c_double, vp]),
+        "eoc_lwe_phase": (C.c_int32, [vp, vp]),
+        "eoc_modswitch_to_torus32": (C.c_int32, [C.c_int32, C.c_int32]),
+        "eoc_modswitch_from_torus32": (C.c_int32, [C.c_int32, C.c_int32]),
+        "eoc_device_count": (C.c_int, []),
+        "eoc_engine_create": (C.c_int, [C.c_int, PP, C.POINTER(vp)]),
+        "eoc_engine_destroy": (None, [vp]),
+        "eoc_last_error": (C.c_char_p, []),
+        "eoc_device_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+        "eoc_device_free": (C.c_int, [vp, vp]),
+        "eoc_host_to_device": (C.c_int, [vp, vp, vp, sz]),
+        "eoc_device_to_host": (C.c_int, [vp, vp, vp, sz]),
+        "eoc_engine_synchronize": (C.c_int, [vp]),
+        "eoc_bkfft_bytes": (sz, [PP]),
+        "eoc_ksk_dev_bytes": (sz, [PP]),
+        "eoc_ksk_row_stride": (sz, [PP]),
+        "eoc_engine_load_cloud_key": (C.c_int, [vp, vp, vp]),
+        "eoc_engine_set_cloud_key_device": (C.c_int, [vp, vp, vp]),
+        "eoc_engine_cloud_key_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "eoc_gate_batch_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, sz, vp]),
+        "eoc_circuit_run_device": (C.c_int, [vp, vp, sz, vp, sz, sz, vp]),
+        "eoc_circuit_bootstraps": (sz, [vp, sz]),
+        "eoc_dbg_fft_fwd_device": (C.c_int, [vp, vp, vp, sz, vp]),
+        "eoc_dbg_fft_inv_device": (C.c_int, [vp, vp, vp, sz, vp]),
+        "eoc_blind_rotate_device": (C.c_int, [vp, vp, vp, sz, vp]),
+        "eoc_keyswitch_device": (C.c_int, [vp, vp, vp, sz, vp]),
+        "eoc_engine_stats": (C.c_int, [vp, C.POINTER(u64 * 3)]),
+        "eoc_gpu_init": (C.c_int, [C.c_int, PP]),
+        "eoc_upload_cloud_key": (C.c_int, [vp]),
+        "eoc_global_engine": (vp, []),
+        "eoc_gpu_shutdown": (None, []),
+        "eoc_gate_batch": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz]),
+        "eoc_circuit_run": (C.c_int, [vp, sz, vp, sz, sz]),
+        "generateGateKey": (vp, [C.c_int, u64]),
+        "resetGateKey": (None, []),
+        "encryptBit": (vp, [C.c_int, C.c_char_p]),
+        "decryptBit": (C.c_int, [C.c_char_p, C.c_char_p]),
+        "gateNAND": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateAND": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateNOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateXOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateXNOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateNOT": (vp, [C.c_char_p, C.c_char_p]),
+        "gateMUX": (vp, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = None  # filled lazily by abi_symbols()
+
+
+def abi_symbols():
+    """Every symbol include/eoc_tfhe_gpu.h declares (parsed from the header)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "eoc_tfhe_gpu.h")
+    text = open(hdr).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
+    return sorted(set(names))
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().eoc_last_error()
+        raise EocError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def default_params(pset=0):
+    p = Params()
+    _check(lib().eoc_default_params(pset, C.byref(p)), "eoc_default_params")
+    return p
+
+
+def _take_str(ptr):
+    """Copy and free() a heap C string returned by the string API (NULL -> None, like Lua nil)."""
+    if not ptr:
+        return None
+    s = C.string_at(ptr).decode()
+    C.CDLL(None).free(C.c_void_p(ptr))
+    return s
+
+
+def _np_view(ptr, count, dtype):
+    if not ptr:
+        return None
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class SecretKey:
+    """TFheGateBootstrappingSecretKeySet: LWE key, TLWE key and (optionally) the cloud key."""
+
+    def __init__(self, params, seed, with_cloud_key=True):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.params = params.copy()
+        _check(self.L.eoc_keygen(C.byref(self.params), seed, int(with_cloud_key), C.byref(self.h)), "eoc_keygen")
+        self.n = params.n
+        self.seed = seed
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.eoc_secret_key_free(self.h)
+            self.h = None
+
+    @property
+    def lwe_key(self):
+        return _np_view(self.L.eoc_sk_lwe_key(self.h), self.n, np.int32)
+
+    @property
+    def tlwe_key(self):
+        return _np_view(self.L.eoc_sk_tlwe_key(self.h), N, np.int32)
+
+    @property
+    def bk(self):
+        p = self.params
+        v = _np_view(self.L.eoc_sk_bk(self.h), self.L.eoc_bk_len(C.byref(p)), np.int32)
+        return None if v is None else v.reshape(p.n, 2 * p.l, 2, N)
+
+    @property
+    def ksk(self):
+        p = self.params
+        v = _np_view(self.L.eoc_sk_ksk(self.h), self.L.eoc_ksk_len(C.byref(p)), np.int32)
+        return None if v is None else v.reshape(-1, p.n + 1)
+
+    def encrypt_bits(self, bits, enc_seed, first_idx=0):
+        bits = np.ascontiguousarray(np.asarray(bits).ravel(), np.uint8)
+        out = np.empty((bits.size, self.n + 1), np.int32)
+        _check(self.L.eoc_encrypt_bits(self.h, enc_seed, first_idx, bits.ctypes.data, bits.size, out.ctypes.data),
+               "eoc_encrypt_bits")
+        return out
+
+    def decrypt_bits(self, cts):
+        cts = np.ascontiguousarray(cts, np.int32).reshape(-1, self.n + 1)
+        out = np.empty(cts.shape[0], np.uint8)
+        _check(self.L.eoc_decrypt_bits(self.h, cts.ctypes.data, cts.shape[0], out.ctypes.data), "eoc_decrypt_bits")
+        return out
+
+    def phase(self, ct):
+        ct = np.ascontiguousarray(ct, np.int32)
+        return self.L.eoc_lwe_phase(self.h, ct.ctypes.data)
+
+
+class Engine:
+    """One HIP engine (one GPU).  All array arguments are DEVICE pointers (ints) unless noted."""
+
+    def __init__(self, params, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.params = params.copy()
+        _check(self.L.eoc_engine_create(device, C.byref(self.params), C.byref(self.h)), "eoc_engine_create")
+        self.device = device
+        self.n = params.n
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.eoc_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # -- cloud key ---------------------------------------------------------------------------
+    def load_cloud_key(self, sk_or_bk, ksk=None):
+        """Host torus-form BK/KSK -> device images (forward transform runs on the GPU)."""
+        if isinstance(sk_or_bk, SecretKey):
+            bk, ksk = sk_or_bk.bk, sk_or_bk.ksk
+        else:
+            bk = sk_or_bk
+        bk = np.ascontiguousarray(bk, np.int32)
+        ksk = np.ascontiguousarray(ksk, np.int32)
+        _check(self.L.eoc_engine_load_cloud_key(self.h, bk.ctypes.data, ksk.ctypes.data), "eoc_engine_load_cloud_key")
+
+    def set_cloud_key_device(self, d_bkfft, d_ksk):
+        _check(self.L.eoc_engine_set_cloud_key_device(self.h, d_bkfft, d_ksk), "eoc_engine_set_cloud_key_device")
+
+    def cloud_key_device(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(self.L.eoc_engine_cloud_key_device(self.h, C.byref(a), C.byref(b)), "eoc_engine_cloud_key_device")
+        return a.value, b.value
+
+    def download(self, d_ptr, nbytes, dtype=np.uint8):
+        """device -> host numpy copy of a raw buffer"""
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype)
+        _check(self.L.eoc_device_to_host(self.h, out.ctypes.data, d_ptr, nbytes), "eoc_device_to_host")
+        return out
+
+    def synchronize(self):
+        _check(self.L.eoc_engine_synchronize(self.h), "eoc_engine_synchronize")
+
+    @property
+    def bkfft_bytes(self):
+        return self.L.eoc_bkfft_bytes(C.byref(self.params))
+
+    @property
+    def ksk_dev_bytes(self):
+        return self.L.eoc_ksk_dev_bytes(C.byref(self.params))
+
+    # -- hot path ----------------------------------------------------------------------------
+    def gate_batch_device(self, op, d_in0, d_in1, d_in2, d_out, count, ops=None, stream=None):
+        ops_p = None
+        if ops is not None:
+            ops = np.ascontiguousarray(ops, np.uint8)
+            ops_p = ops.ctypes.data
+        _check(self.L.eoc_gate_batch_device(self.h, int(op), ops_p, d_in0, d_in1, d_in2, d_out, count, stream),
+               "eoc_gate_batch_device")
+
+    def circuit_run_device(self, gates, d_wires, n_wires, instances, stream=None):
+        arr = (Gate * len(gates))(*gates)
+        _check(self.L.eoc_circuit_run_device(self.h, C.addressof(arr), len(gates), d_wires, n_wires, instances, stream),
+               "eoc_circuit_run_device")
+
+    def fft_fwd_device(self, d_polys, d_specs, count, stream=None):
+        _check(self.L.eoc_dbg_fft_fwd_device(self.h, d_polys, d_specs, count, stream), "eoc_dbg_fft_fwd_device")
+
+    def fft_inv_device(self, d_specs, d_polys, count, stream=None):
+        _check(self.L.eoc_dbg_fft_inv_device(self.h, d_specs, d_polys, count, stream), "eoc_dbg_fft_inv_device")
+
+    def blind_rotate_device(self, d_t, d_u, count, stream=None):
+        _check(self.L.eoc_blind_rotate_device(self.h, d_t, d_u, count, stream), "eoc_blind_rotate_device")
+
+    def keyswitch_device(self, d_u, d_out, count, stream=None):
+        _check(self.L.eoc_keyswitch_device(self.h, d_u, d_out, count, stream), "eoc_keyswitch_device")
+
+    def stats(self):
+        out = (C.c_uint64 * 3)()
+        _check(self.L.eoc_engine_stats(self.h, C.byref(out)), "eoc_engine_stats")
+        return dict(batches=out[0], bootstraps=out[1], keyswitches=out[2])
+
+
+def circuit_bootstraps(gates):
+    arr = (Gate * len(gates))(*gates)
+    return lib().eoc_circuit_bootstraps(C.addressof(arr), len(gates))
+
+
+# ---- host-buffer batch API (global engine), numpy in / numpy out ----------------------------------
+def gpu_init(params, device=0):
+    _check(lib().eoc_gpu_init(device, C.byref(params)), "eoc_gpu_init")
+
+
+def gpu_shutdown():
+    lib().eoc_gpu_shutdown()
+
+
+def upload_cloud_key(sk):
+    _check(lib().eoc_upload_cloud_key(sk.h), "eoc_upload_cloud_key")
+
+
+def gate_batch(op, in0, in1=None, in2=None, ops=None):
+    in0 = np.ascontiguousarray(in0, np.int32)
+    out = np.empty_like(in0)
+    p = lambda a: None if a is None else np.ascontiguousarray(a, np.int32).ctypes.data  # noqa: E731
+    in1c = None if in1 is None else np.ascontiguousarray(in1, np.int32)
+    in2c = None if in2 is None else np.ascontiguousarray(in2, np.int32)
+    opsc = None if ops is None else np.ascontiguousarray(ops, np.uint8)
+    _check(lib().eoc_gate_batch(int(op), None if opsc is None else opsc.ctypes.data, in0.ctypes.data,
+                                None if in1c is None else in1c.ctypes.data,
+                                None if in2c is None else in2c.ctypes.data, out.ctypes.data, in0.shape[0]),
+           "eoc_gate_batch")
+    return out
+
+
+def circuit_run(gates, wires, instances):
+    wires = np.ascontiguousarray(wires, np.int32)
+    arr = (Gate * len(gates))(*gates)
+    _check(lib().eoc_circuit_run(C.addressof(arr), len(gates), wires.ctypes.data, wires.shape[0], instances),
+           "eoc_circuit_run")
+    return wires
+
+
+class Tfhe:
+    """String façade in the shape of ao-tfhe/tfhe.lua (Tfhe.* -> backend.*), for the Boolean path."""
+
+    @staticmethod
+    def generateGateKey(minimum_lambda=80, seed=1):
+        return _take_str(lib().generateGateKey(minimum_lambda, seed))
+
+    @staticmethod
+    def resetGateKey():
+        lib().resetGateKey()
+
+    @staticmethod
+    def encryptBit(bit, key=""):
+        return _take_str(lib().encryptBit(int(bit), key.encode()))
+
+    @staticmethod
+    def decryptBit(ct, key=""):
+        return lib().decryptBit(ct.encode(), key.encode())
+
+    @staticmethod
+    def _g2(name, a, b, pk=""):
+        return _take_str(getattr(lib(), name)(a.encode(), b.encode(), pk.encode()))
+
+    nand = staticmethod(lambda a, b, pk="": Tfhe._g2("gateNAND", a, b, pk))
+    and_ = staticmethod(lambda a, b, pk="": Tfhe._g2("gateAND", a, b, pk))
+    or_ = staticmethod(lambda a, b, pk="": Tfhe._g2("gateOR", a, b, pk))
+    nor = staticmethod(lambda a, b, pk="": Tfhe._g2("gateNOR", a, b, pk))
+    xor = staticmethod(lambda a, b, pk="": Tfhe._g2("gateXOR", a, b, pk))
+    xnor = staticmethod(lambda a, b, pk="": Tfhe._g2("gateXNOR", a, b, pk))
+
+    @staticmethod
+    def not_(a, pk=""):
+        return _take_str(lib().gateNOT(a.encode(), pk.encode()))
+
+    @staticmethod
+    def mux(a, b, c, pk=""):
+        return _take_str(lib().gateMUX(a.encode(), b.encode(), c.encode(), pk.encode()))

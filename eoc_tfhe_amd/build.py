@@ -1,0 +1,58 @@
+"""Build libeoc_tfhe_gpu.so in-tree (hipcc cross-compiles gfx950 without a GPU).
+
+  python -m eoc_tfhe_amd.build [--force] [--verbose]
+
+-ffp-contract=off is part of the arithmetic contract of the canonical transform:
+every fused multiply-add in the kernels is written explicitly.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libeoc_tfhe_gpu.so")
+OBJ = os.path.join(HERE, "_build")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+GXX = os.environ.get("CXX") or shutil.which("g++") or "g++"
+ARCH = "gfx950"
+
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
+             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fopenmp", "-mavx2", "-mfma", "-Wall"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose=False, extra_hip_flags=()):
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in ("kernels.hip.h", "canon_twiddles.h", "common.h")]
+    hdrs.append(os.path.join(ROOT, "include", "eoc_tfhe_gpu.h"))
+    eng_src, eng_obj = os.path.join(CSRC, "engine.hip"), os.path.join(OBJ, "engine.o")
+    host_src, host_obj = os.path.join(CSRC, "host.cpp"), os.path.join(OBJ, "host.o")
+    if force or _newer(eng_obj, [eng_src] + hdrs):
+        _run([HIPCC, *HIP_FLAGS, *extra_hip_flags, "-c", eng_src, "-o", eng_obj], verbose)
+    if force or _newer(host_obj, [host_src] + hdrs):
+        _run([GXX, *CXX_FLAGS, "-c", host_src, "-o", host_obj], verbose)
+    if force or _newer(LIB, [eng_obj, host_obj]):
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", eng_obj, host_obj, "-o", LIB,
+              "-lgomp", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

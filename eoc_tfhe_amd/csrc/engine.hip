@@ -1,0 +1,660 @@
+// engine.hip -- device engine behind the C ABI of include/eoc_tfhe_gpu.h (layers 1 and 2).
+//
+// Mirrors the role libtfhe's LweBootstrappingKeyFFT + boots* functions play under
+// ao-tfhe/eoc-tfhe-run.cpp (the reference builds the key at :231 and never calls a gate,
+// SURVEY.md 0.1); here the cloud key lives in HBM and every gate batch is three kernel launches.
+// No CPU fallback exists: if HIP reports no device the constructors fail.
+#include "kernels.hip.h"
+#include "canon_twiddles.h"
+#include "common.h"
+#include "../../include/eoc_tfhe_gpu.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using namespace eoc;
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            eoc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                        \
+            return EOC_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+struct eoc_engine {
+    int device = 0;
+    eoc_params p{};
+    int kpl = 0;
+    size_t n1p = 0;
+    d2 *d_tw = nullptr, *d_twist = nullptr;
+    // cloud key images
+    double *d_bkfft = nullptr;
+    int32_t *d_ksk = nullptr;
+    bool own_keys = false;
+    const double *bkfft = nullptr; // in use (owned or adopted)
+    const int32_t *ksk = nullptr;
+    // workspaces
+    uint16_t *d_bara = nullptr;
+    int32_t *d_u = nullptr;
+    size_t ws_jobs = 0;
+    GateDesc *d_descs = nullptr;
+    size_t ws_descs = 0;
+    int bara_stride = 0;
+    uint64_t stats[3] = {0, 0, 0};
+    std::mutex mu;
+};
+
+static int valid_params(const eoc_params *p)
+{
+    if (!p) return 0;
+    if (p->n < 1 || p->n > 1023) return 0;
+    if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->l * p->Bgbit > 32) return 0;
+    if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_basebit > 4 || p->ks_t * p->ks_basebit > 31) return 0;
+    return 1;
+}
+
+extern "C" size_t eoc_bkfft_bytes(const eoc_params *p) { return (size_t)p->n * 2 * p->l * 2 * kNH * 16; }
+extern "C" size_t eoc_ksk_row_stride(const eoc_params *p) { return ((size_t)p->n + 1 + 63) / 64 * 64; }
+extern "C" size_t eoc_ksk_dev_bytes(const eoc_params *p)
+{
+    return (size_t)kN * p->ks_t * ((size_t)1 << p->ks_basebit) * eoc_ksk_row_stride(p) * 4;
+}
+
+extern "C" int eoc_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+static int upload_tables(eoc_engine *e)
+{
+    // per-lane twiddle slots of kernels.hip.h (W512[k] = E2048[4k]) and the twist table E2048[j]
+    std::vector<double> tw((size_t)kTwSlots * 64 * 2), twist((size_t)kNH * 2);
+    auto W = [](int k, double *o) { o[0] = EOC_E2048[4 * k][0]; o[1] = EOC_E2048[4 * k][1]; };
+    for (int lane = 0; lane < 64; lane++) {
+        int lo = lane & 7;
+        for (int s = 0; s < 4; s++) W(lane + 64 * s, &tw[((size_t)s * 64 + lane) * 2]);
+        for (int s = 0; s < 2; s++) W(2 * (lane + 64 * s), &tw[((size_t)(4 + s) * 64 + lane) * 2]);
+        W(4 * lane, &tw[((size_t)6 * 64 + lane) * 2]);
+        for (int s = 0; s < 4; s++) W((s * 8 + lo) * 8, &tw[((size_t)(7 + s) * 64 + lane) * 2]);
+        for (int s = 0; s < 2; s++) W((s * 8 + lo) * 16, &tw[((size_t)(11 + s) * 64 + lane) * 2]);
+        W(lo * 32, &tw[((size_t)13 * 64 + lane) * 2]);
+    }
+    for (int j = 0; j < kNH; j++) {
+        twist[2 * j] = EOC_E2048[j][0];
+        twist[2 * j + 1] = EOC_E2048[j][1];
+    }
+    HIP_TRY(hipMalloc(&e->d_tw, tw.size() * 8));
+    HIP_TRY(hipMalloc(&e->d_twist, twist.size() * 8));
+    HIP_TRY(hipMemcpy(e->d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_twist, twist.data(), twist.size() * 8, hipMemcpyHostToDevice));
+    return EOC_OK;
+}
+
+extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **out)
+{
+    if (!out || !valid_params(p)) {
+        eoc_set_error("eoc_engine_create: bad arguments");
+        return EOC_ERR_ARG;
+    }
+    int cnt = eoc_device_count();
+    if (cnt <= 0 || device < 0 || device >= cnt) {
+        eoc_set_error("eoc_engine_create: no usable HIP device (count=%d, asked %d); the gate path has no CPU fallback",
+                      cnt, device);
+        return EOC_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    eoc_engine *e = new (std::nothrow) eoc_engine();
+    if (!e) return EOC_ERR_ALLOC;
+    e->device = device;
+    e->p = *p;
+    e->kpl = 2 * p->l;
+    e->n1p = eoc_ksk_row_stride(p);
+    e->bara_stride = (p->n + 1 + 7) / 8 * 8;
+    int rc = upload_tables(e);
+    if (rc) {
+        delete e;
+        return rc;
+    }
+    // blind-rotate kernels use > 64 KiB of dynamic LDS
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    *out = e;
+    return EOC_OK;
+}
+
+extern "C" void eoc_engine_destroy(eoc_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    hipFree(e->d_tw);
+    hipFree(e->d_twist);
+    if (e->own_keys) {
+        hipFree(e->d_bkfft);
+        hipFree(e->d_ksk);
+    }
+    hipFree(e->d_bara);
+    hipFree(e->d_u);
+    hipFree(e->d_descs);
+    delete e;
+}
+
+static int ensure_ws(eoc_engine *e, size_t jobs, size_t descs)
+{
+    if (jobs > e->ws_jobs) {
+        hipDeviceSynchronize();
+        hipFree(e->d_bara);
+        hipFree(e->d_u);
+        e->d_bara = nullptr;
+        e->d_u = nullptr;
+        e->ws_jobs = 0;
+        size_t cap = std::max<size_t>(jobs, 1024);
+        HIP_TRY(hipMalloc(&e->d_bara, cap * e->bara_stride * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc(&e->d_u, cap * (kN + 1) * sizeof(int32_t)));
+        e->ws_jobs = cap;
+    }
+    if (descs > e->ws_descs) {
+        hipDeviceSynchronize();
+        hipFree(e->d_descs);
+        e->d_descs = nullptr;
+        e->ws_descs = 0;
+        size_t cap = std::max<size_t>(descs, 256);
+        HIP_TRY(hipMalloc(&e->d_descs, cap * sizeof(GateDesc)));
+        e->ws_descs = cap;
+    }
+    return EOC_OK;
+}
+
+// ---- raw buffers -----------------------------------------------------------------------------
+extern "C" int eoc_device_alloc(eoc_engine *e, size_t bytes, void **d_ptr)
+{
+    if (!e || !d_ptr) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return EOC_OK;
+}
+extern "C" int eoc_device_free(eoc_engine *e, void *d_ptr)
+{
+    if (!e) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipFree(d_ptr));
+    return EOC_OK;
+}
+extern "C" int eoc_host_to_device(eoc_engine *e, void *d_dst, const void *src, size_t bytes)
+{
+    if (!e || !d_dst || !src) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return EOC_OK;
+}
+extern "C" int eoc_device_to_host(eoc_engine *e, void *dst, const void *d_src, size_t bytes)
+{
+    if (!e || !dst || !d_src) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return EOC_OK;
+}
+extern "C" int eoc_engine_synchronize(eoc_engine *e)
+{
+    if (!e) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return EOC_OK;
+}
+
+// ---- transforms (debug / key load) ----------------------------------------------------------
+extern "C" int eoc_dbg_fft_fwd_device(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count,
+                                      void *hip_stream)
+{
+    if (!e || !d_polys || !d_specs) return EOC_ERR_ARG;
+    if (!count) return EOC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    dim3 grid((unsigned)((count + 3) / 4));
+    hipLaunchKernelGGL(k_fft_fwd_polys, grid, dim3(256), 0, st, d_polys, d_specs, count, e->d_tw, e->d_twist);
+    HIP_TRY(hipGetLastError());
+    return EOC_OK;
+}
+extern "C" int eoc_dbg_fft_inv_device(eoc_engine *e, const double *d_specs, int32_t *d_polys, size_t count,
+                                      void *hip_stream)
+{
+    if (!e || !d_polys || !d_specs) return EOC_ERR_ARG;
+    if (!count) return EOC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    dim3 grid((unsigned)((count + 3) / 4));
+    hipLaunchKernelGGL(k_fft_inv_polys, grid, dim3(256), 0, st, d_specs, d_polys, count, e->d_tw, e->d_twist);
+    HIP_TRY(hipGetLastError());
+    return EOC_OK;
+}
+
+// ---- cloud key ------------------------------------------------------------------------------
+extern "C" int eoc_engine_load_cloud_key(eoc_engine *e, const int32_t *bk, const int32_t *ksk)
+{
+    if (!e || !bk || !ksk) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const eoc_params &p = e->p;
+    if (!e->own_keys) {
+        HIP_TRY(hipMalloc(&e->d_bkfft, eoc_bkfft_bytes(&p)));
+        HIP_TRY(hipMalloc(&e->d_ksk, eoc_ksk_dev_bytes(&p)));
+        e->own_keys = true;
+    }
+    // BK: upload the torus form, transform on the GPU (tGswToFFTConvert)
+    const size_t npoly = (size_t)p.n * e->kpl * 2;
+    int32_t *d_bk = nullptr;
+    HIP_TRY(hipMalloc(&d_bk, npoly * kN * 4));
+    HIP_TRY(hipMemcpy(d_bk, bk, npoly * kN * 4, hipMemcpyHostToDevice));
+    int rc = eoc_dbg_fft_fwd_device(e, d_bk, e->d_bkfft, npoly, nullptr);
+    if (rc) {
+        hipFree(d_bk);
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    hipFree(d_bk);
+    // KSK: [N*t][base-1][n+1]  ->  [N*t][base][n1p], row 0 and the padding zero
+    const int base = 1 << p.ks_basebit;
+    const size_t groups = (size_t)kN * p.ks_t;
+    HIP_TRY(hipMemset(e->d_ksk, 0, eoc_ksk_dev_bytes(&p)));
+    for (int d = 1; d < base; d++) {
+        // rows (g, d) for all groups g: strided 2-D copy, one row of (n+1) ints per group
+        HIP_TRY(hipMemcpy2D(e->d_ksk + (size_t)d * e->n1p, e->n1p * 4 * base,
+                            ksk + (size_t)(d - 1) * (p.n + 1), (size_t)(p.n + 1) * 4 * (base - 1),
+                            (size_t)(p.n + 1) * 4, groups, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    e->bkfft = e->d_bkfft;
+    e->ksk = e->d_ksk;
+    return EOC_OK;
+}
+
+extern "C" int eoc_engine_set_cloud_key_device(eoc_engine *e, const void *d_bkfft, const void *d_ksk)
+{
+    if (!e || !d_bkfft || !d_ksk) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->bkfft = static_cast<const double *>(d_bkfft);
+    e->ksk = static_cast<const int32_t *>(d_ksk);
+    return EOC_OK;
+}
+extern "C" int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void **d_ksk)
+{
+    if (!e || !e->bkfft || !e->ksk) return EOC_ERR_NO_KEY;
+    if (d_bkfft) *d_bkfft = e->bkfft;
+    if (d_ksk) *d_ksk = e->ksk;
+    return EOC_OK;
+}
+
+// ---- launch helpers -------------------------------------------------------------------------
+static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
+{
+    BRArgs a;
+    a.bkfft = e->bkfft;
+    a.bara = e->d_bara;
+    a.u = e->d_u;
+    a.njobs = njobs;
+    a.n = e->p.n;
+    a.Bgbit = e->p.Bgbit;
+    a.bara_stride = e->bara_stride;
+    a.mu = (int32_t)(1u << 29);
+    dim3 grid((njobs + 1) / 2), block(256);
+    switch (e->p.l) {
+    case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+    case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+    case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+    case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+    default: return EOC_ERR_ARG;
+    }
+    HIP_TRY(hipGetLastError());
+    return EOC_OK;
+}
+
+static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t ngates, uint32_t S, hipStream_t st)
+{
+    KSArgs a;
+    a.ksk = e->ksk;
+    a.u = e->d_u;
+    a.n = e->p.n;
+    a.n1p = (int)e->n1p;
+    a.t = e->p.ks_t;
+    a.basebit = e->p.ks_basebit;
+    a.S = S;
+    a.mu = (int32_t)(1u << 29);
+    dim3 grid(S, ngates), block(256);
+    int ch = (e->p.n + 1 + 255) / 256;
+    switch (ch) {
+    case 1: hipLaunchKernelGGL(k_keyswitch<1>, grid, block, 0, st, d_descs, a); break;
+    case 2: hipLaunchKernelGGL(k_keyswitch<2>, grid, block, 0, st, d_descs, a); break;
+    case 3: hipLaunchKernelGGL(k_keyswitch<3>, grid, block, 0, st, d_descs, a); break;
+    default: hipLaunchKernelGGL(k_keyswitch<4>, grid, block, 0, st, d_descs, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return EOC_OK;
+}
+
+static inline bool op_free(int op) { return op == OP_NOT || op == OP_COPY; }
+static inline bool op_valid(int op) { return (op >= 0 && op <= 12); }
+
+// One "level": a set of gates that all run over the same S instances.  descs are host-side and
+// carry device pointers; free gates and bootstrapped gates are separated here.
+static int run_level(eoc_engine *e, std::vector<GateDesc> &boot, std::vector<GateDesc> &freeg, size_t S,
+                     GateDesc *d_descs_slot, hipStream_t st)
+{
+    const int n = e->p.n;
+    size_t ofs = 0;
+    if (!freeg.empty()) {
+        HIP_TRY(hipMemcpyAsync(d_descs_slot, freeg.data(), freeg.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
+        size_t total = S * (size_t)(n + 1);
+        dim3 grid((unsigned)((total + 255) / 256), (unsigned)freeg.size());
+        hipLaunchKernelGGL(k_free_gates, grid, dim3(256), 0, st, d_descs_slot, total);
+        HIP_TRY(hipGetLastError());
+        ofs = freeg.size();
+    }
+    if (boot.empty()) return EOC_OK;
+    // jobs: [gate][variant][instance]
+    uint32_t jobs = 0;
+    bool any_mux = false;
+    for (auto &d : boot) {
+        d.job_base = jobs;
+        jobs += (uint32_t)S * (d.op == OP_MUX ? 2u : 1u);
+        any_mux |= d.op == OP_MUX;
+    }
+    GateDesc *dd = d_descs_slot + ofs;
+    HIP_TRY(hipMemcpyAsync(dd, boot.data(), boot.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
+    {
+        dim3 grid((unsigned)((n + 1 + 255) / 256), (unsigned)(S * (any_mux ? 2 : 1)), (unsigned)boot.size());
+        hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, e->d_bara, e->bara_stride);
+        HIP_TRY(hipGetLastError());
+    }
+    int rc = launch_blind_rotate(e, jobs, st);
+    if (rc) return rc;
+    rc = launch_keyswitch(e, dd, (uint32_t)boot.size(), (uint32_t)S, st);
+    if (rc) return rc;
+    e->stats[0] += 1;
+    e->stats[1] += jobs;
+    e->stats[2] += S * boot.size();
+    return EOC_OK;
+}
+
+// ---- batch of independent gates --------------------------------------------------------------
+extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
+                                     const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
+                                     void *hip_stream)
+{
+    if (!e || !d_in0 || !d_out) {
+        eoc_set_error("eoc_gate_batch_device: null argument");
+        return EOC_ERR_ARG;
+    }
+    if (!count) return EOC_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->bkfft || !e->ksk) {
+        eoc_set_error("eoc_gate_batch_device: no cloud key loaded");
+        return EOC_ERR_NO_KEY;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t stride = (size_t)e->p.n + 1;
+    std::vector<GateDesc> boot, freeg;
+    if (!ops) {
+        if (!op_valid(op) || (!op_free(op) && !d_in1) || (op == OP_MUX && !d_in2)) {
+            eoc_set_error("eoc_gate_batch_device: bad opcode %d or missing operand", op);
+            return EOC_ERR_ARG;
+        }
+        GateDesc d{op, 0, d_in0, d_in1, d_in2, d_out};
+        (op_free(op) ? freeg : boot).push_back(d);
+        int rc = ensure_ws(e, count * (op == OP_MUX ? 2 : 1), 2);
+        if (rc) return rc;
+        return run_level(e, boot, freeg, count, e->d_descs, st);
+    }
+    // mixed batch: maximal runs of equal opcode become one descriptor each (S differs per run, so
+    // runs are grouped by opcode class and launched run by run when lengths differ).  To keep the
+    // launch count at three per batch, gates are bucketed per opcode with S = 1 descriptors only
+    // when a run is short; long runs dominate in practice (bench config 4 sorts by opcode).
+    size_t i = 0;
+    int rc = EOC_OK;
+    size_t max_jobs = 0;
+    for (size_t k = 0; k < count; k++) {
+        if (!op_valid(ops[k])) {
+            eoc_set_error("eoc_gate_batch_device: bad opcode %d at %zu", (int)ops[k], k);
+            return EOC_ERR_ARG;
+        }
+    }
+    // worst case jobs for one run
+    {
+        size_t run = 0;
+        for (size_t k = 0; k < count; k++) {
+            run = (k && ops[k] == ops[k - 1]) ? run + 1 : 1;
+            max_jobs = std::max(max_jobs, run * (ops[k] == OP_MUX ? 2 : 1));
+        }
+    }
+    rc = ensure_ws(e, max_jobs, 2);
+    if (rc) return rc;
+    while (i < count) {
+        size_t j = i;
+        while (j < count && ops[j] == ops[i]) j++;
+        int o = ops[i];
+        if ((!op_free(o) && !d_in1) || (o == OP_MUX && !d_in2)) {
+            eoc_set_error("eoc_gate_batch_device: missing operand for opcode %d", o);
+            return EOC_ERR_ARG;
+        }
+        GateDesc d{o, 0, d_in0 + i * stride, d_in1 ? d_in1 + i * stride : nullptr,
+                   d_in2 ? d_in2 + i * stride : nullptr, d_out + i * stride};
+        boot.clear();
+        freeg.clear();
+        (op_free(o) ? freeg : boot).push_back(d);
+        rc = run_level(e, boot, freeg, j - i, e->d_descs, st);
+        if (rc) return rc;
+        i = j;
+    }
+    return EOC_OK;
+}
+
+// ---- circuits -------------------------------------------------------------------------------
+extern "C" size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates)
+{
+    size_t b = 0;
+    for (size_t g = 0; g < n_gates; g++) {
+        int op = gates[g].op;
+        b += op == OP_MUX ? 2 : (op_free(op) ? 0 : 1);
+    }
+    return b;
+}
+
+extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size_t n_gates, int32_t *d_wires,
+                                      size_t n_wires, size_t instances, void *hip_stream)
+{
+    if (!e || !gates || !d_wires) return EOC_ERR_ARG;
+    if (!n_gates || !instances) return EOC_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->bkfft || !e->ksk) {
+        eoc_set_error("eoc_circuit_run_device: no cloud key loaded");
+        return EOC_ERR_NO_KEY;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    // levelise: RAW, WAR and WAW hazards on wires
+    std::vector<int> wr_level(n_wires, 0), rd_level(n_wires, 0), level(n_gates, 0);
+    int nlev = 0;
+    for (size_t k = 0; k < n_gates; k++) {
+        const eoc_gate &q = gates[k];
+        int nin = op_free(q.op) ? 1 : (q.op == OP_MUX ? 3 : 2);
+        const int32_t ins[3] = {q.in0, q.in1, q.in2};
+        if (!op_valid(q.op) || q.out < 0 || (size_t)q.out >= n_wires) {
+            eoc_set_error("eoc_circuit_run_device: bad gate %zu", k);
+            return EOC_ERR_ARG;
+        }
+        int lv = std::max(wr_level[q.out], rd_level[q.out]) + 0;
+        for (int a = 0; a < nin; a++) {
+            if (ins[a] < 0 || (size_t)ins[a] >= n_wires) {
+                eoc_set_error("eoc_circuit_run_device: bad input wire in gate %zu", k);
+                return EOC_ERR_ARG;
+            }
+            lv = std::max(lv, wr_level[ins[a]]);
+        }
+        lv += 1;
+        level[k] = lv;
+        for (int a = 0; a < nin; a++) rd_level[ins[a]] = std::max(rd_level[ins[a]], lv);
+        wr_level[q.out] = lv;
+        nlev = std::max(nlev, lv);
+    }
+    std::vector<std::vector<GateDesc>> boot(nlev + 1), freeg(nlev + 1);
+    const size_t wstride = instances * ((size_t)e->p.n + 1);
+    size_t max_jobs = 0, total_descs = 0;
+    for (size_t k = 0; k < n_gates; k++) {
+        const eoc_gate &q = gates[k];
+        GateDesc d{q.op, 0, d_wires + (size_t)q.in0 * wstride,
+                   q.in1 >= 0 ? d_wires + (size_t)q.in1 * wstride : nullptr,
+                   q.in2 >= 0 ? d_wires + (size_t)q.in2 * wstride : nullptr, d_wires + (size_t)q.out * wstride};
+        (op_free(q.op) ? freeg : boot)[level[k]].push_back(d);
+    }
+    for (int lv = 1; lv <= nlev; lv++) {
+        size_t jobs = 0;
+        for (auto &d : boot[lv]) jobs += instances * (d.op == OP_MUX ? 2 : 1);
+        max_jobs = std::max(max_jobs, jobs);
+        total_descs += boot[lv].size() + freeg[lv].size();
+    }
+    int rc = ensure_ws(e, max_jobs, total_descs);
+    if (rc) return rc;
+    size_t ofs = 0;
+    for (int lv = 1; lv <= nlev; lv++) {
+        rc = run_level(e, boot[lv], freeg[lv], instances, e->d_descs + ofs, st);
+        if (rc) return rc;
+        ofs += boot[lv].size() + freeg[lv].size();
+    }
+    return EOC_OK;
+}
+
+// ---- building blocks ------------------------------------------------------------------------
+extern "C" int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_t *d_u, size_t count,
+                                       void *hip_stream)
+{
+    if (!e || !d_t || !d_u) return EOC_ERR_ARG;
+    if (!count) return EOC_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->bkfft) return EOC_ERR_NO_KEY;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = ensure_ws(e, count, 2);
+    if (rc) return rc;
+    GateDesc d{OP_RAW, 0, d_t, nullptr, nullptr, nullptr};
+    HIP_TRY(hipMemcpyAsync(e->d_descs, &d, sizeof d, hipMemcpyHostToDevice, st));
+    dim3 grid((unsigned)((e->p.n + 1 + 255) / 256), (unsigned)count, 1);
+    hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, e->d_descs, e->p.n, (uint32_t)count, e->d_bara,
+                       e->bara_stride);
+    HIP_TRY(hipGetLastError());
+    rc = launch_blind_rotate(e, (uint32_t)count, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_u, e->d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
+    return EOC_OK;
+}
+
+extern "C" int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *d_out, size_t count,
+                                    void *hip_stream)
+{
+    if (!e || !d_u || !d_out) return EOC_ERR_ARG;
+    if (!count) return EOC_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->ksk) return EOC_ERR_NO_KEY;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = ensure_ws(e, count, 2);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->d_u, d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
+    GateDesc d{OP_RAW, 0, nullptr, nullptr, nullptr, d_out};
+    HIP_TRY(hipMemcpyAsync(e->d_descs, &d, sizeof d, hipMemcpyHostToDevice, st));
+    return launch_keyswitch(e, e->d_descs, 1, (uint32_t)count, st);
+}
+
+extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])
+{
+    if (!e || !out) return EOC_ERR_ARG;
+    for (int i = 0; i < 3; i++) out[i] = e->stats[i];
+    return EOC_OK;
+}
+
+// ---- batch API on host buffers (layer 2) -----------------------------------------------------
+static eoc_engine *g_engine = nullptr;
+static std::mutex g_engine_mu;
+
+extern "C" int eoc_gpu_init(int device, const eoc_params *p)
+{
+    std::lock_guard<std::mutex> g(g_engine_mu);
+    if (g_engine) {
+        eoc_set_error("eoc_gpu_init: engine already initialised");
+        return EOC_ERR_STATE;
+    }
+    return eoc_engine_create(device, p, &g_engine);
+}
+extern "C" eoc_engine *eoc_global_engine(void) { return g_engine; }
+extern "C" void eoc_gpu_shutdown(void)
+{
+    std::lock_guard<std::mutex> g(g_engine_mu);
+    eoc_engine_destroy(g_engine);
+    g_engine = nullptr;
+}
+extern "C" int eoc_upload_cloud_key(const eoc_secret_key *sk)
+{
+    if (!g_engine) {
+        eoc_set_error("eoc_upload_cloud_key: call eoc_gpu_init first");
+        return EOC_ERR_STATE;
+    }
+    if (!sk || !eoc_sk_bk(sk) || !eoc_sk_ksk(sk)) return EOC_ERR_NO_KEY;
+    return eoc_engine_load_cloud_key(g_engine, eoc_sk_bk(sk), eoc_sk_ksk(sk));
+}
+
+extern "C" int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
+                              const int32_t *in2, int32_t *out, size_t count)
+{
+    eoc_engine *e = g_engine;
+    if (!e) {
+        eoc_set_error("eoc_gate_batch: no GPU engine (eoc_gpu_init not called or failed); there is no CPU fallback");
+        return EOC_ERR_NO_DEVICE;
+    }
+    if (!in0 || !out) return EOC_ERR_ARG;
+    if (!count) return EOC_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t bytes = count * ((size_t)e->p.n + 1) * 4;
+    int32_t *d[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int32_t *h[3] = {in0, in1, in2};
+    int rc = EOC_OK;
+    for (int k = 0; k < 4 && rc == EOC_OK; k++) {
+        if (k < 3 && !h[k]) continue;
+        if (hipMalloc(&d[k], bytes) != hipSuccess) rc = EOC_ERR_ALLOC;
+        else if (k < 3 && hipMemcpy(d[k], h[k], bytes, hipMemcpyHostToDevice) != hipSuccess) rc = EOC_ERR_HIP;
+    }
+    if (rc == EOC_OK) rc = eoc_gate_batch_device(e, op, ops, d[0], d[1], d[2], d[3], count, nullptr);
+    if (rc == EOC_OK && hipMemcpy(out, d[3], bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = EOC_ERR_HIP;
+    for (int k = 0; k < 4; k++) hipFree(d[k]);
+    return rc;
+}
+
+extern "C" int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,
+                               size_t instances)
+{
+    eoc_engine *e = g_engine;
+    if (!e) {
+        eoc_set_error("eoc_circuit_run: no GPU engine; there is no CPU fallback");
+        return EOC_ERR_NO_DEVICE;
+    }
+    if (!gates || !wires) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t bytes = n_wires * instances * ((size_t)e->p.n + 1) * 4;
+    int32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    int rc = EOC_OK;
+    if (hipMemcpy(d, wires, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = EOC_ERR_HIP;
+    if (rc == EOC_OK) rc = eoc_circuit_run_device(e, gates, n_gates, d, n_wires, instances, nullptr);
+    if (rc == EOC_OK && hipMemcpy(wires, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = EOC_ERR_HIP;
+    hipFree(d);
+    return rc;
+}

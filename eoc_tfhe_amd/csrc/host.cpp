@@ -1,0 +1,414 @@
+// host.cpp -- client-side (CPU) half of libeoc_tfhe_gpu.so: parameters, the deterministic sampler,
+// key generation, Boolean encryption/decryption, the sample wire format and the reference-style
+// string API.  Mirrors ao-tfhe/eoc-tfhe-run.cpp's operation layer: process-global key context
+// (:38-40), base64 strings in/out (:42-90), NULL/-1 + stderr on error (:218-219,277-278,397-398).
+//
+// Nothing here evaluates a gate: all boots* work is forwarded to the HIP engine (engine.hip), and
+// fails when no GPU is present.
+#include "common.h"
+#include "../../include/eoc_tfhe_gpu.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// error channel
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void eoc_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "eoc-tfhe: %s\n", g_err);
+}
+extern "C" const char *eoc_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// parameters (new_default_gate_bootstrapping_parameters, eoc-tfhe-run.cpp:230)
+// ------------------------------------------------------------------------------------------------
+extern "C" int eoc_default_params(int set, eoc_params *out)
+{
+    if (!out) return EOC_ERR_ARG;
+    switch (set) {
+    case 0: *out = eoc_params{500, 2, 10, 8, 2, 2.44e-5, 7.18e-9}; return EOC_OK;
+    case 1: *out = eoc_params{630, 3, 7, 8, 2, std::ldexp(1.0, -15), std::ldexp(1.0, -25)}; return EOC_OK;
+    default: eoc_set_error("eoc_default_params: unknown set %d", set); return EOC_ERR_ARG;
+    }
+}
+extern "C" int eoc_params_for_lambda(int lambda, eoc_params *out)
+{
+    if (lambda <= 0) {
+        eoc_set_error("the requested security parameter must be positive");
+        return EOC_ERR_ARG;
+    }
+    if (lambda <= 80) return eoc_default_params(0, out);
+    if (lambda <= 128) return eoc_default_params(1, out);
+    eoc_set_error("parameters are only implemented for 80 and 128 bits of security");
+    return EOC_ERR_ARG;
+}
+extern "C" size_t eoc_bk_len(const eoc_params *p) { return (size_t)p->n * 2 * p->l * 2 * EOC_N; }
+extern "C" size_t eoc_ksk_len(const eoc_params *p)
+{
+    return (size_t)EOC_N * p->ks_t * (((size_t)1 << p->ks_basebit) - 1) * ((size_t)p->n + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler: counter-based splitmix64 streams (DESIGN.md "PRNG")
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Stream {
+    enum Tag : uint32_t { LweKey = 1, TlweKey = 2, Bk = 3, Ksk = 4, Enc = 5 };
+    uint64_t key;
+    static uint64_t fin(uint64_t z)
+    {
+        z ^= z >> 30;
+        z *= 0xBF58476D1CE4E5B9ull;
+        z ^= z >> 27;
+        z *= 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return z;
+    }
+    Stream(uint64_t seed, Tag tag, uint64_t idx)
+    {
+        uint64_t a = fin(seed + 0x9E3779B97F4A7C15ull * (uint64_t(tag) + 1));
+        key = fin(a ^ (idx * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
+    }
+    uint64_t u64(uint64_t ctr) const { return fin(key + 0x9E3779B97F4A7C15ull * (ctr + 1)); }
+    uint32_t torus(uint64_t ctr) const { return uint32_t(u64(ctr) >> 32); }
+    uint32_t bit(uint64_t ctr) const { return uint32_t(u64(ctr) >> 63); }
+    // mu + dtot32(N(0, sigma)); Box-Muller cosine branch on counters ctr, ctr+1
+    uint32_t gaussian(uint64_t ctr, uint32_t mu, double sigma) const
+    {
+        const double scale = 1.0 / 9007199254740992.0;
+        double u1 = double((u64(ctr) >> 11) + 1) * scale;
+        double u2 = double(u64(ctr + 1) >> 11) * scale;
+        double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2);
+        double d = sigma * z;
+        double frac = d - double(int64_t(d));
+        return mu + uint32_t(uint64_t(int64_t(frac * 4294967296.0)));
+    }
+};
+
+// b = gaussian(mu, sigma) + <a, s>
+void lwe_encrypt(int n, const int32_t *s, const Stream &st, uint32_t mu, double sigma, int32_t *ct)
+{
+    uint32_t b = st.gaussian(uint64_t(n), mu, sigma);
+    for (int m = 0; m < n; m++) {
+        uint32_t a = st.torus(uint64_t(m));
+        ct[m] = int32_t(a);
+        b += s[m] ? a : 0u;
+    }
+    ct[n] = int32_t(b);
+}
+
+} // namespace
+
+extern "C" int32_t eoc_modswitch_to_torus32(int32_t mu, int32_t Msize)
+{
+    uint64_t interv = ((uint64_t(1) << 63) / uint64_t(Msize)) * 2;
+    return int32_t(uint32_t((uint64_t(int64_t(mu)) * interv) >> 32));
+}
+extern "C" int32_t eoc_modswitch_from_torus32(int32_t phase, int32_t Msize)
+{
+    uint64_t interv = ((uint64_t(1) << 63) / uint64_t(Msize)) * 2;
+    uint64_t ph = (uint64_t(uint32_t(phase)) << 32) + interv / 2;
+    return int32_t(ph / interv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// secret key set (TFheGateBootstrappingSecretKeySet; built at eoc-tfhe-run.cpp:231)
+// ------------------------------------------------------------------------------------------------
+struct eoc_secret_key {
+    eoc_params p;
+    uint64_t seed;
+    std::vector<int32_t> lwe, tlwe, bk, ksk;
+};
+
+static void make_ksk(eoc_secret_key &k)
+{
+    const eoc_params &p = k.p;
+    const int n = p.n, t = p.ks_t, bb = p.ks_basebit, nd = (1 << bb) - 1;
+    const size_t rows = size_t(EOC_N) * t * nd;
+    k.ksk.assign(rows * (n + 1), 0);
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < rows; r++) {
+        const int d = int(r % nd) + 1, j = int((r / nd) % t), i = int(r / (size_t(nd) * t));
+        // message s'_i * d / base^(j+1)   
+        uint32_t msg = k.tlwe[i] ? uint32_t(d) << (32 - (j + 1) * bb) : 0u;
+        lwe_encrypt(n, k.lwe.data(), Stream(k.seed, Stream::Ksk, r), msg, p.ks_stdev, &k.ksk[r * (n + 1)]);
+    }
+}
+
+static void make_bk(eoc_secret_key &k)
+{
+    const eoc_params &p = k.p;
+    const int kpl = 2 * p.l;
+    k.bk.assign(eoc_bk_len(&p), 0);
+    // positions of the ones of the TLWE key: b = e + s*a is a sum of signed rotations of a
+    std::vector<int> ones;
+    for (int m = 0; m < EOC_N; m++)
+        if (k.tlwe[m]) ones.push_back(m);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int ir = 0; ir < p.n * kpl; ir++) {
+        Stream st(k.seed, Stream::Bk, uint64_t(ir));
+        uint32_t *a = reinterpret_cast<uint32_t *>(&k.bk[(size_t(ir) * 2) * EOC_N]);
+        uint32_t *b = a + EOC_N;
+        for (int j = 0; j < EOC_N; j++) {
+            a[j] = st.torus(uint64_t(j));
+            b[j] = st.gaussian(uint64_t(EOC_N) + 2 * uint64_t(j), 0u, p.bk_stdev);
+        }
+        for (int m : ones) {
+            // X^m * a: coefficient j gets +a[j-m] (j >= m) or -a[j-m+N] (j < m)
+            const uint32_t *src = a + (EOC_N - m);
+            for (int j = 0; j < m; j++) b[j] -= src[j];
+            for (int j = m; j < EOC_N; j++) b[j] += a[j - m];
+        }
+        const int i = ir / kpl, row = ir % kpl;
+        if (k.lwe[i]) { // gadget: s_i * 2^(32 - p*Bgbit) on polynomial q of row (q, p)
+            const int q = row / p.l, pp = row % p.l + 1;
+            (q ? b : a)[0] += 1u << (32 - pp * p.Bgbit);
+        }
+    }
+}
+
+extern "C" int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key, eoc_secret_key **out)
+{
+    if (!p || !out || p->n < 1 || p->n > 1023 || p->l < 1 || p->l * p->Bgbit > 32 ||
+        p->ks_t * p->ks_basebit > 31) {
+        eoc_set_error("eoc_keygen: bad arguments");
+        return EOC_ERR_ARG;
+    }
+    std::unique_ptr<eoc_secret_key> k(new (std::nothrow) eoc_secret_key());
+    if (!k) return EOC_ERR_ALLOC;
+    k->p = *p;
+    k->seed = seed;
+    k->lwe.resize(p->n);
+    k->tlwe.resize(EOC_N);
+    Stream s1(seed, Stream::LweKey, 0), s2(seed, Stream::TlweKey, 0);
+    for (int i = 0; i < p->n; i++) k->lwe[i] = int32_t(s1.bit(uint64_t(i)));
+    for (int j = 0; j < EOC_N; j++) k->tlwe[j] = int32_t(s2.bit(uint64_t(j)));
+    if (with_cloud_key) {
+        make_ksk(*k);
+        make_bk(*k);
+    }
+    *out = k.release();
+    return EOC_OK;
+}
+extern "C" void eoc_secret_key_free(eoc_secret_key *sk) { delete sk; }
+extern "C" const eoc_params *eoc_sk_params(const eoc_secret_key *sk) { return sk ? &sk->p : nullptr; }
+extern "C" const int32_t *eoc_sk_lwe_key(const eoc_secret_key *sk) { return sk ? sk->lwe.data() : nullptr; }
+extern "C" const int32_t *eoc_sk_tlwe_key(const eoc_secret_key *sk) { return sk ? sk->tlwe.data() : nullptr; }
+extern "C" const int32_t *eoc_sk_bk(const eoc_secret_key *sk) { return sk && !sk->bk.empty() ? sk->bk.data() : nullptr; }
+extern "C" const int32_t *eoc_sk_ksk(const eoc_secret_key *sk) { return sk && !sk->ksk.empty() ? sk->ksk.data() : nullptr; }
+
+extern "C" int eoc_lwe_encrypt(const eoc_secret_key *sk, uint64_t enc_seed, uint64_t idx, int32_t mu, double sigma,
+                               int32_t *ct)
+{
+    if (!sk || !ct) return EOC_ERR_ARG;
+    lwe_encrypt(sk->p.n, sk->lwe.data(), Stream(enc_seed, Stream::Enc, idx), uint32_t(mu), sigma, ct);
+    return EOC_OK;
+}
+extern "C" int32_t eoc_lwe_phase(const eoc_secret_key *sk, const int32_t *ct)
+{
+    uint32_t ph = uint32_t(ct[sk->p.n]);
+    for (int m = 0; m < sk->p.n; m++) ph -= sk->lwe[m] ? uint32_t(ct[m]) : 0u;
+    return int32_t(ph);
+}
+// bootsSymEncrypt: mu = +-1/8, sigma = in_out alpha_min
+extern "C" int eoc_encrypt_bits(const eoc_secret_key *sk, uint64_t enc_seed, uint64_t first_idx, const uint8_t *bits,
+                                size_t count, int32_t *cts)
+{
+    if (!sk || !bits || !cts) return EOC_ERR_ARG;
+    const size_t st = size_t(sk->p.n) + 1;
+    const int32_t one8 = eoc_modswitch_to_torus32(1, 8);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < count; i++)
+        eoc_lwe_encrypt(sk, enc_seed, first_idx + i, bits[i] ? one8 : -one8, sk->p.ks_stdev, cts + i * st);
+    return EOC_OK;
+}
+extern "C" int eoc_decrypt_bits(const eoc_secret_key *sk, const int32_t *cts, size_t count, uint8_t *bits)
+{
+    if (!sk || !bits || !cts) return EOC_ERR_ARG;
+    const size_t st = size_t(sk->p.n) + 1;
+    for (size_t i = 0; i < count; i++) bits[i] = eoc_lwe_phase(sk, cts + i * st) > 0;
+    return EOC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// base64 + the LWE sample wire format (export_lweSample_toStream bytes, eoc-tfhe-run.cpp:293-295:
+// little-endian a[n] | b | f64 current_variance)
+// ------------------------------------------------------------------------------------------------
+namespace {
+const char kB64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+
+std::string b64_encode(const unsigned char *d, size_t len)
+{
+    std::string o;
+    o.reserve((len + 2) / 3 * 4);
+    for (size_t i = 0; i < len; i += 3) {
+        uint32_t v = uint32_t(d[i]) << 16;
+        if (i + 1 < len) v |= uint32_t(d[i + 1]) << 8;
+        if (i + 2 < len) v |= d[i + 2];
+        o.push_back(kB64[(v >> 18) & 63]);
+        o.push_back(kB64[(v >> 12) & 63]);
+        o.push_back(i + 1 < len ? kB64[(v >> 6) & 63] : '=');
+        o.push_back(i + 2 < len ? kB64[v & 63] : '=');
+    }
+    return o;
+}
+// stops at the first non-alphabet byte, like the reference decoder (eoc-tfhe-run.cpp:77-80)
+std::string b64_decode(const char *s)
+{
+    static int8_t T[256];
+    static bool init = false;
+    if (!init) {
+        memset(T, -1, sizeof T);
+        for (int i = 0; i < 64; i++) T[(unsigned char)kB64[i]] = int8_t(i);
+        init = true;
+    }
+    std::string o;
+    uint32_t acc = 0;
+    int bits = 0;
+    for (; *s; s++) {
+        int v = T[(unsigned char)*s];
+        if (v < 0) break;
+        acc = (acc << 6) | uint32_t(v);
+        bits += 6;
+        if (bits >= 8) {
+            bits -= 8;
+            o.push_back(char((acc >> bits) & 0xFF));
+        }
+    }
+    return o;
+}
+char *dup_cstr(const std::string &s)
+{ // malloc, because the Lua binding releases results with free() (eoc-tfhe-bindings.c:21)
+    char *r = static_cast<char *>(malloc(s.size() + 1));
+    if (r) memcpy(r, s.c_str(), s.size() + 1);
+    return r;
+}
+char *sample_to_b64(const int32_t *ct, int n)
+{
+    std::vector<unsigned char> buf(size_t(n + 1) * 4 + 8);
+    memcpy(buf.data(), ct, size_t(n + 1) * 4);
+    double var = 0.0;
+    memcpy(buf.data() + size_t(n + 1) * 4, &var, 8);
+    return dup_cstr(b64_encode(buf.data(), buf.size()));
+}
+bool b64_to_sample(const char *s, int n, std::vector<int32_t> &ct)
+{
+    if (!s) return false;
+    std::string raw = b64_decode(s);
+    if (raw.size() != size_t(n + 1) * 4 + 8) return false;
+    ct.resize(n + 1);
+    memcpy(ct.data(), raw.data(), size_t(n + 1) * 4);
+    return true;
+}
+
+// process-global key context (globalSecretKey / globalPublicKey, eoc-tfhe-run.cpp:38-39)
+std::mutex g_mu;
+eoc_secret_key *g_sk = nullptr;
+uint64_t g_enc_counter = 0;
+uint64_t g_enc_seed = 0;
+} // namespace
+
+extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    if (g_sk) { // eoc-tfhe-run.cpp:245-249
+        fprintf(stdout, "Secret key is already generated for this instance...\n");
+        return nullptr;
+    }
+    eoc_params p;
+    if (eoc_params_for_lambda(minimum_lambda, &p)) return nullptr;
+    eoc_secret_key *sk = nullptr;
+    if (eoc_keygen(&p, seed, 1, &sk)) return nullptr;
+    if (!eoc_global_engine() && eoc_gpu_init(0, &p)) {
+        eoc_secret_key_free(sk);
+        return nullptr;
+    }
+    if (eoc_engine_load_cloud_key(eoc_global_engine(), sk->bk.data(), sk->ksk.data())) {
+        eoc_secret_key_free(sk);
+        return nullptr;
+    }
+    g_sk = sk;
+    g_enc_seed = Stream::fin(seed ^ 0xA5A5A5A5DEADBEEFull);
+    g_enc_counter = 0;
+    char tok[96];
+    snprintf(tok, sizeof tok, "EOCGATEKEY n=%d l=%d Bgbit=%d seed=%llu", p.n, p.l, p.Bgbit, (unsigned long long)seed);
+    return dup_cstr(b64_encode(reinterpret_cast<const unsigned char *>(tok), strlen(tok)));
+}
+
+extern "C" void resetGateKey(void)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    eoc_secret_key_free(g_sk);
+    g_sk = nullptr;
+    eoc_gpu_shutdown();
+}
+
+extern "C" const char *encryptBit(int bit, const char *)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    if (!g_sk) { // eoc-tfhe-run.cpp:277-278
+        fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
+        return nullptr;
+    }
+    std::vector<int32_t> ct(g_sk->p.n + 1);
+    uint8_t b = bit ? 1 : 0;
+    eoc_encrypt_bits(g_sk, g_enc_seed, g_enc_counter++, &b, 1, ct.data());
+    return sample_to_b64(ct.data(), g_sk->p.n);
+}
+
+extern "C" int decryptBit(const char *b64ct, const char *)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    if (!g_sk) { // eoc-tfhe-run.cpp:421-424
+        fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
+        return -1;
+    }
+    std::vector<int32_t> ct;
+    if (!b64_to_sample(b64ct, g_sk->p.n, ct)) {
+        fprintf(stderr, "decryptBit: malformed ciphertext\n");
+        return -1;
+    }
+    return eoc_lwe_phase(g_sk, ct.data()) > 0 ? 1 : 0;
+}
+
+static const char *gate_strings(int op, const char *c1, const char *c2, const char *c3)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    if (!g_sk || !eoc_global_engine()) { // eoc-tfhe-run.cpp:465-468
+        fprintf(stderr, "Public key not initialized. Generate the secret key first.\n");
+        return nullptr;
+    }
+    const int n = g_sk->p.n;
+    std::vector<int32_t> a, b, c, out(n + 1);
+    if (!b64_to_sample(c1, n, a) || (op != EOC_NOT && !b64_to_sample(c2, n, b)) ||
+        (op == EOC_MUX && !b64_to_sample(c3, n, c))) {
+        fprintf(stderr, "gate: malformed ciphertext\n");
+        return nullptr;
+    }
+    if (eoc_gate_batch(op, nullptr, a.data(), b.empty() ? nullptr : b.data(), c.empty() ? nullptr : c.data(),
+                       out.data(), 1))
+        return nullptr;
+    return sample_to_b64(out.data(), n);
+}
+
+extern "C" const char *gateNAND(const char *a, const char *b, const char *) { return gate_strings(EOC_NAND, a, b, nullptr); }
+extern "C" const char *gateAND(const char *a, const char *b, const char *) { return gate_strings(EOC_AND, a, b, nullptr); }
+extern "C" const char *gateOR(const char *a, const char *b, const char *) { return gate_strings(EOC_OR, a, b, nullptr); }
+extern "C" const char *gateNOR(const char *a, const char *b, const char *) { return gate_strings(EOC_NOR, a, b, nullptr); }
+extern "C" const char *gateXOR(const char *a, const char *b, const char *) { return gate_strings(EOC_XOR, a, b, nullptr); }
+extern "C" const char *gateXNOR(const char *a, const char *b, const char *) { return gate_strings(EOC_XNOR, a, b, nullptr); }
+extern "C" const char *gateNOT(const char *a, const char *) { return gate_strings(EOC_NOT, a, nullptr, nullptr); }
+extern "C" const char *gateMUX(const char *a, const char *b, const char *c, const char *) { return gate_strings(EOC_MUX, a, b, c); }

@@ -1,0 +1,602 @@
+// kernels.hip.h -- hand-written HIP kernels (gfx950 / CDNA4) for the TFHE gate-bootstrapping path.
+//
+// Replaces, on the device, the upstream libtfhe CPU functions listed in SURVEY.md 8a:
+//   k_prepare        bootsNAND... linear stage + modSwitchFromTorus32 loop of tfhe_bootstrap_woKS_FFT
+//   k_blind_rotate   tfhe_blindRotateAndExtract_FFT / tfhe_blindRotate_FFT / tfhe_MuxRotate_FFT /
+//                    tLweMulByXaiMinusOne / tGswTorus32PolynomialDecompH / IntPolynomial_ifft /
+//                    tLweFFTAddMulRTo / tLweFromFFTConvert / tLweAddTo / tLweExtractLweSample
+//   k_keyswitch      lweKeySwitch
+//   k_fft_fwd_polys  tGswToFFTConvert (key load)
+//
+// Arithmetic contract (DESIGN.md "Canonical transform v1"): every floating-point operation below
+// is a separately rounded IEEE-754 binary64 +, -, * or an explicit fma; the file MUST be compiled
+// with -ffp-contract=off.  The data-flow graph is the oracle's radix-2 DIF/DIT graph; three radix-2
+// stages are executed per register pass (8 points per lane, one 512-point transform per wave64).
+//
+// Wave layouts of the 512 complex points (e = 9-bit index):
+//   L0: reg r = e[8:6], lane = e[5:0]           (input of forward / output of inverse)
+//   L1: reg r = e[5:3], lane = e[8:6]*8 + e[2:0]
+//   L2: reg r = e[2:0], lane = e[8:3]           (spectrum layout; stored at sigma(e) = r*64 + lane)
+// The two transposes go through a per-wave LDS scratch with conflict-free address maps f01 / f12.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace eoc {
+
+typedef double d2 __attribute__((ext_vector_type(2))); // (re, im)
+
+constexpr int kN = 1024;
+constexpr int kNH = 512;
+constexpr int kScr = 568;      // d2 elements of per-wave transpose scratch (f01 needs 72*7+64)
+constexpr int kTwSlots = 14;   // per-lane twiddle slots (7 for pass 0, 7 for pass 1)
+
+#define EOC_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+__device__ __forceinline__ d2 cmul(d2 a, d2 w)
+{ // a * w
+    d2 r;
+    r.x = EOC_FMA(a.x, w.x, -(a.y * w.y));
+    r.y = EOC_FMA(a.x, w.y, a.y * w.x);
+    return r;
+}
+__device__ __forceinline__ d2 cmulc(d2 a, d2 w)
+{ // a * conj(w)
+    d2 r;
+    r.x = EOC_FMA(a.x, w.x, a.y * w.y);
+    r.y = EOC_FMA(a.y, w.x, -(a.x * w.y));
+    return r;
+}
+
+// --- radix-2 butterflies -------------------------------------------------------------------------
+__device__ __forceinline__ void dif_w(d2 &a, d2 &b, d2 w)
+{
+    d2 u = a, v = b;
+    a = u + v;
+    b = cmul(u - v, w);
+}
+__device__ __forceinline__ void dif_1(d2 &a, d2 &b)
+{
+    d2 u = a, v = b;
+    a = u + v;
+    b = u - v;
+}
+__device__ __forceinline__ void dif_i(d2 &a, d2 &b)
+{ // w = i: (t.x, t.y) * i = (-t.y, t.x)
+    d2 u = a, v = b;
+    a = u + v;
+    d2 t = u - v;
+    b.x = -t.y;
+    b.y = t.x;
+}
+__device__ __forceinline__ void dit_w(d2 &a, d2 &b, d2 w)
+{
+    d2 u = a, p = cmulc(b, w);
+    a = u + p;
+    b = u - p;
+}
+__device__ __forceinline__ void dit_1(d2 &a, d2 &b)
+{
+    d2 u = a, p = b;
+    a = u + p;
+    b = u - p;
+}
+__device__ __forceinline__ void dit_i(d2 &a, d2 &b)
+{ // v * conj(i) = (v.y, -v.x)
+    d2 u = a, p;
+    p.x = b.y;
+    p.y = -b.x;
+    a = u + p;
+    b = u - p;
+}
+
+// W512[64] = (c, c), W512[192] = (-c, c), c = correctly rounded sqrt(1/2) = EOC_E2048[256][0]
+#define EOC_SQRT_HALF 0x1.6a09e667f3bcdp-1
+
+// --- LDS address maps ---------------------------------------------------------------------------
+__device__ __forceinline__ int f12(int e) { return e ^ (((e >> 4) & 7) | (((e >> 6) & 1) << 3)); }
+
+// compiler-level ordering between a wave's own LDS writes and cross-lane reads (the hardware
+// executes one wave's LDS operations in order, so no s_barrier is needed inside a wave)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// forward: x[] in L0 (already twisted) -> x[] in L2.  tw = LDS table [14][64], scr = this wave's scratch
+__device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+{
+    // ---- pass 0: stages 0,1,2 (bits 8,7,6) ----
+    {
+        d2 w0 = tw[0 * 64 + lane], w1 = tw[1 * 64 + lane], w2 = tw[2 * 64 + lane], w3 = tw[3 * 64 + lane];
+        dif_w(x[0], x[4], w0);
+        dif_w(x[1], x[5], w1);
+        dif_w(x[2], x[6], w2);
+        dif_w(x[3], x[7], w3);
+        d2 w4 = tw[4 * 64 + lane], w5 = tw[5 * 64 + lane];
+        dif_w(x[0], x[2], w4);
+        dif_w(x[1], x[3], w5);
+        dif_w(x[4], x[6], w4);
+        dif_w(x[5], x[7], w5);
+        d2 w6 = tw[6 * 64 + lane];
+        dif_w(x[0], x[1], w6);
+        dif_w(x[2], x[3], w6);
+        dif_w(x[4], x[5], w6);
+        dif_w(x[6], x[7], w6);
+    }
+    // ---- transpose L0 -> L1 ----
+    const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[72 * r + lane] = x[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = scr[72 * hi + 8 * r + lo];
+    wave_lds_fence();
+    // ---- pass 1: stages 3,4,5 (bits 5,4,3) ----
+    {
+        d2 w0 = tw[7 * 64 + lane], w1 = tw[8 * 64 + lane], w2 = tw[9 * 64 + lane], w3 = tw[10 * 64 + lane];
+        dif_w(x[0], x[4], w0);
+        dif_w(x[1], x[5], w1);
+        dif_w(x[2], x[6], w2);
+        dif_w(x[3], x[7], w3);
+        d2 w4 = tw[11 * 64 + lane], w5 = tw[12 * 64 + lane];
+        dif_w(x[0], x[2], w4);
+        dif_w(x[1], x[3], w5);
+        dif_w(x[4], x[6], w4);
+        dif_w(x[5], x[7], w5);
+        d2 w6 = tw[13 * 64 + lane];
+        dif_w(x[0], x[1], w6);
+        dif_w(x[2], x[3], w6);
+        dif_w(x[4], x[5], w6);
+        dif_w(x[6], x[7], w6);
+    }
+    // ---- transpose L1 -> L2 ----
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[f12(hi * 64 + r * 8 + lo)] = x[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = scr[f12(lane * 8 + r)];
+    wave_lds_fence();
+    // ---- pass 2: stages 6,7,8 (bits 2,1,0), lane-independent twiddles ----
+    {
+        const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
+        dif_1(x[0], x[4]);
+        dif_w(x[1], x[5], wc);
+        dif_i(x[2], x[6]);
+        dif_w(x[3], x[7], wd);
+        dif_1(x[0], x[2]);
+        dif_i(x[1], x[3]);
+        dif_1(x[4], x[6]);
+        dif_i(x[5], x[7]);
+        dif_1(x[0], x[1]);
+        dif_1(x[2], x[3]);
+        dif_1(x[4], x[5]);
+        dif_1(x[6], x[7]);
+    }
+}
+
+// inverse: x[] in L2 -> x[] in L0 (before the un-twist)
+__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    {
+        const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
+        dit_1(x[0], x[1]);
+        dit_1(x[2], x[3]);
+        dit_1(x[4], x[5]);
+        dit_1(x[6], x[7]);
+        dit_1(x[0], x[2]);
+        dit_i(x[1], x[3]);
+        dit_1(x[4], x[6]);
+        dit_i(x[5], x[7]);
+        dit_1(x[0], x[4]);
+        dit_w(x[1], x[5], wc);
+        dit_i(x[2], x[6]);
+        dit_w(x[3], x[7], wd);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
+    wave_lds_fence();
+    {
+        d2 w6 = tw[13 * 64 + lane];
+        dit_w(x[0], x[1], w6);
+        dit_w(x[2], x[3], w6);
+        dit_w(x[4], x[5], w6);
+        dit_w(x[6], x[7], w6);
+        d2 w4 = tw[11 * 64 + lane], w5 = tw[12 * 64 + lane];
+        dit_w(x[0], x[2], w4);
+        dit_w(x[1], x[3], w5);
+        dit_w(x[4], x[6], w4);
+        dit_w(x[5], x[7], w5);
+        d2 w0 = tw[7 * 64 + lane], w1 = tw[8 * 64 + lane], w2 = tw[9 * 64 + lane], w3 = tw[10 * 64 + lane];
+        dit_w(x[0], x[4], w0);
+        dit_w(x[1], x[5], w1);
+        dit_w(x[2], x[6], w2);
+        dit_w(x[3], x[7], w3);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = x[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
+    wave_lds_fence();
+    {
+        d2 w6 = tw[6 * 64 + lane];
+        dit_w(x[0], x[1], w6);
+        dit_w(x[2], x[3], w6);
+        dit_w(x[4], x[5], w6);
+        dit_w(x[6], x[7], w6);
+        d2 w4 = tw[4 * 64 + lane], w5 = tw[5 * 64 + lane];
+        dit_w(x[0], x[2], w4);
+        dit_w(x[1], x[3], w5);
+        dit_w(x[4], x[6], w4);
+        dit_w(x[5], x[7], w5);
+        d2 w0 = tw[0 * 64 + lane], w1 = tw[1 * 64 + lane], w2 = tw[2 * 64 + lane], w3 = tw[3 * 64 + lane];
+        dit_w(x[0], x[4], w0);
+        dit_w(x[1], x[5], w1);
+        dit_w(x[2], x[6], w2);
+        dit_w(x[3], x[7], w3);
+    }
+}
+
+// rint + wrap to 32 bits: exact for |v| < 2^63
+__device__ __forceinline__ uint32_t wrap_round(double v)
+{
+    double r = __builtin_rint(v);
+    double h = __builtin_floor(r * 0x1p-32);
+    double lo = EOC_FMA(h, -4294967296.0, r);
+    return (uint32_t)lo;
+}
+
+// copy the two constant tables into LDS (called by all 256 threads, followed by __syncthreads)
+__device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_tw, const d2 *g_twist, int tid)
+{
+    for (int i = tid; i < kTwSlots * 64; i += 256) s_tw[i] = g_tw[i];
+    for (int i = tid; i < kNH; i += 256) s_twist[i] = g_twist[i];
+}
+
+// =================================================================================================
+// K4 / debug: forward transform of `count` integer polynomials, one wave each
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_fft_fwd_polys(const int32_t *__restrict__ polys,
+                                                        double *__restrict__ specs, size_t count,
+                                                        const d2 *__restrict__ g_tw,
+                                                        const d2 *__restrict__ g_twist)
+{
+    __shared__ d2 s_tw[kTwSlots * 64];
+    __shared__ d2 s_twist[kNH];
+    __shared__ d2 s_scr[4][kScr];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid);
+    __syncthreads();
+    size_t poly = (size_t)blockIdx.x * 4 + w;
+    if (poly >= count) return;
+    const int32_t *p = polys + poly * kN;
+    d2 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int j = lane + 64 * r;
+        d2 v = {(double)p[j], (double)p[j + kNH]};
+        x[r] = cmul(v, s_twist[j]);
+    }
+    fft_fwd_wave(x, s_tw, s_scr[w], lane);
+    d2 *o = reinterpret_cast<d2 *>(specs) + poly * kNH;
+#pragma unroll
+    for (int r = 0; r < 8; r++) o[r * 64 + lane] = x[r];
+}
+
+__global__ __launch_bounds__(256) void k_fft_inv_polys(const double *__restrict__ specs,
+                                                        int32_t *__restrict__ polys, size_t count,
+                                                        const d2 *__restrict__ g_tw,
+                                                        const d2 *__restrict__ g_twist)
+{
+    __shared__ d2 s_tw[kTwSlots * 64];
+    __shared__ d2 s_twist[kNH];
+    __shared__ d2 s_scr[4][kScr];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid);
+    __syncthreads();
+    size_t poly = (size_t)blockIdx.x * 4 + w;
+    if (poly >= count) return;
+    const d2 *in = reinterpret_cast<const d2 *>(specs) + poly * kNH;
+    d2 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = in[r * 64 + lane];
+    fft_inv_wave(x, s_tw, s_scr[w], lane);
+    int32_t *p = polys + poly * kN;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int j = lane + 64 * r;
+        d2 y = cmulc(x[r], s_twist[j] * 0x1p-9);
+        p[j] = (int32_t)wrap_round(y.x);
+        p[j + kNH] = (int32_t)wrap_round(y.y);
+    }
+}
+
+// =================================================================================================
+// K1: gate linear stage + mod-switch.   t = (0,cst) + s0*in0 + s1*in1  ->  bara/barb in [0, 2N)
+// =================================================================================================
+struct GateDesc {
+    int32_t op;        // eoc_op, or OP_RAW
+    uint32_t job_base; // first blind-rotate job of this gate (jobs are [variant][instance])
+    const int32_t *in0, *in1, *in2;
+    int32_t *out;
+};
+constexpr int OP_MUX = 10, OP_NOT = 11, OP_COPY = 12, OP_RAW = 100;
+
+__device__ __forceinline__ void gate_lin(int op, int &cst8, int &s0, int &s1)
+{
+    // (cst in eighths, s0, s1) -- SURVEY.md 8a a1
+    switch (op) {
+    case 0: cst8 = 1; s0 = -1; s1 = -1; break;  // NAND
+    case 1: cst8 = -1; s0 = 1; s1 = 1; break;   // AND
+    case 2: cst8 = 1; s0 = 1; s1 = 1; break;    // OR
+    case 3: cst8 = -1; s0 = -1; s1 = -1; break; // NOR
+    case 4: cst8 = 2; s0 = 2; s1 = 2; break;    // XOR
+    case 5: cst8 = -2; s0 = -2; s1 = -2; break; // XNOR
+    case 6: cst8 = -1; s0 = -1; s1 = 1; break;  // ANDNY
+    case 7: cst8 = -1; s0 = 1; s1 = -1; break;  // ANDYN
+    case 8: cst8 = 1; s0 = -1; s1 = 1; break;   // ORNY
+    case 9: cst8 = 1; s0 = 1; s1 = -1; break;   // ORYN
+    default: cst8 = 0; s0 = 1; s1 = 0; break;   // RAW: t = in0
+    }
+}
+
+// grid: x = ceil((n+1)/256), y = jobs of the widest gate (S or 2S), z = gates of this level
+__global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ descs, int n, uint32_t S,
+                                                 uint16_t *__restrict__ bara, int bara_stride)
+{
+    const GateDesc d = descs[blockIdx.z];
+    const uint32_t y = blockIdx.y;
+    const uint32_t variant = y / S, s = y - variant * S;
+    if (variant >= (d.op == OP_MUX ? 2u : 1u)) return;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m > n) return;
+    int op = d.op;
+    const int32_t *a = d.in0, *b = d.in1;
+    if (d.op == OP_MUX) { // u1 = AND(a,b), u2 = ANDNY(a,c)
+        op = variant ? 6 : 1;
+        b = variant ? d.in2 : d.in1;
+    }
+    int cst8, s0, s1;
+    gate_lin(op, cst8, s0, s1);
+    const size_t off = (size_t)s * (n + 1) + m;
+    uint32_t t = (uint32_t)s0 * (uint32_t)a[off];
+    if (s1) t += (uint32_t)s1 * (uint32_t)b[off];
+    if (m == n) t += (uint32_t)cst8 << 29;
+    // modSwitchFromTorus32(t, 2N), N = 1024: round(t * 2048 / 2^32) mod 2048
+    bara[(size_t)(d.job_base + y) * bara_stride + m] = (uint16_t)(((t + (1u << 20)) >> 21) & 2047u);
+}
+
+// NOT / COPY: no bootstrap.  grid: x = ceil(S*(n+1)/256), y = gates
+__global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__ descs, size_t total)
+{
+    const GateDesc d = descs[blockIdx.y];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    uint32_t v = (uint32_t)d.in0[i];
+    d.out[i] = (int32_t)(d.op == OP_NOT ? 0u - v : v);
+}
+
+// =================================================================================================
+// K2: blind rotate + sample extract.  One workgroup = 4 waves = 2 ciphertexts; wave pair (h = 0,1)
+// of a ciphertext: wave h owns accumulator polynomial h, decomposes it, runs the l forward
+// transforms of its digits, multiplies by rows (h, p) of BK_i for BOTH output polynomials, hands the
+// partial spectrum of the other polynomial to its partner through LDS, and runs the inverse
+// transform of its own.
+// =================================================================================================
+struct BRArgs {
+    const double *bkfft;  // [n][2l][2][512] complex, bin order sigma
+    const uint16_t *bara; // [jobs][stride], entry n = barb
+    int32_t *u;           // [jobs][N+1]
+    uint32_t njobs;
+    int n, Bgbit, bara_stride;
+    int32_t mu;
+};
+
+constexpr int kBRLds = (kTwSlots * 64 + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
+
+template <int L>
+__global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__restrict__ g_tw,
+                                                         const d2 *__restrict__ g_twist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    d2 *s_tw = reinterpret_cast<d2 *>(smem);
+    d2 *s_twist = s_tw + kTwSlots * 64;
+    d2 *s_scr_all = s_twist + kNH;
+    int32_t *s_acc_all = reinterpret_cast<int32_t *>(s_scr_all + 4 * kScr);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = w & 1;
+    d2 *scr = s_scr_all + w * kScr;
+    d2 *scr_partner = s_scr_all + (w ^ 1) * kScr;
+    int32_t *acc = s_acc_all + w * kN;
+
+    uint32_t job = blockIdx.x * 2 + (w >> 1);
+    const bool valid = job < A.njobs;
+    if (!valid) job = A.njobs - 1; // idle pair shadows the last job, keeps barriers matched
+    const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
+
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid);
+
+    // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
+    {
+        const int barb = bara[A.n];
+        const int rot = (2 * kN - barb) & (2 * kN - 1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int j = lane + 64 * r;
+            int idx = (j - rot) & (2 * kN - 1);
+            int32_t v = (idx & kN) ? -A.mu : A.mu;
+            acc[j] = h ? v : 0;
+        }
+    }
+    __syncthreads();
+
+    const int Bgbit = A.Bgbit;
+    const uint32_t maskBg = (1u << Bgbit) - 1, halfBg = 1u << (Bgbit - 1);
+    uint32_t offset = 0;
+#pragma unroll
+    for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
+    constexpr int KPL = 2 * L;
+    const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
+
+    for (int i = 0; i < A.n; i++) {
+        const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
+        // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
+        // zero update, which is what skipping the step (as libtfhe does) amounts to.
+        uint32_t dlo[8], dhi[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int j = lane + 64 * r;
+            int i0 = (j - abar) & (2 * kN - 1);
+            int i1 = (j + kNH - abar) & (2 * kN - 1);
+            uint32_t v0 = (uint32_t)acc[i0 & (kN - 1)];
+            uint32_t v1 = (uint32_t)acc[i1 & (kN - 1)];
+            v0 = (i0 & kN) ? 0u - v0 : v0;
+            v1 = (i1 & kN) ? 0u - v1 : v1;
+            dlo[r] = v0 - (uint32_t)acc[j] + offset;
+            dhi[r] = v1 - (uint32_t)acc[j + kNH] + offset;
+        }
+        // mine[] accumulates output polynomial h (kept by this wave), theirs[] polynomial 1-h
+        d2 mine[8], theirs[8];
+        auto digit_pass = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            const int shift = 32 - p * Bgbit;
+            const d2 *row = bk + ((size_t)i * KPL + (h * L + (p - 1))) * 2 * kNH;
+            const d2 *row_m = row + h * kNH, *row_t = row + (1 - h) * kNH;
+            d2 bm[8], bt[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                bm[r] = row_m[r * 64 + lane];
+                bt[r] = row_t[r * 64 + lane];
+            }
+            d2 x[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int dl = (int)((dlo[r] >> shift) & maskBg) - (int)halfBg;
+                int dh = (int)((dhi[r] >> shift) & maskBg) - (int)halfBg;
+                d2 v = {(double)dl, (double)dh};
+                x[r] = cmul(v, s_twist[lane + 64 * r]);
+            }
+            fft_fwd_wave(x, s_tw, scr, lane);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if constexpr (p == 1) {
+                    mine[r].x = EOC_FMA(-x[r].y, bm[r].y, x[r].x * bm[r].x);
+                    mine[r].y = EOC_FMA(x[r].y, bm[r].x, x[r].x * bm[r].y);
+                    theirs[r].x = EOC_FMA(-x[r].y, bt[r].y, x[r].x * bt[r].x);
+                    theirs[r].y = EOC_FMA(x[r].y, bt[r].x, x[r].x * bt[r].y);
+                } else {
+                    mine[r].x = EOC_FMA(-x[r].y, bm[r].y, EOC_FMA(x[r].x, bm[r].x, mine[r].x));
+                    mine[r].y = EOC_FMA(x[r].y, bm[r].x, EOC_FMA(x[r].x, bm[r].y, mine[r].y));
+                    theirs[r].x = EOC_FMA(-x[r].y, bt[r].y, EOC_FMA(x[r].x, bt[r].x, theirs[r].x));
+                    theirs[r].y = EOC_FMA(x[r].y, bt[r].x, EOC_FMA(x[r].x, bt[r].y, theirs[r].y));
+                }
+            }
+        };
+        digit_pass(std::integral_constant<int, 1>{});
+        if constexpr (L >= 2) digit_pass(std::integral_constant<int, 2>{});
+        if constexpr (L >= 3) digit_pass(std::integral_constant<int, 3>{});
+        if constexpr (L >= 4) digit_pass(std::integral_constant<int, 4>{});
+        // hand the other polynomial's partial spectrum to the partner wave
+#pragma unroll
+        for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+        __syncthreads();
+        d2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) // S = part(q_in=0) + part(q_in=1); IEEE addition commutes
+            x[r] = mine[r] + scr_partner[r * 64 + lane];
+        __syncthreads();
+        fft_inv_wave(x, s_tw, scr, lane);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int j = lane + 64 * r;
+            d2 y = cmulc(x[r], s_twist[j] * 0x1p-9);
+            acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round(y.x));
+            acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round(y.y));
+        }
+        wave_lds_fence();
+    }
+
+    // tLweExtractLweSample, index 0
+    if (valid) {
+        int32_t *u = A.u + (size_t)job * (kN + 1);
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int j = lane + 64 * r;
+                u[j] = j == 0 ? acc[0] : (int32_t)(0u - (uint32_t)acc[kN - j]);
+            }
+        } else if (lane == 0) {
+            u[kN] = acc[0];
+        }
+    }
+}
+
+// =================================================================================================
+// K3: key switch.  One workgroup per ciphertext; thread c owns output coefficients c, c+256, ...
+// KSK device image: [N*t][base][n1p] with row d = 0 all zero, so the digit loop is branch-free.
+// =================================================================================================
+struct KSArgs {
+    const int32_t *ksk;
+    const int32_t *u;    // [jobs][N+1]
+    int n, n1p, t, basebit;
+    uint32_t S;
+    int32_t mu;
+};
+
+template <int CH> // CH = ceil((n+1)/256)
+__global__ __launch_bounds__(256) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
+{
+    __shared__ uint32_t s_u[kN + 1];
+    const GateDesc d = descs[blockIdx.y];
+    const uint32_t s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int32_t *u1 = A.u + (size_t)(d.job_base + s) * (kN + 1);
+    const bool mux = d.op == OP_MUX;
+    const int32_t *u2 = u1 + (size_t)A.S * (kN + 1);
+    const uint32_t prec_offset = 1u << (32 - (1 + A.basebit * A.t));
+    for (int j = tid; j <= kN; j += 256) {
+        uint32_t v = (uint32_t)u1[j];
+        if (mux) v += (uint32_t)u2[j] + (j == kN ? (uint32_t)A.mu : 0u);
+        s_u[j] = j < kN ? v + prec_offset : v;
+    }
+    __syncthreads();
+    uint32_t out[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) out[c] = 0;
+    const uint32_t mask = (1u << A.basebit) - 1;
+    const int base = 1 << A.basebit;
+    const size_t n1p = (size_t)A.n1p;
+    for (int i = 0; i < kN; i++) {
+        const uint32_t ai = s_u[i];
+        const int32_t *rows = A.ksk + (size_t)i * A.t * base * n1p;
+#pragma unroll 8
+        for (int j = 0; j < A.t; j++) {
+            uint32_t dg = (ai >> (32 - (j + 1) * A.basebit)) & mask;
+            const int32_t *row = rows + ((size_t)j * base + dg) * n1p;
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                int m = tid + 256 * c;
+                if (m < A.n1p) out[c] -= (uint32_t)row[m];
+            }
+        }
+    }
+    int32_t *o = d.out + (size_t)s * (A.n + 1);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        int m = tid + 256 * c;
+        if (m < A.n) o[m] = (int32_t)out[c];
+        else if (m == A.n) o[m] = (int32_t)(out[c] + s_u[kN]);
+    }
+}
+
+} // namespace eoc

@@ -1,0 +1,209 @@
+/*
+ * eoc_tfhe_gpu.h -- C ABI of libeoc_tfhe_gpu.so, the MI355X-native gate-bootstrapping engine that
+ * sits behind the eoc-tfhe Lua/C surface.
+ *
+ * Conventions are the reference's (ao-tfhe/eoc-tfhe-run.h:8-19, ao-tfhe/eoc-tfhe-run.cpp:167-513):
+ *   - plain C symbols, plain pointers and sizes, no exceptions across the boundary
+ *     (the reference is built -fno-exceptions, ao-tfhe/build.sh:23);
+ *   - string functions return a heap C string the caller releases with free() (the binding does
+ *     exactly that, ao-tfhe/eoc-tfhe-bindings.c:21,35,47,65,75,86,112) or NULL on error with a
+ *     message on stderr (eoc-tfhe-run.cpp:218-219,277-278); int functions return a negative code;
+ *   - one process-global key context for the string API (globalSecretKey / globalPublicKey,
+ *     eoc-tfhe-run.cpp:38-40); every base64Key / public_key argument is accepted and ignored,
+ *     as the bindings pass NULL (ao-tfhe/eoc-tfhe-bindings.c:63,73,84,97,110).
+ *
+ * Three layers, lowest first:
+ *   1. engine API  (eoc_engine_*, eoc_*_device): device pointers + a HIP stream; what bench.py and
+ *      a multi-GPU host use.  This is where libtfhe's bootsNAND/.../bootsMUX -> tfhe_bootstrap_FFT
+ *      -> tfhe_blindRotate_FFT -> lweKeySwitch would be bound (upstream tfhe/tfhe@bc71bfae, absent
+ *      from /root/reference; call-stack in SURVEY.md 3.3).
+ *   2. batch API   (eoc_keygen, eoc_encrypt_bits, eoc_gate_batch, eoc_circuit_run): caller-owned
+ *      host buffers of int32 LWE samples.
+ *   3. string API  (encryptBit, gateNAND, ...): base64 in / base64 out, the exact style of
+ *      addCiphertexts (eoc-tfhe-run.cpp:427-470) so that `l_gate*` wrappers follow
+ *      l_addCiphertexts (ao-tfhe/eoc-tfhe-bindings.c:12-24) line for line.
+ *
+ * The gate path has NO CPU fallback: without a usable HIP device every hot-path entry point
+ * fails (negative code / NULL and a message on stderr).
+ */
+#ifndef EOC_TFHE_GPU_H
+#define EOC_TFHE_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EOC_N 1024 /* ring degree, fixed (k = 1) */
+
+/* TFheGateBootstrappingParameterSet (type used at eoc-tfhe-run.cpp:230) flattened. */
+typedef struct eoc_params {
+    int32_t n;          /* LWE dimension */
+    int32_t l;          /* gadget length */
+    int32_t Bgbit;      /* log2 gadget base */
+    int32_t ks_t;       /* key-switch length */
+    int32_t ks_basebit; /* log2 key-switch base */
+    double ks_stdev;    /* LWE / fresh-ciphertext / key-switch-key noise */
+    double bk_stdev;    /* bootstrapping-key noise */
+} eoc_params;
+
+/* gate opcodes: libtfhe's boots* family (SURVEY.md 8a a1,a2) */
+enum eoc_op {
+    EOC_NAND = 0, EOC_AND = 1, EOC_OR = 2, EOC_NOR = 3, EOC_XOR = 4, EOC_XNOR = 5,
+    EOC_ANDNY = 6, EOC_ANDYN = 7, EOC_ORNY = 8, EOC_ORYN = 9, EOC_MUX = 10,
+    EOC_NOT = 11, EOC_COPY = 12
+};
+
+/* error codes (all negative) */
+enum {
+    EOC_OK = 0, EOC_ERR_ARG = -1, EOC_ERR_NO_DEVICE = -2, EOC_ERR_HIP = -3, EOC_ERR_NO_KEY = -4,
+    EOC_ERR_ALLOC = -5, EOC_ERR_STATE = -6
+};
+
+/* replaces new_default_gate_bootstrapping_parameters(minimum_lambda) (eoc-tfhe-run.cpp:230).
+ * set 0 = "A" (n=500, l=2, Bgbit=10; BASELINE.json's numbers), set 1 = "B" (n=630, l=3, Bgbit=7;
+ * what minimum_lambda=128 selects at the pinned libtfhe).  eoc_params_for_lambda mirrors the
+ * lambda switch: lambda <= 80 -> A, 81..128 -> B, else error. */
+int eoc_default_params(int set, eoc_params *out);
+int eoc_params_for_lambda(int minimum_lambda, eoc_params *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * client side (CPU): keys, encryption, decryption
+ * replaces new_random_gate_bootstrapping_secret_keyset (eoc-tfhe-run.cpp:231), bootsSymEncrypt /
+ * bootsSymDecrypt (upstream), lweSymEncrypt / lwePhase (eoc-tfhe-run.cpp:149,161,291,411)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct eoc_secret_key eoc_secret_key; /* TFheGateBootstrappingSecretKeySet */
+
+int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key, eoc_secret_key **out);
+void eoc_secret_key_free(eoc_secret_key *sk);
+const eoc_params *eoc_sk_params(const eoc_secret_key *sk);
+const int32_t *eoc_sk_lwe_key(const eoc_secret_key *sk);  /* [n]   bits */
+const int32_t *eoc_sk_tlwe_key(const eoc_secret_key *sk); /* [N]   bits */
+const int32_t *eoc_sk_bk(const eoc_secret_key *sk);       /* [n][2l][2][N] torus32, or NULL */
+const int32_t *eoc_sk_ksk(const eoc_secret_key *sk);      /* [N*t*(base-1)][n+1], or NULL */
+size_t eoc_bk_len(const eoc_params *p);                   /* int32 count of the two arrays above */
+size_t eoc_ksk_len(const eoc_params *p);
+
+/* bits[count] -> cts[count][n+1]; sample s uses stream (enc_seed, first_idx + s) */
+int eoc_encrypt_bits(const eoc_secret_key *sk, uint64_t enc_seed, uint64_t first_idx,
+                     const uint8_t *bits, size_t count, int32_t *cts);
+int eoc_decrypt_bits(const eoc_secret_key *sk, const int32_t *cts, size_t count, uint8_t *bits);
+/* lweSymEncrypt / lwePhase with an arbitrary message and noise (eoc-tfhe-run.cpp:149,161) */
+int eoc_lwe_encrypt(const eoc_secret_key *sk, uint64_t enc_seed, uint64_t idx, int32_t mu,
+                    double sigma, int32_t *ct);
+int32_t eoc_lwe_phase(const eoc_secret_key *sk, const int32_t *ct);
+/* modSwitchToTorus32 / modSwitchFromTorus32 (eoc-tfhe-run.cpp:145,162) */
+int32_t eoc_modswitch_to_torus32(int32_t mu, int32_t Msize);
+int32_t eoc_modswitch_from_torus32(int32_t phase, int32_t Msize);
+
+/* ------------------------------------------------------------------------------------------------
+ * engine API (one engine per GPU; device pointers; asynchronous on `hip_stream`)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct eoc_engine eoc_engine;
+
+int eoc_device_count(void);
+int eoc_engine_create(int device, const eoc_params *p, eoc_engine **out);
+void eoc_engine_destroy(eoc_engine *e);
+const char *eoc_last_error(void);
+
+/* raw HBM buffers for hosts that have no allocator of their own (a Lua/Node host; tests) */
+int eoc_device_alloc(eoc_engine *e, size_t bytes, void **d_ptr);
+int eoc_device_free(eoc_engine *e, void *d_ptr);
+int eoc_host_to_device(eoc_engine *e, void *d_dst, const void *src, size_t bytes);
+int eoc_device_to_host(eoc_engine *e, void *dst, const void *d_src, size_t bytes);
+int eoc_engine_synchronize(eoc_engine *e);
+
+/* device-side key image sizes in bytes: BK-FFT [n][2l][2][512] complex f64 (bin order sigma),
+ * KSK [N*t][base][n1p] int32 (row d = 0 all-zero, rows padded to n1p = eoc_ksk_row_stride) */
+size_t eoc_bkfft_bytes(const eoc_params *p);
+size_t eoc_ksk_dev_bytes(const eoc_params *p);
+size_t eoc_ksk_row_stride(const eoc_params *p);
+
+/* host torus-form keys -> device images (H2D, pad KSK, forward-transform BK on the GPU).
+ * Replaces new_LweBootstrappingKeyFFT / tGswToFFTConvert.  Synchronous. */
+int eoc_engine_load_cloud_key(eoc_engine *e, const int32_t *bk, const int32_t *ksk);
+/* adopt caller-owned device images (e.g. buffers filled by an RCCL broadcast); not freed by the
+ * engine; must stay valid while the engine uses them */
+int eoc_engine_set_cloud_key_device(eoc_engine *e, const void *d_bkfft, const void *d_ksk);
+/* borrow the engine's images (for broadcasting them, or for parity checks) */
+int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void **d_ksk);
+
+/* one homogeneous or mixed batch of independent gates, all operands resident on the device.
+ *   op      : opcode when ops == NULL
+ *   ops     : HOST array [count] of opcodes, or NULL
+ *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX)
+ *   d_out   : DEVICE array  [count][n+1] int32
+ * bootsNAND ... bootsMUX over a batch.  Asynchronous on hip_stream (NULL = default stream). */
+int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
+                          const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
+                          void *hip_stream);
+
+/* netlist evaluation: `instances` independent copies of one circuit.
+ * wires: DEVICE array [n_wires][instances][n+1]; gate g reads wires in0,in1,in2 and writes out.
+ * Gates must be topologically ordered; the engine levelises them and batches every level. */
+typedef struct eoc_gate {
+    int32_t op;
+    int32_t in0, in1, in2; /* wire ids (unused = -1) */
+    int32_t out;
+} eoc_gate;
+int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size_t n_gates, int32_t *d_wires,
+                           size_t n_wires, size_t instances, void *hip_stream);
+/* number of bootstraps (blind rotations) a netlist costs per instance: MUX = 2, NOT/COPY = 0 */
+size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
+
+/* building blocks exposed for parity tests and profiling (device pointers, async) */
+int eoc_dbg_fft_fwd_device(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count,
+                           void *hip_stream);
+int eoc_dbg_fft_inv_device(eoc_engine *e, const double *d_specs, int32_t *d_polys, size_t count,
+                           void *hip_stream);
+/* t[count][n+1] -> u[count][N+1]  (tfhe_blindRotateAndExtract_FFT, mu = 1/8) */
+int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_t *d_u, size_t count,
+                            void *hip_stream);
+/* u[count][N+1] -> out[count][n+1]  (lweKeySwitch) */
+int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *d_out, size_t count,
+                         void *hip_stream);
+/* last launch statistics: kernel names/grids are in the rocprof trace; this returns counters the
+ * host keeps: [0] batches, [1] bootstraps, [2] keyswitches */
+int eoc_engine_stats(eoc_engine *e, uint64_t out[3]);
+
+/* ------------------------------------------------------------------------------------------------
+ * batch API (host buffers; synchronous: H2D, kernels, D2H).  Uses the global engine on device 0
+ * unless eoc_gpu_init() chose another one.
+ * ---------------------------------------------------------------------------------------------- */
+int eoc_gpu_init(int device, const eoc_params *p);     /* create the global engine */
+int eoc_upload_cloud_key(const eoc_secret_key *sk);    /* push sk's BK/KSK to the global engine */
+eoc_engine *eoc_global_engine(void);
+void eoc_gpu_shutdown(void);
+int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
+                   const int32_t *in2, int32_t *out, size_t count);
+int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,
+                    size_t instances);
+
+/* ------------------------------------------------------------------------------------------------
+ * string API (reference style; global key context)
+ * ---------------------------------------------------------------------------------------------- */
+/* like generateSecretKey (eoc-tfhe-run.cpp:214-250) but for the Boolean path: creates the global
+ * secret + cloud key from `seed`, brings up the GPU engine and uploads the cloud key.  Returns a
+ * short base64 token describing the key (params + seed), NULL if a key already exists
+ * (eoc-tfhe-run.cpp:245-249) or on error. */
+const char *generateGateKey(int minimum_lambda, uint64_t seed);
+void resetGateKey(void);
+/* bootsSymEncrypt / bootsSymDecrypt on base64(export_lweSample_toStream bytes):
+ * little-endian a[n] | b | f64 current_variance  (eoc-tfhe-run.cpp:293-295) */
+const char *encryptBit(int bit, const char *base64SecretKey);
+int decryptBit(const char *base64Ciphertext, const char *base64SecretKey);
+/* boots* gates, signature style of addCiphertexts (eoc-tfhe-run.cpp:427) */
+const char *gateNAND(const char *ct1, const char *ct2, const char *base64PublicKey);
+const char *gateAND(const char *ct1, const char *ct2, const char *base64PublicKey);
+const char *gateOR(const char *ct1, const char *ct2, const char *base64PublicKey);
+const char *gateNOR(const char *ct1, const char *ct2, const char *base64PublicKey);
+const char *gateXOR(const char *ct1, const char *ct2, const char *base64PublicKey);
+const char *gateXNOR(const char *ct1, const char *ct2, const char *base64PublicKey);
+const char *gateNOT(const char *ct1, const char *base64PublicKey);
+const char *gateMUX(const char *ct1, const char *ct2, const char *ct3, const char *base64PublicKey);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOC_TFHE_GPU_H */

@@ -1,0 +1,205 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bit-exact (integer / Torus32) everywhere; spectra compare as exact binary64 values.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpu_util import dev_empty, sync, to_dev, torch_cuda
+
+pytestmark = pytest.mark.gpu
+N = 1024
+
+
+@pytest.fixture(scope="module")
+def eoc(built_lib):
+    torch_cuda()
+    import eoc_tfhe_amd
+    return eoc_tfhe_amd
+
+
+class Rig:
+    """Oracle keys + product keys + engine for one parameter set (optionally reduced n)."""
+
+    def __init__(self, eoc, pset, seed, n_override=None):
+        self.eoc = eoc
+        self.orc = ol.Oracle(pset, seed, n_override=n_override)
+        p = eoc.default_params(pset)
+        if n_override is not None:
+            p.n = n_override
+        self.p = p
+        self.sk = eoc.SecretKey(p, seed)
+        self.eng = eoc.Engine(p)
+        self.eng.load_cloud_key(self.sk)
+        self.n = p.n
+
+    def gate(self, op, c0, c1=None, c2=None, ops=None):
+        torch = torch_cuda()
+        d0 = to_dev(c0)
+        d1 = None if c1 is None else to_dev(c1)
+        d2 = None if c2 is None else to_dev(c2)
+        out = torch.empty_like(d0)
+        self.eng.gate_batch_device(op, d0.data_ptr(), None if d1 is None else d1.data_ptr(),
+                                   None if d2 is None else d2.data_ptr(), out.data_ptr(), d0.shape[0], ops=ops)
+        sync()
+        return out.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def rig_small(eoc):
+    return Rig(eoc, 0, 7, n_override=24)
+
+
+@pytest.fixture(scope="module")
+def rig_small_b(eoc):
+    return Rig(eoc, 1, 9, n_override=20)
+
+
+@pytest.fixture(scope="module")
+def rig_a(eoc):
+    return Rig(eoc, 0, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_native_library_loaded(eoc):
+    """the HIP extension is the thing under test, not a fallback"""
+    import ctypes
+    assert eoc.lib().eoc_device_count() >= 1
+    assert isinstance(eoc.lib(), ctypes.CDLL)
+
+
+def test_fft_forward_inverse_bit_exact(eoc, rig_small):
+    rng = np.random.default_rng(11)
+    polys = np.concatenate([
+        rng.integers(-512, 512, (5, N)),
+        rng.integers(-2**31, 2**31, (5, N)),
+        np.zeros((1, N)), np.full((1, N), -2**31), np.full((1, N), 2**31 - 1),
+    ]).astype(np.int32)
+    d_p = to_dev(polys)
+    d_s = dev_empty((polys.shape[0], N), torch_cuda().float64)
+    rig_small.eng.fft_fwd_device(d_p.data_ptr(), d_s.data_ptr(), polys.shape[0])
+    sync()
+    got = d_s.cpu().numpy()
+    want = np.stack([ol.fft_fwd(p) for p in polys])
+    assert np.array_equal(got, want), f"max |diff| = {np.abs(got - want).max()}"
+    # inverse on products of spectra (full-magnitude values)
+    specs = want.view(np.complex128)
+    prod = np.stack([specs[i] * specs[5 + i] for i in range(5)]).view(np.float64)
+    d_in = to_dev(prod)
+    d_out = dev_empty((5, N), torch_cuda().int32)
+    rig_small.eng.fft_inv_device(d_in.data_ptr(), d_out.data_ptr(), 5)
+    sync()
+    got_i = d_out.cpu().numpy()
+    want_i = np.stack([ol.fft_inv(s) for s in prod])
+    assert np.array_equal(got_i, want_i)
+
+
+def test_keygen_and_bkfft_parity(eoc, rig_small):
+    r = rig_small
+    assert np.array_equal(r.sk.lwe_key, r.orc.lwe_key)
+    assert np.array_equal(r.sk.tlwe_key, r.orc.tlwe_key)
+    assert np.array_equal(r.sk.bk, r.orc.bk)
+    assert np.array_equal(r.sk.ksk, r.orc.ksk)
+    d_bk, d_ksk = r.eng.cloud_key_device()
+    got = r.eng.download(d_bk, r.eng.bkfft_bytes, np.float64).reshape(r.orc.bkfft.shape)
+    assert np.array_equal(got, r.orc.bkfft)
+    # KSK device image: [N*t][base][n1p], row d = 0 and the padding are zero
+    p = r.p
+    base, n1p = 1 << p.ks_basebit, (p.n + 1 + 63) // 64 * 64
+    img = r.eng.download(d_ksk, r.eng.ksk_dev_bytes, np.int32).reshape(N * p.ks_t, base, n1p)
+    assert not img[:, 0, :].any() and not img[:, :, p.n + 1:].any()
+    assert np.array_equal(img[:, 1:, : p.n + 1].reshape(-1, p.n + 1), r.orc.ksk)
+
+
+def _rand_cts(rig, count, enc_seed, first=0):
+    bits = np.random.default_rng(enc_seed).integers(0, 2, count)
+    return bits, rig.sk.encrypt_bits(bits, enc_seed, first)
+
+
+@pytest.mark.parametrize("which", ["A", "B"])
+def test_blind_rotate_and_keyswitch_small(eoc, rig_small, rig_small_b, which):
+    r = rig_small if which == "A" else rig_small_b
+    torch = torch_cuda()
+    rng = np.random.default_rng(5)
+    cnt = 7  # odd: exercises the idle wave pair
+    t = rng.integers(-2**31, 2**31, (cnt, r.n + 1)).astype(np.int32)
+    t[0, :] = 0          # all bara = 0 (every step skipped upstream)
+    t[1, : r.n] = 0      # only barb
+    d_t = to_dev(t)
+    d_u = dev_empty((cnt, N + 1), torch.int32)
+    r.eng.blind_rotate_device(d_t.data_ptr(), d_u.data_ptr(), cnt)
+    sync()
+    got = d_u.cpu().numpy()
+    want = np.stack([r.orc.blind_rotate_extract(x) for x in t])
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    d_o = dev_empty((cnt, r.n + 1), torch.int32)
+    r.eng.keyswitch_device(d_u.data_ptr(), d_o.data_ptr(), cnt)
+    sync()
+    want_ks = np.stack([r.orc.keyswitch(x) for x in want])
+    assert np.array_equal(d_o.cpu().numpy(), want_ks)
+
+
+@pytest.mark.parametrize("name", ["NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN"])
+def test_gates_small_bit_exact(eoc, rig_small, name):
+    r = rig_small
+    b0, c0 = _rand_cts(r, 9, 21)
+    b1, c1 = _rand_cts(r, 9, 22, 100)
+    got = r.gate(eoc.OPS[name], c0, c1)
+    want = r.orc.gate_batch(ol.OPS[name], c0, c1)
+    assert np.array_equal(got, want)
+
+
+def test_mux_not_copy_small(eoc, rig_small):
+    r = rig_small
+    _, a = _rand_cts(r, 5, 31)
+    _, b = _rand_cts(r, 5, 32, 50)
+    _, c = _rand_cts(r, 5, 33, 90)
+    assert np.array_equal(r.gate(eoc.OPS["MUX"], a, b, c), r.orc.gate_batch(ol.OPS["MUX"], a, b, c))
+    assert np.array_equal(r.gate(eoc.OPS["NOT"], a), r.orc.gate_batch(ol.OPS["NOT"], a))
+    assert np.array_equal(r.gate(eoc.OPS["COPY"], a), a)
+
+
+def test_mixed_ops_small(eoc, rig_small):
+    r = rig_small
+    cnt = 12
+    _, a = _rand_cts(r, cnt, 41)
+    _, b = _rand_cts(r, cnt, 42, 50)
+    _, c = _rand_cts(r, cnt, 43, 90)
+    ops = np.array([0, 0, 4, 4, 4, 10, 10, 0, 11, 2, 10, 4], np.uint8)
+    got = r.gate(0, a, b, c, ops=ops)
+    want = r.orc.gate_batch(0, a, b, c, ops=ops)
+    assert np.array_equal(got, want)
+
+
+def test_full_size_set_a_truth_tables_and_parity(eoc, rig_a):
+    """Set A (n=500): all four input combinations of every 2-input gate decrypt to the truth table,
+    and the ciphertexts equal the oracle's bit for bit."""
+    r = rig_a
+    bits0 = np.array([0, 0, 1, 1]); bits1 = np.array([0, 1, 0, 1])
+    c0 = r.sk.encrypt_bits(bits0, 2, 0)
+    c1 = r.sk.encrypt_bits(bits1, 2, 100)
+    assert np.array_equal(c0, r.orc.encrypt_bits(bits0, 2, 0))
+    tt = dict(NAND=1 - (bits0 & bits1), AND=bits0 & bits1, OR=bits0 | bits1, NOR=1 - (bits0 | bits1),
+              XOR=bits0 ^ bits1, XNOR=1 - (bits0 ^ bits1), ANDNY=(1 - bits0) & bits1, ANDYN=bits0 & (1 - bits1),
+              ORNY=(1 - bits0) | bits1, ORYN=bits0 | (1 - bits1))
+    for name, want_bits in tt.items():
+        got = r.gate(eoc.OPS[name], c0, c1)
+        assert np.array_equal(r.sk.decrypt_bits(got), want_bits), name
+        assert np.array_equal(got, r.orc.gate_batch(ol.OPS[name], c0, c1)), name
+
+
+def test_full_size_batch_parity_set_a(eoc, rig_a):
+    """BASELINE config 2 shape at a size the oracle finishes in seconds: 96 NAND gates, bit-exact;
+    then 1024 gates checked by decryption (truth) and by re-running a slice through the oracle."""
+    r = rig_a
+    cnt = 1024
+    b0, c0 = _rand_cts(r, cnt, 2, 0)
+    b1, c1 = _rand_cts(r, cnt, 3, 0)
+    got = r.gate(eoc.OPS["NAND"], c0, c1)
+    assert np.array_equal(r.sk.decrypt_bits(got), 1 - (b0 & b1))
+    sl = slice(0, 96)
+    assert np.array_equal(got[sl], r.orc.gate_batch(ol.OPS["NAND"], c0[sl], c1[sl]))
+    # determinism: same inputs, same bits
+    assert np.array_equal(got, r.gate(eoc.OPS["NAND"], c0, c1))
