@@ -43,6 +43,29 @@ class Gate(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7); if our library pulled /opt/rocm's copy in first, a later `import torch`
+    would load a second runtime and one of the two would see no device.  Pre-loading torch's copy
+    (when torch is installed) makes both resolve to the same one, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the C-ABI library (fails loudly when it has not been built)."""
     global _lib
@@ -51,6 +74,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise EocError(f"{LIB_PATH} is missing: run `python -m eoc_tfhe_amd.build` "
                        "(there is no Python/CPU fallback for the gate path)")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     PP = C.POINTER(Params)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
@@ -86,6 +110,9 @@ def lib():
         "eoc_ksk_row_stride": (sz, [PP]),
         "eoc_engine_load_cloud_key": (C.c_int, [vp, vp, vp]),
         "eoc_engine_set_cloud_key_device": (C.c_int, [vp, vp, vp]),
+        "eoc_engine_build_cloud_key_device": (C.c_int, [vp, vp, vp, vp, vp]),
+        "eoc_engine_set_profiling": (C.c_int, [vp, C.c_int]),
+        "eoc_engine_kernel_times": (C.c_int, [vp, C.POINTER(C.c_double * 3), C.POINTER(u64 * 3), C.c_int]),
         "eoc_engine_cloud_key_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "eoc_gate_batch_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, sz, vp]),
         "eoc_circuit_run_device": (C.c_int, [vp, vp, sz, vp, sz, sz, vp]),
@@ -246,6 +273,22 @@ class Engine:
         bk = np.ascontiguousarray(bk, np.int32)
         ksk = np.ascontiguousarray(ksk, np.int32)
         _check(self.L.eoc_engine_load_cloud_key(self.h, bk.ctypes.data, ksk.ctypes.data), "eoc_engine_load_cloud_key")
+
+    def build_cloud_key_device(self, sk, d_bkfft, d_ksk):
+        """Like load_cloud_key but into caller-owned device buffers (e.g. torch tensors)."""
+        bk = np.ascontiguousarray(sk.bk, np.int32)
+        ksk = np.ascontiguousarray(sk.ksk, np.int32)
+        _check(self.L.eoc_engine_build_cloud_key_device(self.h, bk.ctypes.data, ksk.ctypes.data, d_bkfft, d_ksk),
+               "eoc_engine_build_cloud_key_device")
+
+    def set_profiling(self, on=True):
+        _check(self.L.eoc_engine_set_profiling(self.h, int(on)), "eoc_engine_set_profiling")
+
+    def kernel_times(self, reset=True):
+        ms, cnt = (C.c_double * 3)(), (C.c_uint64 * 3)()
+        _check(self.L.eoc_engine_kernel_times(self.h, C.byref(ms), C.byref(cnt), int(reset)), "eoc_engine_kernel_times")
+        names = ("prepare", "blind_rotate", "keyswitch")
+        return {k: dict(ms=ms[i], launches=cnt[i]) for i, k in enumerate(names)}
 
     def set_cloud_key_device(self, d_bkfft, d_ksk):
         _check(self.L.eoc_engine_set_cloud_key_device(self.h, d_bkfft, d_ksk), "eoc_engine_set_cloud_key_device")

@@ -48,7 +48,37 @@ struct eoc_engine {
     size_t ws_descs = 0;
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    double kernel_ms[3] = {0, 0, 0};
+    uint64_t kernel_launches[3] = {0, 0, 0};
     std::mutex mu;
+};
+
+enum { KIND_PREPARE = 0, KIND_BLIND_ROTATE = 1, KIND_KEYSWITCH = 2 };
+
+struct SpanGuard { // records start/stop events around one kernel launch when profiling is on
+    eoc_engine *e;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind;
+    SpanGuard(eoc_engine *e_, hipStream_t st_, int kind_) : e(e_), st(st_), kind(kind_)
+    {
+        if (!e->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            a = b = nullptr;
+            return;
+        }
+        hipEventRecord(a, st);
+    }
+    ~SpanGuard()
+    {
+        if (!a) return;
+        hipEventRecord(b, st);
+        e->spans.push_back({a, b, kind});
+    }
 };
 
 static int valid_params(const eoc_params *p)
@@ -240,42 +270,67 @@ extern "C" int eoc_dbg_fft_inv_device(eoc_engine *e, const double *d_specs, int3
 }
 
 // ---- cloud key ------------------------------------------------------------------------------
+static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_t *ksk, double *d_bkfft,
+                                  int32_t *d_ksk)
+{
+    const eoc_params &p = e->p;
+    // BK: upload the torus form, transform on the GPU (tGswToFFTConvert)
+    const size_t npoly = (size_t)p.n * e->kpl * 2;
+    int32_t *d_bk = nullptr;
+    HIP_TRY(hipMalloc(&d_bk, npoly * kN * 4));
+    if (hipMemcpy(d_bk, bk, npoly * kN * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(d_bk);
+        eoc_set_error("cloud key upload failed");
+        return EOC_ERR_HIP;
+    }
+    int rc = eoc_dbg_fft_fwd_device(e, d_bk, d_bkfft, npoly, nullptr);
+    hipError_t se = hipDeviceSynchronize();
+    hipFree(d_bk);
+    if (rc) return rc;
+    HIP_TRY(se);
+    // KSK: [N*t][base-1][n+1]  ->  [N*t][base][n1p], row 0 and the padding zero
+    const int base = 1 << p.ks_basebit;
+    const size_t groups = (size_t)kN * p.ks_t;
+    HIP_TRY(hipMemset(d_ksk, 0, eoc_ksk_dev_bytes(&p)));
+    for (int d = 1; d < base; d++) {
+        // rows (g, d) for all groups g: strided 2-D copy, one row of (n+1) ints per group
+        HIP_TRY(hipMemcpy2D(d_ksk + (size_t)d * e->n1p, e->n1p * 4 * base, ksk + (size_t)(d - 1) * (p.n + 1),
+                            (size_t)(p.n + 1) * 4 * (base - 1), (size_t)(p.n + 1) * 4, groups,
+                            hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return EOC_OK;
+}
+
 extern "C" int eoc_engine_load_cloud_key(eoc_engine *e, const int32_t *bk, const int32_t *ksk)
 {
     if (!e || !bk || !ksk) return EOC_ERR_ARG;
     std::lock_guard<std::mutex> g(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    const eoc_params &p = e->p;
     if (!e->own_keys) {
-        HIP_TRY(hipMalloc(&e->d_bkfft, eoc_bkfft_bytes(&p)));
-        HIP_TRY(hipMalloc(&e->d_ksk, eoc_ksk_dev_bytes(&p)));
+        HIP_TRY(hipMalloc(&e->d_bkfft, eoc_bkfft_bytes(&e->p)));
+        HIP_TRY(hipMalloc(&e->d_ksk, eoc_ksk_dev_bytes(&e->p)));
         e->own_keys = true;
     }
-    // BK: upload the torus form, transform on the GPU (tGswToFFTConvert)
-    const size_t npoly = (size_t)p.n * e->kpl * 2;
-    int32_t *d_bk = nullptr;
-    HIP_TRY(hipMalloc(&d_bk, npoly * kN * 4));
-    HIP_TRY(hipMemcpy(d_bk, bk, npoly * kN * 4, hipMemcpyHostToDevice));
-    int rc = eoc_dbg_fft_fwd_device(e, d_bk, e->d_bkfft, npoly, nullptr);
-    if (rc) {
-        hipFree(d_bk);
-        return rc;
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    hipFree(d_bk);
-    // KSK: [N*t][base-1][n+1]  ->  [N*t][base][n1p], row 0 and the padding zero
-    const int base = 1 << p.ks_basebit;
-    const size_t groups = (size_t)kN * p.ks_t;
-    HIP_TRY(hipMemset(e->d_ksk, 0, eoc_ksk_dev_bytes(&p)));
-    for (int d = 1; d < base; d++) {
-        // rows (g, d) for all groups g: strided 2-D copy, one row of (n+1) ints per group
-        HIP_TRY(hipMemcpy2D(e->d_ksk + (size_t)d * e->n1p, e->n1p * 4 * base,
-                            ksk + (size_t)(d - 1) * (p.n + 1), (size_t)(p.n + 1) * 4 * (base - 1),
-                            (size_t)(p.n + 1) * 4, groups, hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipDeviceSynchronize());
+    int rc = build_cloud_key_images(e, bk, ksk, e->d_bkfft, e->d_ksk);
+    if (rc) return rc;
     e->bkfft = e->d_bkfft;
     e->ksk = e->d_ksk;
+    return EOC_OK;
+}
+
+// same, into caller-owned device buffers (which the engine then uses); lets the host keep the
+// images in its own allocations, e.g. torch tensors that an RCCL broadcast reads or fills
+extern "C" int eoc_engine_build_cloud_key_device(eoc_engine *e, const int32_t *bk, const int32_t *ksk,
+                                                 void *d_bkfft, void *d_ksk)
+{
+    if (!e || !bk || !ksk || !d_bkfft || !d_ksk) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = build_cloud_key_images(e, bk, ksk, static_cast<double *>(d_bkfft), static_cast<int32_t *>(d_ksk));
+    if (rc) return rc;
+    e->bkfft = static_cast<const double *>(d_bkfft);
+    e->ksk = static_cast<const int32_t *>(d_ksk);
     return EOC_OK;
 }
 
@@ -308,6 +363,7 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     a.bara_stride = e->bara_stride;
     a.mu = (int32_t)(1u << 29);
     dim3 grid((njobs + 1) / 2), block(256);
+    SpanGuard span(e, st, KIND_BLIND_ROTATE);
     switch (e->p.l) {
     case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
     case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
@@ -332,6 +388,7 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
     a.mu = (int32_t)(1u << 29);
     dim3 grid(S, ngates), block(256);
     int ch = (e->p.n + 1 + 255) / 256;
+    SpanGuard span(e, st, KIND_KEYSWITCH);
     switch (ch) {
     case 1: hipLaunchKernelGGL(k_keyswitch<1>, grid, block, 0, st, d_descs, a); break;
     case 2: hipLaunchKernelGGL(k_keyswitch<2>, grid, block, 0, st, d_descs, a); break;
@@ -373,6 +430,7 @@ static int run_level(eoc_engine *e, std::vector<GateDesc> &boot, std::vector<Gat
     HIP_TRY(hipMemcpyAsync(dd, boot.data(), boot.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
     {
         dim3 grid((unsigned)((n + 1 + 255) / 256), (unsigned)(S * (any_mux ? 2 : 1)), (unsigned)boot.size());
+        SpanGuard span(e, st, KIND_PREPARE);
         hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, e->d_bara, e->bara_stride);
         HIP_TRY(hipGetLastError());
     }
@@ -573,6 +631,42 @@ extern "C" int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *
     GateDesc d{OP_RAW, 0, nullptr, nullptr, nullptr, d_out};
     HIP_TRY(hipMemcpyAsync(e->d_descs, &d, sizeof d, hipMemcpyHostToDevice, st));
     return launch_keyswitch(e, e->d_descs, 1, (uint32_t)count, st);
+}
+
+extern "C" int eoc_engine_set_profiling(eoc_engine *e, int on)
+{
+    if (!e) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    e->profiling = on != 0;
+    return EOC_OK;
+}
+
+// drains the recorded event pairs (synchronises the device) and returns accumulated times
+extern "C" int eoc_engine_kernel_times(eoc_engine *e, double ms[3], uint64_t launches[3], int reset)
+{
+    if (!e || !ms || !launches) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto &sp : e->spans) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) {
+            e->kernel_ms[sp.kind] += t;
+            e->kernel_launches[sp.kind] += 1;
+        }
+        hipEventDestroy(sp.a);
+        hipEventDestroy(sp.b);
+    }
+    e->spans.clear();
+    for (int i = 0; i < 3; i++) {
+        ms[i] = e->kernel_ms[i];
+        launches[i] = e->kernel_launches[i];
+        if (reset) {
+            e->kernel_ms[i] = 0;
+            e->kernel_launches[i] = 0;
+        }
+    }
+    return EOC_OK;
 }
 
 extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])

@@ -123,6 +123,10 @@ size_t eoc_ksk_row_stride(const eoc_params *p);
 /* host torus-form keys -> device images (H2D, pad KSK, forward-transform BK on the GPU).
  * Replaces new_LweBootstrappingKeyFFT / tGswToFFTConvert.  Synchronous. */
 int eoc_engine_load_cloud_key(eoc_engine *e, const int32_t *bk, const int32_t *ksk);
+/* same, written into caller-owned device buffers of eoc_bkfft_bytes / eoc_ksk_dev_bytes, which the
+ * engine then uses (not freed by the engine) */
+int eoc_engine_build_cloud_key_device(eoc_engine *e, const int32_t *bk, const int32_t *ksk,
+                                      void *d_bkfft, void *d_ksk);
 /* adopt caller-owned device images (e.g. buffers filled by an RCCL broadcast); not freed by the
  * engine; must stay valid while the engine uses them */
 int eoc_engine_set_cloud_key_device(eoc_engine *e, const void *d_bkfft, const void *d_ksk);
@@ -163,6 +167,10 @@ int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_t *d_u, siz
 /* u[count][N+1] -> out[count][n+1]  (lweKeySwitch) */
 int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *d_out, size_t count,
                          void *hip_stream);
+/* per-kernel timing with HIP events recorded on the launch stream.  kinds: [0] prepare,
+ * [1] blind_rotate, [2] keyswitch.  eoc_engine_kernel_times synchronises the device. */
+int eoc_engine_set_profiling(eoc_engine *e, int on);
+int eoc_engine_kernel_times(eoc_engine *e, double ms[3], uint64_t launches[3], int reset);
 /* last launch statistics: kernel names/grids are in the rocprof trace; this returns counters the
  * host keeps: [0] batches, [1] bootstraps, [2] keyswitches */
 int eoc_engine_stats(eoc_engine *e, uint64_t out[3]);
