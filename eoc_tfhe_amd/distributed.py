@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm).
+
+The path shards naturally: every gate / circuit instance is independent given the
+cloud key, so ranks take contiguous blocks of instances and the only collective is the one-time
+broadcast of the two key images (BK-FFT, KSK) from rank 0 over xGMI.  No steady-state collective.
+The same functions run under the "gloo" backend on CPU tensors (tests/test_distributed_cpu.py).
+"""
+import os
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank, dist)."""
+    rank, world, local_rank = env_rank()
+    if world == 1:
+        return rank, world, local_rank, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return rank, world, local_rank, dist
+
+
+def shard(total, rank, world):
+    """Contiguous block [lo, hi) of `total` independent instances owned by `rank`; blocks differ by
+    at most one instance and cover [0, total) exactly once."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_key_images(dist, tensors, src=0):
+    """One broadcast per key image (BK-FFT, KSK) from `src`; returns seconds spent."""
+    import time
+    import torch
+    if dist is None:
+        return 0.0
+    if tensors and tensors[0].is_cuda:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for t in tensors:
+        dist.broadcast(t, src=src)
+    if tensors and tensors[0].is_cuda:
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def gather_blocks(dist, local, total, rank, world):
+    """All-gather ragged contiguous blocks (rows) back into one [total, ...] tensor (used by tests and
+    by hosts that want the whole result on every rank; the benchmark never needs it)."""
+    import torch
+    if dist is None:
+        return local
+    sizes = [shard(total, r, world) for r in range(world)]
+    maxlen = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxlen,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([outs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)

@@ -1,0 +1,128 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol,
+client-side functions agree with the oracle bit for bit, the hot path refuses to run without a GPU."""
+import base64
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 1024
+
+
+@pytest.fixture(scope="module")
+def eoc(built_lib):
+    import eoc_tfhe_amd
+    return eoc_tfhe_amd
+
+
+def test_library_exports_every_declared_symbol(eoc):
+    syms = eoc.abi_symbols()
+    assert len(syms) >= 50 and "eoc_gate_batch_device" in syms and "gateNAND" in syms
+    lib = eoc.lib()
+    assert [s for s in syms if not hasattr(lib, s)] == []
+
+
+def test_twiddle_tables_identical_and_pinned():
+    import hashlib
+    a = open(os.path.join(ROOT, "oracle", "canon_twiddles.h")).read()
+    b = open(os.path.join(ROOT, "eoc_tfhe_amd", "csrc", "canon_twiddles.h")).read()
+    assert a == b
+    vals = re.findall(r"\{(\S+), (\S+)\}", a)
+    assert len(vals) == 1024
+    tab = np.array([[float.fromhex(c), float.fromhex(s)] for c, s in vals])
+    k = np.arange(1024)
+    assert np.abs(tab[:, 0] - np.cos(np.pi * k / 1024)).max() < 4e-16
+    assert np.abs(tab[:, 1] - np.sin(np.pi * k / 1024)).max() < 4e-16
+    assert tab[0].tolist() == [1.0, 0.0] and tab[512].tolist() == [0.0, 1.0] and tab[256, 0] == tab[256, 1]
+    assert hashlib.sha256(tab.tobytes()).hexdigest() == \
+        "e2258706aa14d5f4346fdd6433ab56676613dc50847456f5f4d3c847fc3218fe"
+
+
+def test_params(eoc):
+    a, b = eoc.default_params(0), eoc.default_params(1)
+    assert (a.n, a.l, a.Bgbit, a.ks_t, a.ks_basebit) == (500, 2, 10, 8, 2)
+    assert (b.n, b.l, b.Bgbit, b.ks_t, b.ks_basebit) == (630, 3, 7, 8, 2)
+    assert a.ks_stdev == 2.44e-5 and b.ks_stdev == 2.0**-15 and b.bk_stdev == 2.0**-25
+    import ctypes as C
+    p = eoc.Params()
+    L = eoc.lib()
+    assert L.eoc_params_for_lambda(80, C.byref(p)) == 0 and p.n == 500
+    assert L.eoc_params_for_lambda(110, C.byref(p)) == 0 and p.n == 630   # what lambda=110 really selects
+    assert L.eoc_params_for_lambda(128, C.byref(p)) == 0 and p.n == 630   # the reference's minimum_lambda
+    assert L.eoc_params_for_lambda(129, C.byref(p)) < 0 and L.eoc_params_for_lambda(0, C.byref(p)) < 0
+
+
+@pytest.mark.parametrize("pset,n", [(0, 16), (1, 12), (0, None)])
+def test_keygen_encrypt_decrypt_match_oracle(eoc, pset, n):
+    p = eoc.default_params(pset)
+    if n:
+        p.n = n
+    sk = eoc.SecretKey(p, 42)
+    o = ol.Oracle(pset, 42, n_override=n)
+    assert np.array_equal(sk.lwe_key, o.lwe_key) and np.array_equal(sk.tlwe_key, o.tlwe_key)
+    assert np.array_equal(sk.bk, o.bk) and np.array_equal(sk.ksk, o.ksk)
+    bits = np.random.default_rng(1).integers(0, 2, 33)
+    c = sk.encrypt_bits(bits, 5, 17)
+    assert np.array_equal(c, o.encrypt_bits(bits, 5, 17))
+    assert np.array_equal(sk.decrypt_bits(c), bits) and np.array_equal(o.decrypt_bits(c), bits)
+    assert sk.phase(c[0]) == o.phases(c[:1])[0]
+    L = eoc.lib()
+    for mu, M in [(1, 8), (-1, 8), (42, 2**31 - 1), (-7, 12345)]:
+        assert L.eoc_modswitch_to_torus32(mu, M) == ol.lib().orc_modswitch_to_torus32(mu, M)
+    for ph in [0, 1, -1, 2**31 - 1, -2**31, 99999999]:
+        assert L.eoc_modswitch_from_torus32(ph, 2048) == ol.lib().orc_modswitch_from_torus32(ph, 2048)
+
+
+def test_key_image_sizes(eoc):
+    import ctypes as C
+    L = eoc.lib()
+    a = eoc.default_params(0)
+    assert L.eoc_bkfft_bytes(C.byref(a)) == 32_768_000            # SURVEY.md 8(d), Set A
+    assert L.eoc_ksk_row_stride(C.byref(a)) == 512
+    assert L.eoc_ksk_dev_bytes(C.byref(a)) == 1024 * 8 * 4 * 512 * 4
+    b = eoc.default_params(1)
+    assert L.eoc_bkfft_bytes(C.byref(b)) == 61_931_520            # Set B
+    assert L.eoc_bk_len(C.byref(a)) == 500 * 4 * 2 * 1024 and L.eoc_ksk_len(C.byref(a)) == 1024 * 8 * 3 * 501
+
+
+def test_hot_path_fails_loudly_without_gpu(eoc):
+    """no CPU fallback: on a box without a GPU every gate entry point errors out"""
+    import ctypes as C
+    L = eoc.lib()
+    if L.eoc_device_count() > 0:
+        pytest.skip("GPU present")
+    p = eoc.default_params(0)
+    with pytest.raises(eoc.EocError, match="no usable HIP device"):
+        eoc.Engine(p)
+    with pytest.raises(eoc.EocError):
+        eoc.gpu_init(p)
+    x = np.zeros((1, 501), np.int32)
+    with pytest.raises(eoc.EocError, match="no CPU fallback"):
+        eoc.gate_batch(0, x, x)
+    # string API: reference behaviour -- NULL (None) + message on stderr
+    assert eoc.Tfhe.encryptBit(1) is None
+    assert eoc.Tfhe.decryptBit("AAAA") == -1
+    assert eoc.Tfhe.nand("AAAA", "AAAA") is None
+    assert eoc.Tfhe.generateGateKey(80, 1) is None   # cannot bring the engine up
+
+
+def test_circuit_bootstrap_count(eoc):
+    G = eoc.Gate
+    gates = [G(eoc.OPS["XOR"], 0, 1, -1, 2), G(eoc.OPS["MUX"], 0, 1, 2, 3), G(eoc.OPS["NOT"], 3, -1, -1, 4),
+             G(eoc.OPS["AND"], 4, 2, -1, 5)]
+    assert eoc.circuit_bootstraps(gates) == 1 + 2 + 0 + 1
+
+
+def test_shard_partition():
+    from eoc_tfhe_amd.distributed import shard
+    for total in (0, 1, 7, 1024, 2**20, 1000003):
+        for world in (1, 2, 3, 8):
+            blocks = [shard(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,197 @@
+"""CPU tests of the oracle: committed golden vectors, properties that do not need upstream libtfhe
+(SURVEY.md 8c "what pins results instead").  No GPU needed."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N = 1024
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    g = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    a = np.load(os.path.join(HERE, "golden", "golden_arrays.npz"), allow_pickle=False)
+    return g, a
+
+
+@pytest.fixture(scope="module")
+def orc_a():
+    return ol.Oracle(0, 1)
+
+
+def test_prng_and_modswitch_kats(golden):
+    g, _ = golden
+    L = ol.lib()
+    k = L.orc_stream_key(1, 3, 5)
+    assert str(k) == g["prng"]["stream_key(1,3,5)"]
+    assert [str(L.orc_rng_u64(k, i)) for i in range(4)] == g["prng"]["u64(key(1,3,5),0..3)"]
+    k2 = L.orc_stream_key(9, 5, 0)
+    assert [int(L.orc_gaussian32(k2, 10 + 2 * i, 0, 2.44e-5)) for i in range(4)] == \
+        g["prng"]["gaussian32(key(9,5,0),ctr=10,mu=0,sigma=2.44e-5)x4"]
+    m = g["modswitch"]
+    assert L.orc_modswitch_to_torus32(1, 8) == m["to(1,8)"] == 2**29
+    assert L.orc_modswitch_to_torus32(-1, 8) == m["to(-1,8)"] == -2**29
+    assert L.orc_modswitch_to_torus32(1, 4) == m["to(1,4)"] == 2**30
+    # the reference's own use: Msize = 2^31-1 round trip (eoc-tfhe-run.cpp:290,412; tests/tfhe.test.js:103 pins 42)
+    assert m["from(to(42,M),M)"] == 42
+    assert L.orc_modswitch_from_torus32(L.orc_modswitch_to_torus32(42, 2**31 - 1), 2**31 - 1) == 42
+    assert L.orc_modswitch_from_torus32(-1, 2048) == m["from(-1,2048)"] == 0
+    assert L.orc_modswitch_from_torus32(2**20 - 1, 2048) == 0
+    assert L.orc_modswitch_from_torus32(2**20, 2048) == 1
+    for phase in [0, 1, -1, 2**31 - 1, -2**31, 123456789, -987654321, 2**20, 2**21 + 2**20 - 1]:
+        want = ((phase + 2**20) >> 21) & 2047
+        assert L.orc_modswitch_from_torus32(phase, 2048) == want
+
+
+def test_transform_golden_and_properties(golden):
+    g, a = golden
+    fs = ol.fft_fwd(a["fft_small_in"])
+    fb = ol.fft_fwd(a["fft_big_in"])
+    assert np.array_equal(fs, a["fft_small_spec"])
+    assert sha(fs) == g["fft"]["small_spec_sha"] and sha(fb) == g["fft"]["big_spec_sha"]
+    prod = (fs.view(np.complex128) * fb.view(np.complex128)).view(np.float64)
+    assert np.array_equal(ol.fft_inv(prod), a["fft_prod_inv"])
+    # round trip is the identity on full-range torus polynomials
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        p = rng.integers(-2**31, 2**31, N).astype(np.int32)
+        assert np.array_equal(ol.fft_inv(ol.fft_fwd(p)), p)
+    # linearity of the forward map on small integers is exact
+    x = rng.integers(-512, 512, N).astype(np.int32)
+    y = rng.integers(-512, 512, N).astype(np.int32)
+    assert np.allclose(ol.fft_fwd(x) + ol.fft_fwd(y), ol.fft_fwd(x + y), rtol=0, atol=1e-6)
+    # X * p is a negacyclic shift: spectrum of X^1 times spectrum of p
+    X1 = np.zeros(N, np.int32); X1[1] = 1
+    sp = (ol.fft_fwd(X1).view(np.complex128) * ol.fft_fwd(x).view(np.complex128)).view(np.float64)
+    want = np.concatenate([[-x[-1]], x[:-1]]).astype(np.int32)
+    assert np.array_equal(ol.fft_inv(sp), want)
+
+
+def _schoolbook(a, b):
+    full = np.zeros(2 * N, dtype=object)
+    bo = b.astype(object)
+    for m in range(N):
+        if a[m]:
+            full[m:m + N] += int(a[m]) * bo
+    neg = full[:N] - full[N:]
+    return np.array([int(v) % 2**32 for v in neg], dtype=np.uint64).astype(np.uint32).astype(np.int32)
+
+
+def test_fft_product_vs_exact_schoolbook():
+    """T2: the FP64 transform path equals the exact negacyclic product mod 2^32 up to a few LSB at
+    the magnitudes of an external product (digits x full-range torus)."""
+    rng = np.random.default_rng(8)
+    worst = 0
+    for Bg in (1024, 128):
+        d = rng.integers(-Bg // 2, Bg // 2, N).astype(np.int32)
+        t = rng.integers(-2**31, 2**31, N).astype(np.int32)
+        got = ol.fft_inv((ol.fft_fwd(d).view(np.complex128) * ol.fft_fwd(t).view(np.complex128)).view(np.float64))
+        dev = (got.astype(np.int64) - _schoolbook(d, t).astype(np.int64) + 2**31) % 2**32 - 2**31
+        worst = max(worst, int(np.abs(dev).max()))
+    assert worst <= 4, worst
+
+
+def test_keys_match_golden(golden, orc_a):
+    g, _ = golden
+    o = orc_a
+    e = g["A"]
+    assert (o.n, o.l) == (e["n"], e["l"]) == (500, 2)
+    assert sha(o.lwe_key) == e["lwe_key_sha"] and sha(o.tlwe_key) == e["tlwe_key_sha"]
+    assert sha(o.bk) == e["bk_sha"] and sha(o.ksk) == e["ksk_sha"]
+    assert sha(o.bkfft + 0.0) == e["bkfft_sha"]
+    # TGSW structure: phase of every BK row is small noise + s_i * gadget on the diagonal
+    i, row = 3, 1
+    a, b = o.bk[i, row, 0].astype(np.int64), o.bk[i, row, 1].astype(np.int64)
+    s = o.tlwe_key.astype(object)
+    full = np.zeros(2 * N, dtype=object)
+    for m in range(N):
+        if s[m]:
+            full[m:m + N] += a.astype(object)
+    sa = np.array([int(v) for v in (full[:N] - full[N:])], dtype=object)
+    phase = np.array([(int(b[j]) - int(sa[j]) + 2**31) % 2**32 - 2**31 for j in range(N)], dtype=np.int64)
+    q, pp = row // o.l, row % o.l + 1
+    h = int(o.lwe_key[i]) << (32 - pp * o.p.Bgbit)
+    if q == 1:
+        phase[0] -= h                                   # message on the body: + s_i * h
+    else:
+        phase += h * o.tlwe_key.astype(np.int64)        # message on the mask:  - s_i * h * s(X)
+    assert np.abs(phase).max() < 2**32 * 7.18e-9 * 8  # 8 sigma
+
+
+def test_gates_match_golden_set_a(golden, orc_a):
+    g, a = golden
+    o = orc_a
+    c0, c1, c2 = a["A_c0"], a["A_c1"], a["A_c2"]
+    assert np.array_equal(o.encrypt_bits([0, 0, 1, 1], 2, 0), c0)
+    assert np.array_equal(o.encrypt_bits([0, 1, 0, 1], 2, 100), c1)
+    b0, b1, b2 = np.array([0, 0, 1, 1]), np.array([0, 1, 0, 1]), np.array([1, 0, 0, 1])
+    tt = dict(NAND=1 - (b0 & b1), AND=b0 & b1, OR=b0 | b1, NOR=1 - (b0 | b1), XOR=b0 ^ b1, XNOR=1 - (b0 ^ b1),
+              ANDNY=(1 - b0) & b1, ANDYN=b0 & (1 - b1), ORNY=(1 - b0) | b1, ORYN=b0 | (1 - b1),
+              MUX=np.where(b0 == 1, b1, b2), NOT=1 - b0)
+    for name, want in tt.items():
+        out = o.gate_batch(ol.OPS[name], c0, None if name == "NOT" else c1, c2 if name == "MUX" else None)
+        assert sha(out) == g["A"]["gates"][name]["sha"], name
+        assert o.decrypt_bits(out).tolist() == want.tolist() == g["A"]["gates"][name]["bits"], name
+    assert np.array_equal(o.gate_batch(ol.OPS["NAND"], c0, c1), a["A_NAND_out"])
+    t = o.gate_linear(ol.OPS["NAND"], c0[3], c1[3])
+    assert np.array_equal(o.blind_rotate_extract(t), a["A_nand_11_u"])
+
+
+def test_gates_match_golden_set_b(golden):
+    g, a = golden
+    o = ol.Oracle(1, 1)
+    e = g["B"]
+    assert (o.n, o.l) == (630, 3)
+    assert sha(o.bk) == e["bk_sha"] and sha(o.ksk) == e["ksk_sha"]
+    out = o.gate_batch(ol.OPS["NAND"], a["B_c0"], a["B_c1"])
+    assert np.array_equal(out, a["B_NAND_out"])
+    assert o.decrypt_bits(out).tolist() == [1, 1, 1, 0]
+    assert np.array_equal(o.gate_batch(ol.OPS["MUX"], a["B_c0"], a["B_c1"], a["B_c2"]), a["B_MUX_out"])
+
+
+def test_fft_step_close_to_exact_step(orc_a):
+    """one CMux step: FP64 path vs exact integer external product differ by at most a few LSB"""
+    import ctypes as C
+    o = orc_a
+    rng = np.random.default_rng(4)
+    acc = rng.integers(-2**31, 2**31, 2 * N).astype(np.int32)
+    a1, a2 = acc.copy(), acc.copy()
+    i, abar = 5, 777
+    bkfft_i = np.ascontiguousarray(o.bkfft[i])
+    bk_i = np.ascontiguousarray(o.bk[i])
+    o.L.orc_blind_rotate_step(C.byref(o.p), bkfft_i.ctypes.data, None, abar, a1, 1)
+    o.L.orc_blind_rotate_step(C.byref(o.p), None, bk_i.ctypes.data, abar, a2, 0)
+    dev = (a1.astype(np.int64) - a2.astype(np.int64) + 2**31) % 2**32 - 2**31
+    assert np.abs(dev).max() <= 8, np.abs(dev).max()
+    # a = 0 is the identity on the accumulator (what skipping the step amounts to)
+    a3 = acc.copy()
+    o.L.orc_blind_rotate_step(C.byref(o.p), bkfft_i.ctypes.data, None, 0, a3, 1)
+    assert np.array_equal(a3, acc)
+
+
+def test_bootstrap_noise_and_truth_many(orc_a):
+    """64 random NANDs: every output decrypts correctly and sits within 1/16 of +-1/8
+    (output noise stdev ~ 4e-3 of the torus)."""
+    o = orc_a
+    rng = np.random.default_rng(77)
+    b0, b1 = rng.integers(0, 2, 64), rng.integers(0, 2, 64)
+    c0, c1 = o.encrypt_bits(b0, 11, 0), o.encrypt_bits(b1, 12, 0)
+    out = o.gate_batch(ol.OPS["NAND"], c0, c1)
+    assert np.array_equal(o.decrypt_bits(out), 1 - (b0 & b1))
+    ph = o.phases(out) / 2**32
+    err = np.abs(np.abs(ph) - 0.125)
+    assert err.max() < 1 / 16 and err.std() < 0.012467
+    # a second level of gates on bootstrapped outputs still decrypts (noise does not accumulate)
+    out2 = o.gate_batch(ol.OPS["XOR"], out, np.roll(out, 1, axis=0))
+    w = 1 - (b0 & b1)
+    assert np.array_equal(o.decrypt_bits(out2), w ^ np.roll(w, 1))
