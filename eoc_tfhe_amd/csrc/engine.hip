@@ -43,6 +43,7 @@ struct eoc_engine {
     // workspaces
     uint16_t *d_bara = nullptr;
     int32_t *d_u = nullptr;
+    uint32_t *d_ubarT = nullptr; // [N][ws_jobs] key-switch operand, transposed
     size_t ws_jobs = 0;
     GateDesc *d_descs = nullptr;
     size_t ws_descs = 0;
@@ -91,10 +92,10 @@ static int valid_params(const eoc_params *p)
 }
 
 extern "C" size_t eoc_bkfft_bytes(const eoc_params *p) { return (size_t)p->n * 2 * p->l * 2 * kNH * 16; }
-extern "C" size_t eoc_ksk_row_stride(const eoc_params *p) { return ((size_t)p->n + 1 + 63) / 64 * 64; }
+extern "C" size_t eoc_ksk_row_stride(const eoc_params *p) { return ((size_t)p->n + 1 + 255) / 256 * 256; }
 extern "C" size_t eoc_ksk_dev_bytes(const eoc_params *p)
 {
-    return (size_t)kN * p->ks_t * ((size_t)1 << p->ks_basebit) * eoc_ksk_row_stride(p) * 4;
+    return (size_t)kN * p->ks_t * (((size_t)1 << p->ks_basebit) - 1) * eoc_ksk_row_stride(p) * 4;
 }
 
 extern "C" int eoc_device_count(void)
@@ -176,6 +177,7 @@ extern "C" void eoc_engine_destroy(eoc_engine *e)
     }
     hipFree(e->d_bara);
     hipFree(e->d_u);
+    hipFree(e->d_ubarT);
     hipFree(e->d_descs);
     delete e;
 }
@@ -186,12 +188,16 @@ static int ensure_ws(eoc_engine *e, size_t jobs, size_t descs)
         hipDeviceSynchronize();
         hipFree(e->d_bara);
         hipFree(e->d_u);
+        hipFree(e->d_ubarT);
         e->d_bara = nullptr;
         e->d_u = nullptr;
+        e->d_ubarT = nullptr;
         e->ws_jobs = 0;
-        size_t cap = std::max<size_t>(jobs, 1024);
+        size_t cap = (std::max<size_t>(jobs, 1024) + 63) / 64 * 64;
         HIP_TRY(hipMalloc(&e->d_bara, cap * e->bara_stride * sizeof(uint16_t)));
         HIP_TRY(hipMalloc(&e->d_u, cap * (kN + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&e->d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(e->d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
         e->ws_jobs = cap;
     }
     if (descs > e->ws_descs) {
@@ -288,16 +294,11 @@ static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_
     hipFree(d_bk);
     if (rc) return rc;
     HIP_TRY(se);
-    // KSK: [N*t][base-1][n+1]  ->  [N*t][base][n1p], row 0 and the padding zero
-    const int base = 1 << p.ks_basebit;
-    const size_t groups = (size_t)kN * p.ks_t;
+    // KSK: [N*t*(base-1)][n+1]  ->  same rows padded with zeros to n1p
+    const size_t rows = (size_t)kN * p.ks_t * (((size_t)1 << p.ks_basebit) - 1);
     HIP_TRY(hipMemset(d_ksk, 0, eoc_ksk_dev_bytes(&p)));
-    for (int d = 1; d < base; d++) {
-        // rows (g, d) for all groups g: strided 2-D copy, one row of (n+1) ints per group
-        HIP_TRY(hipMemcpy2D(d_ksk + (size_t)d * e->n1p, e->n1p * 4 * base, ksk + (size_t)(d - 1) * (p.n + 1),
-                            (size_t)(p.n + 1) * 4 * (base - 1), (size_t)(p.n + 1) * 4, groups,
-                            hipMemcpyHostToDevice));
-    }
+    HIP_TRY(hipMemcpy2D(d_ksk, e->n1p * 4, ksk, (size_t)(p.n + 1) * 4, (size_t)(p.n + 1) * 4, rows,
+                        hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
     return EOC_OK;
 }
@@ -380,20 +381,31 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
     KSArgs a;
     a.ksk = e->ksk;
     a.u = e->d_u;
+    a.ubarT = e->d_ubarT;
     a.n = e->p.n;
     a.n1p = (int)e->n1p;
     a.t = e->p.ks_t;
     a.basebit = e->p.ks_basebit;
     a.S = S;
+    a.jstride = (uint32_t)e->ws_jobs + KS_GT;
     a.mu = (int32_t)(1u << 29);
-    dim3 grid(S, ngates), block(256);
-    int ch = (e->p.n + 1 + 255) / 256;
     SpanGuard span(e, st, KIND_KEYSWITCH);
-    switch (ch) {
-    case 1: hipLaunchKernelGGL(k_keyswitch<1>, grid, block, 0, st, d_descs, a); break;
-    case 2: hipLaunchKernelGGL(k_keyswitch<2>, grid, block, 0, st, d_descs, a); break;
-    case 3: hipLaunchKernelGGL(k_keyswitch<3>, grid, block, 0, st, d_descs, a); break;
-    default: hipLaunchKernelGGL(k_keyswitch<4>, grid, block, 0, st, d_descs, a); break;
+    hipLaunchKernelGGL(k_ks_init, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
+    HIP_TRY(hipGetLastError());
+    const uint32_t ntiles = (S + KS_GT - 1) / KS_GT;
+    dim3 grid(ntiles * (kN / KS_IT), ngates), block((unsigned)(e->n1p / KS_CPT));
+    if (e->p.ks_basebit == 2 && e->p.ks_t == 8)
+        hipLaunchKernelGGL((k_keyswitch<2, 8, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
+    else if (e->p.ks_basebit == 1 && e->p.ks_t == 16)
+        hipLaunchKernelGGL((k_keyswitch<1, 16, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
+    else if (e->p.ks_basebit == 2 && e->p.ks_t == 4)
+        hipLaunchKernelGGL((k_keyswitch<2, 4, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
+    else if (e->p.ks_basebit == 3 && e->p.ks_t == 5)
+        hipLaunchKernelGGL((k_keyswitch<3, 5, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
+    else {
+        eoc_set_error("key switch: unsupported (basebit=%d, t=%d); supported: (2,8) (1,16) (2,4) (3,5)",
+                      e->p.ks_basebit, e->p.ks_t);
+        return EOC_ERR_ARG;
     }
     HIP_TRY(hipGetLastError());
     return EOC_OK;

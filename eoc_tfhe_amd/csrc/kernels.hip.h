@@ -542,60 +542,106 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 }
 
 // =================================================================================================
-// K3: key switch.  One workgroup per ciphertext; thread c owns output coefficients c, c+256, ...
-// KSK device image: [N*t][base][n1p] with row d = 0 all zero, so the digit loop is branch-free.
+// K3: key switch (lweKeySwitch), two launches.
+//   k_ks_init      per ciphertext: ubarT[i][job] = u_i + 2^(31 - t*basebit)  (sum of the two extracted
+//                  samples + (0, mu) for MUX), out = (0, ..., 0, b')
+//   k_keyswitch    one workgroup = a tile of KS_GT ciphertexts x a slice of KS_IT indices i.  Each
+//                  (i, j) loads the base-1 candidate rows ONCE (16 B per lane, coalesced) and every
+//                  ciphertext of the tile picks its row by its digit (wave-uniform scalar), so key
+//                  traffic drops by KS_GT versus one pass per ciphertext.  Partial sums leave through
+//                  integer atomics (exact, order independent).
+// KSK device image: [N*t][base-1][n1p], rows padded with zeros to n1p (multiple of 256).
 // =================================================================================================
+constexpr int KS_GT = 32; // ciphertexts per workgroup (tile)
+constexpr int KS_CPT = 2; // key columns per thread
+constexpr int KS_IT = 16; // indices i per workgroup
+
 struct KSArgs {
     const int32_t *ksk;
-    const int32_t *u;    // [jobs][N+1]
+    const int32_t *u;   // [jobs][N+1]
+    uint32_t *ubarT;    // [N][jstride]
     int n, n1p, t, basebit;
-    uint32_t S;
+    uint32_t S, jstride;
     int32_t mu;
 };
 
-template <int CH> // CH = ceil((n+1)/256)
-__global__ __launch_bounds__(256) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
+// grid: x = S, y = gates
+__global__ __launch_bounds__(256) void k_ks_init(const GateDesc *__restrict__ descs, KSArgs A)
 {
-    __shared__ uint32_t s_u[kN + 1];
     const GateDesc d = descs[blockIdx.y];
     const uint32_t s = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int32_t *u1 = A.u + (size_t)(d.job_base + s) * (kN + 1);
+    const uint32_t job = d.job_base + s;
+    const int32_t *u1 = A.u + (size_t)job * (kN + 1);
     const bool mux = d.op == OP_MUX;
     const int32_t *u2 = u1 + (size_t)A.S * (kN + 1);
     const uint32_t prec_offset = 1u << (32 - (1 + A.basebit * A.t));
-    for (int j = tid; j <= kN; j += 256) {
+    for (int j = threadIdx.x; j < kN; j += 256) {
         uint32_t v = (uint32_t)u1[j];
-        if (mux) v += (uint32_t)u2[j] + (j == kN ? (uint32_t)A.mu : 0u);
-        s_u[j] = j < kN ? v + prec_offset : v;
+        if (mux) v += (uint32_t)u2[j];
+        A.ubarT[(size_t)j * A.jstride + job] = v + prec_offset;
     }
-    __syncthreads();
-    uint32_t out[CH];
-#pragma unroll
-    for (int c = 0; c < CH; c++) out[c] = 0;
-    const uint32_t mask = (1u << A.basebit) - 1;
-    const int base = 1 << A.basebit;
+    int32_t *o = d.out + (size_t)s * (A.n + 1);
+    for (int m = threadIdx.x; m < A.n; m += 256) o[m] = 0;
+    if (threadIdx.x == 0) {
+        uint32_t b = (uint32_t)u1[kN];
+        if (mux) b += (uint32_t)u2[kN] + (uint32_t)A.mu;
+        o[A.n] = (int32_t)b;
+    }
+}
+
+template <int W> struct ivec;
+template <> struct ivec<2> { typedef int type __attribute__((ext_vector_type(2))); };
+template <> struct ivec<4> { typedef int type __attribute__((ext_vector_type(4))); };
+
+// grid: x = ceil(S / GT) * (N / KS_IT), y = gates; block = n1p / CPT threads (multiple of 64)
+// CPT = key columns per thread (vector load width), GT = ciphertexts per workgroup
+template <int BASEBIT, int T, int CPT, int GT>
+__global__ __launch_bounds__(512) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
+{
+    typedef typename ivec<CPT>::type iv;
+    constexpr int ND = (1 << BASEBIT) - 1; // stored rows per (i, j)
+    const GateDesc d = descs[blockIdx.y];
+    const uint32_t ntiles = (A.S + GT - 1) / GT;
+    const uint32_t tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
+    const uint32_t s0 = tile * GT;
+    const uint32_t job0 = d.job_base + s0;
+    const int col = threadIdx.x * CPT;
     const size_t n1p = (size_t)A.n1p;
-    for (int i = 0; i < kN; i++) {
-        const uint32_t ai = s_u[i];
-        const int32_t *rows = A.ksk + (size_t)i * A.t * base * n1p;
-#pragma unroll 8
-        for (int j = 0; j < A.t; j++) {
-            uint32_t dg = (ai >> (32 - (j + 1) * A.basebit)) & mask;
-            const int32_t *row = rows + ((size_t)j * base + dg) * n1p;
+
+    iv acc[GT];
 #pragma unroll
-            for (int c = 0; c < CH; c++) {
-                int m = tid + 256 * c;
-                if (m < A.n1p) out[c] -= (uint32_t)row[m];
+    for (int g = 0; g < GT; g++) acc[g] = (iv)(0);
+
+    for (int ii = 0; ii < KS_IT; ii++) {
+        const int i = slice * KS_IT + ii;
+        const uint32_t *ub = A.ubarT + (size_t)i * A.jstride + job0; // uniform: scalar loads
+        uint32_t ubg[GT];
+#pragma unroll
+        for (int g = 0; g < GT; g++) ubg[g] = ub[g];
+        const int32_t *rows = A.ksk + (size_t)i * T * ND * n1p + col;
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            iv r[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) r[k] = *reinterpret_cast<const iv *>(rows + ((size_t)j * ND + k) * n1p);
+#pragma unroll
+            for (int g = 0; g < GT; g++) {
+                const uint32_t dg = (ubg[g] >> (32 - (j + 1) * BASEBIT)) & (uint32_t)ND; // wave-uniform
+                iv sel = r[0];
+#pragma unroll
+                for (int k = 1; k < ND; k++) sel = (dg == (uint32_t)(k + 1)) ? r[k] : sel;
+                if (dg) acc[g] -= sel;
             }
         }
     }
-    int32_t *o = d.out + (size_t)s * (A.n + 1);
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        int m = tid + 256 * c;
-        if (m < A.n) o[m] = (int32_t)out[c];
-        else if (m == A.n) o[m] = (int32_t)(out[c] + s_u[kN]);
+    for (int g = 0; g < GT; g++) {
+        if (s0 + g < A.S) {
+            int32_t *o = d.out + (size_t)(s0 + g) * (A.n + 1) + col;
+#pragma unroll
+            for (int c = 0; c < CPT; c++)
+                if (col + c <= A.n && acc[g][c] != 0) atomicAdd(o + c, acc[g][c]);
+        }
     }
 }
 

@@ -115,7 +115,7 @@ int eoc_device_to_host(eoc_engine *e, void *dst, const void *d_src, size_t bytes
 int eoc_engine_synchronize(eoc_engine *e);
 
 /* device-side key image sizes in bytes: BK-FFT [n][2l][2][512] complex f64 (bin order sigma),
- * KSK [N*t][base][n1p] int32 (row d = 0 all-zero, rows padded to n1p = eoc_ksk_row_stride) */
+ * KSK [N*t][base-1][n1p] int32 (rows d = 1..base-1, zero-padded to n1p = eoc_ksk_row_stride) */
 size_t eoc_bkfft_bytes(const eoc_params *p);
 size_t eoc_ksk_dev_bytes(const eoc_params *p);
 size_t eoc_ksk_row_stride(const eoc_params *p);

@@ -105,12 +105,12 @@ def test_keygen_and_bkfft_parity(eoc, rig_small):
     d_bk, d_ksk = r.eng.cloud_key_device()
     got = r.eng.download(d_bk, r.eng.bkfft_bytes, np.float64).reshape(r.orc.bkfft.shape)
     assert np.array_equal(got, r.orc.bkfft)
-    # KSK device image: [N*t][base][n1p], row d = 0 and the padding are zero
+    # KSK device image: [N*t][base-1][n1p], padding zero
     p = r.p
-    base, n1p = 1 << p.ks_basebit, (p.n + 1 + 63) // 64 * 64
-    img = r.eng.download(d_ksk, r.eng.ksk_dev_bytes, np.int32).reshape(N * p.ks_t, base, n1p)
-    assert not img[:, 0, :].any() and not img[:, :, p.n + 1:].any()
-    assert np.array_equal(img[:, 1:, : p.n + 1].reshape(-1, p.n + 1), r.orc.ksk)
+    base, n1p = 1 << p.ks_basebit, (p.n + 1 + 255) // 256 * 256
+    img = r.eng.download(d_ksk, r.eng.ksk_dev_bytes, np.int32).reshape(N * p.ks_t * (base - 1), n1p)
+    assert not img[:, p.n + 1:].any()
+    assert np.array_equal(img[:, : p.n + 1], r.orc.ksk)
 
 
 def _rand_cts(rig, count, enc_seed, first=0):

@@ -83,7 +83,7 @@ def test_key_image_sizes(eoc):
     a = eoc.default_params(0)
     assert L.eoc_bkfft_bytes(C.byref(a)) == 32_768_000            # SURVEY.md 8(d), Set A
     assert L.eoc_ksk_row_stride(C.byref(a)) == 512
-    assert L.eoc_ksk_dev_bytes(C.byref(a)) == 1024 * 8 * 4 * 512 * 4
+    assert L.eoc_ksk_dev_bytes(C.byref(a)) == 1024 * 8 * 3 * 512 * 4
     b = eoc.default_params(1)
     assert L.eoc_bkfft_bytes(C.byref(b)) == 61_931_520            # Set B
     assert L.eoc_bk_len(C.byref(a)) == 500 * 4 * 2 * 1024 and L.eoc_ksk_len(C.byref(a)) == 1024 * 8 * 3 * 501
