@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeoc_tfhe_gpu.so")
+LIB_PATH = os.environ.get("EOC_TFHE_LIB") or os.path.join(_HERE, "libeoc_tfhe_gpu.so")
 N = 1024
 
 OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9,

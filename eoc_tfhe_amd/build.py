@@ -38,6 +38,20 @@ def _run(cmd, verbose):
     subprocess.check_call(cmd)
 
 
+def build_stamps(verbose=False):
+    """Diagnostic variant with in-kernel s_memtime stamps (tools/stamps.py); never the shipped library."""
+    os.makedirs(OBJ, exist_ok=True)
+    out = os.path.join(HERE, "libeoc_tfhe_gpu_stamps.so")
+    eng_obj = os.path.join(OBJ, "engine_stamps.o")
+    host_obj = os.path.join(OBJ, "host.o")
+    _run([HIPCC, *HIP_FLAGS, "-DEOC_STAMPS", "-c", os.path.join(CSRC, "engine.hip"), "-o", eng_obj], verbose)
+    if not os.path.exists(host_obj):
+        _run([GXX, *CXX_FLAGS, "-c", os.path.join(CSRC, "host.cpp"), "-o", host_obj], verbose)
+    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", eng_obj, host_obj, "-o", out,
+          "-lgomp", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+    return out
+
+
 def build(force=False, verbose=False, extra_hip_flags=()):
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in ("kernels.hip.h", "canon_twiddles.h", "common.h")]
@@ -55,4 +69,7 @@ def build(force=False, verbose=False, extra_hip_flags=()):
 
 
 if __name__ == "__main__":
+    if "--stamps" in sys.argv:
+        print(build_stamps(verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

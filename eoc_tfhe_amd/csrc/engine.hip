@@ -44,6 +44,7 @@ struct eoc_engine {
     uint16_t *d_bara = nullptr;
     int32_t *d_u = nullptr;
     uint32_t *d_ubarT = nullptr; // [N][ws_jobs] key-switch operand, transposed
+    unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
     size_t ws_jobs = 0;
     GateDesc *d_descs = nullptr;
     size_t ws_descs = 0;
@@ -363,6 +364,7 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     a.Bgbit = e->p.Bgbit;
     a.bara_stride = e->bara_stride;
     a.mu = (int32_t)(1u << 29);
+    a.stamps = e->d_stamps;
     dim3 grid((njobs + 1) / 2), block(256);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
     switch (e->p.l) {
@@ -680,6 +682,24 @@ extern "C" int eoc_engine_kernel_times(eoc_engine *e, double ms[3], uint64_t lau
     }
     return EOC_OK;
 }
+
+#ifdef EOC_STAMPS
+// diagnostic build only: allocate / read back the in-kernel stamp buffer ([waves][16] cycle sums)
+extern "C" int eoc_dbg_stamps(eoc_engine *e, size_t waves, unsigned long long *host_out)
+{
+    if (!e) return EOC_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    if (!host_out) {
+        hipFree(e->d_stamps);
+        HIP_TRY(hipMalloc(&e->d_stamps, waves * 16 * 8));
+        HIP_TRY(hipMemset(e->d_stamps, 0, waves * 16 * 8));
+        return EOC_OK;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, e->d_stamps, waves * 16 * 8, hipMemcpyDeviceToHost));
+    return EOC_OK;
+}
+#endif
 
 extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])
 {

@@ -384,6 +384,22 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
     d.out[i] = (int32_t)(d.op == OP_NOT ? 0u - v : v);
 }
 
+// In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
+// segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
+#ifdef EOC_STAMPS
+#define EOC_STAMP(k)                                                                      \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long _t;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        st_acc[k] += _t - st_prev;                                                        \
+        st_prev = _t;                                                                     \
+    } while (0)
+#else
+#define EOC_STAMP(k) do { } while (0)
+#endif
+
 // =================================================================================================
 // K2: blind rotate + sample extract.  One workgroup = 4 waves = 2 ciphertexts; wave pair (h = 0,1)
 // of a ciphertext: wave h owns accumulator polynomial h, decomposes it, runs the l forward
@@ -398,6 +414,7 @@ struct BRArgs {
     uint32_t njobs;
     int n, Bgbit, bara_stride;
     int32_t mu;
+    unsigned long long *stamps; // diagnostic build only: [waves][16] cycle sums per segment
 };
 
 constexpr int kBRLds = (kTwSlots * 64 + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
@@ -448,7 +465,12 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     constexpr int KPL = 2 * L;
     const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
 
+#ifdef EOC_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int i = 0; i < A.n; i++) {
+        EOC_STAMP(15);
         const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
         // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
         // zero update, which is what skipping the step (as libtfhe does) amounts to.
@@ -465,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             dlo[r] = v0 - (uint32_t)acc[j] + offset;
             dhi[r] = v1 - (uint32_t)acc[j + kNH] + offset;
         }
+        EOC_STAMP(0);
         // mine[] accumulates output polynomial h (kept by this wave), theirs[] polynomial 1-h
         d2 mine[8], theirs[8];
         auto digit_pass = [&](auto pc) __attribute__((always_inline)) {
@@ -486,7 +509,9 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 d2 v = {(double)dl, (double)dh};
                 x[r] = cmul(v, s_twist[lane + 64 * r]);
             }
+            EOC_STAMP(1);
             fft_fwd_wave(x, s_tw, scr, lane);
+            EOC_STAMP(2);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 if constexpr (p == 1) {
@@ -501,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                     theirs[r].y = EOC_FMA(x[r].y, bt[r].x, EOC_FMA(x[r].x, bt[r].y, theirs[r].y));
                 }
             }
+            EOC_STAMP(3);
         };
         digit_pass(std::integral_constant<int, 1>{});
         if constexpr (L >= 2) digit_pass(std::integral_constant<int, 2>{});
@@ -509,13 +535,18 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // hand the other polynomial's partial spectrum to the partner wave
 #pragma unroll
         for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+        EOC_STAMP(4);
         __syncthreads();
+        EOC_STAMP(5);
         d2 x[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) // S = part(q_in=0) + part(q_in=1); IEEE addition commutes
             x[r] = mine[r] + scr_partner[r * 64 + lane];
+        EOC_STAMP(6);
         __syncthreads();
+        EOC_STAMP(7);
         fft_inv_wave(x, s_tw, scr, lane);
+        EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
@@ -524,7 +555,12 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round(y.y));
         }
         wave_lds_fence();
+        EOC_STAMP(9);
     }
+#ifdef EOC_STAMPS
+    if (A.stamps && lane == 0)
+        for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * 4 + w) * 16 + k] = st_acc[k];
+#endif
 
     // tLweExtractLweSample, index 0
     if (valid) {

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Cycle shares of the blind-rotate step's segments from the -DEOC_STAMPS diagnostic build.
+Usage (GPU box):  python -m eoc_tfhe_amd.build --stamps && EOC_TFHE_LIB=eoc_tfhe_amd/libeoc_tfhe_gpu_stamps.so python tools/stamps.py [A|B]
+Read SHARES, not lengths: the stamps' waits forbid overlaps the real kernel has."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa
+import eoc_tfhe_amd as eoc  # noqa
+
+pset = {"A": 0, "B": 1}[sys.argv[1] if len(sys.argv) > 1 else "A"]
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+p = eoc.default_params(pset)
+sk = eoc.SecretKey(p, 1)
+eng = eoc.Engine(p)
+eng.load_cloud_key(sk)
+L = eoc.lib()
+L.eoc_dbg_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+waves = (G + 1) // 2 * 4
+bits = np.random.default_rng(0).integers(0, 2, G)
+c0 = torch.from_numpy(sk.encrypt_bits(bits, 2, 0)).cuda()
+c1 = torch.from_numpy(sk.encrypt_bits(bits, 3, 0)).cuda()
+out = torch.empty_like(c0)
+for _ in range(2):
+    eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), None, out.data_ptr(), G)
+torch.cuda.synchronize()
+assert L.eoc_dbg_stamps(eng.h, waves, None) == 0
+eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), None, out.data_ptr(), G)
+buf = np.zeros((waves, 16), np.uint64)
+assert L.eoc_dbg_stamps(eng.h, waves, buf.ctypes.data) == 0
+names = {0: "rotate-diff (acc reads)", 1: "BK loads issue + digits + twist", 2: "forward FFT", 3: "MAC (waits BK)",
+         4: "xchg write", 5: "barrier A", 6: "xchg read + add", 7: "barrier B", 8: "inverse FFT",
+         9: "untwist + round + acc update", 15: "loop top (bara load)"}
+tot = buf.sum(axis=1).astype(np.float64)
+print(f"waves={waves} steps={p.n}  mean cycles/step/wave = {tot.mean() / p.n:.0f}")
+for k in sorted(names):
+    v = buf[:, k].astype(np.float64)
+    print(f"  [{k:2d}] {names[k]:34s} {v.mean() / p.n:9.1f} cyc/step  {100 * v.sum() / tot.sum():5.1f} %")
