@@ -1,0 +1,156 @@
+"""GPU tests of the circuit executor and the string API (BASELINE configs 3 and 5 at test sizes)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpu_util import sync, to_dev, torch_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eoc(built_lib):
+    torch_cuda()
+    import eoc_tfhe_amd
+    return eoc_tfhe_amd
+
+
+def _oracle_run(orc, gates, wires):
+    """gate-by-gate evaluation of the netlist by the oracle on [n_wires][S][n+1]"""
+    w = wires.copy()
+    for g in gates:
+        i1 = None if g.in1 < 0 else w[g.in1]
+        i2 = None if g.in2 < 0 else w[g.in2]
+        w[g.out] = orc.gate_batch(g.op, w[g.in0], i1, i2)
+    return w
+
+
+def _setup(eoc, pset, seed, n_override):
+    p = eoc.default_params(pset)
+    if n_override:
+        p.n = n_override
+    sk = eoc.SecretKey(p, seed)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    orc = ol.Oracle(pset, seed, n_override=n_override)
+    return p, sk, eng, orc
+
+
+def test_adder_4bit_small_params_bit_exact(eoc):
+    from eoc_tfhe_amd import circuits
+    p, sk, eng, orc = _setup(eoc, 0, 3, 20)
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(4)
+    S = 5
+    rng = np.random.default_rng(1)
+    A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+    wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+    for i in range(4):
+        wires[aw[i]] = sk.encrypt_bits((A >> i) & 1, 50 + i, 0)
+        wires[bw[i]] = sk.encrypt_bits((B >> i) & 1, 70 + i, 0)
+    d = to_dev(wires)
+    eng.circuit_run_device(gates, d.data_ptr(), n_wires, S)
+    sync()
+    got = d.cpu().numpy()
+    want = _oracle_run(orc, gates, wires)
+    for w in sw:
+        assert np.array_equal(got[w], want[w]), w
+    total = sum(sk.decrypt_bits(got[sw[i]]).astype(np.int64) << i for i in range(5))
+    assert np.array_equal(total, A + B)
+
+
+def test_adder_8bit_set_a_decrypts(eoc):
+    """BASELINE config 3 shape (8-bit ripple-carry) on full Set A, 64 pairs; sums checked by decryption,
+    the first pair's sum bits bit-exact vs the oracle."""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng, orc = _setup(eoc, 0, 1, None)
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8)
+    assert eoc.circuit_bootstraps(gates) == 37
+    S = 64
+    rng = np.random.default_rng(3)
+    A, B = rng.integers(0, 256, S), rng.integers(0, 256, S)
+    wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+    for i in range(8):
+        wires[aw[i]] = sk.encrypt_bits((A >> i) & 1, 100 + i, 0)
+        wires[bw[i]] = sk.encrypt_bits((B >> i) & 1, 200 + i, 0)
+    d = to_dev(wires)
+    eng.circuit_run_device(gates, d.data_ptr(), n_wires, S)
+    sync()
+    got = d.cpu().numpy()
+    total = sum(sk.decrypt_bits(got[sw[i]]).astype(np.int64) << i for i in range(9))
+    assert np.array_equal(total, A + B)
+    want = _oracle_run(orc, gates, wires[:, :1].copy())
+    for w in sw:
+        assert np.array_equal(got[w][:1], want[w]), w
+    st = eng.stats()
+    assert st["bootstraps"] == 37 * S
+
+
+def test_string_equal_small(eoc):
+    """BASELINE config 5 shape at 2 bytes: 16 XOR + 15 OR + NOT, half of the pairs equal."""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng, orc = _setup(eoc, 1, 4, 16)
+    gates, n_wires, xw, yw, out = circuits.string_equal(2)
+    assert eoc.circuit_bootstraps(gates) == 31
+    S = 6
+    rng = np.random.default_rng(5)
+    X = rng.integers(32, 127, (S, 2))
+    Y = X.copy()
+    Y[::2, 1] ^= 1 << rng.integers(0, 7, len(Y[::2]))  # every other pair differs in one bit
+    bitsx = np.unpackbits(X.astype(np.uint8), axis=1, bitorder="little")
+    bitsy = np.unpackbits(Y.astype(np.uint8), axis=1, bitorder="little")
+    wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+    for i in range(16):
+        wires[xw[i]] = sk.encrypt_bits(bitsx[:, i], 300 + i, 0)
+        wires[yw[i]] = sk.encrypt_bits(bitsy[:, i], 400 + i, 0)
+    got = eoc_run(eoc, eng, gates, wires, n_wires, S)
+    want = _oracle_run(orc, gates, wires)
+    assert np.array_equal(got[out], want[out])
+    assert np.array_equal(sk.decrypt_bits(got[out]), (X == Y).all(axis=1).astype(np.uint8))
+
+
+def eoc_run(eoc, eng, gates, wires, n_wires, S):
+    d = to_dev(wires)
+    eng.circuit_run_device(gates, d.data_ptr(), n_wires, S)
+    sync()
+    return d.cpu().numpy()
+
+
+def test_in_place_and_hazards(eoc):
+    """netlists that reuse wires (WAR / WAW) are ordered correctly by the leveliser"""
+    p, sk, eng, orc = _setup(eoc, 0, 6, 16)
+    G, O = eoc.Gate, eoc.OPS
+    gates = [G(O["XOR"], 0, 1, -1, 2), G(O["AND"], 2, 0, -1, 0),   # overwrites input 0 after it was read
+             G(O["NOT"], 0, -1, -1, 0), G(O["OR"], 0, 2, -1, 2), G(O["MUX"], 2, 0, 1, 3)]
+    S = 3
+    wires = np.zeros((4, S, p.n + 1), np.int32)
+    wires[0] = sk.encrypt_bits([0, 1, 1], 9, 0)
+    wires[1] = sk.encrypt_bits([1, 1, 0], 10, 0)
+    got = eoc_run(eoc, eng, gates, wires, 4, S)
+    want = _oracle_run(orc, gates, wires)
+    assert np.array_equal(got, want)
+
+
+def test_string_api_and_host_batch_api(eoc):
+    """reference-style string API: global key, base64 strings, truth tables through the GPU"""
+    T = eoc.Tfhe
+    tok = T.generateGateKey(80, 11)
+    try:
+        assert tok is not None
+        assert T.generateGateKey(80, 11) is None          # "already generated" (eoc-tfhe-run.cpp:245-249)
+        import base64
+        c0, c1 = T.encryptBit(0), T.encryptBit(1)
+        raw = base64.b64decode(c1)
+        assert len(raw) == 4 * 501 + 8                   # a[n] | b | f64 variance
+        assert T.decryptBit(c0) == 0 and T.decryptBit(c1) == 1
+        assert T.decryptBit(T.nand(c1, c1)) == 0 and T.decryptBit(T.nand(c0, c1)) == 1
+        assert T.decryptBit(T.xor(c0, c1)) == 1 and T.decryptBit(T.and_(c1, c1)) == 1
+        assert T.decryptBit(T.not_(c1)) == 0
+        assert T.decryptBit(T.mux(c1, c0, c1)) == 0 and T.decryptBit(T.mux(c0, c0, c1)) == 1
+        assert T.nand("not base64!", c1) is None          # malformed input -> NULL
+        # host-buffer batch API on the same global engine
+        raw0 = np.frombuffer(base64.b64decode(c0)[: 4 * 501], np.int32)
+        raw1 = np.frombuffer(raw[: 4 * 501], np.int32)
+        out = eoc.gate_batch(eoc.OPS["OR"], np.stack([raw0, raw1]), np.stack([raw0, raw0]))
+        assert out.shape == (2, 501)
+    finally:
+        T.resetGateKey()
