@@ -106,76 +106,138 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// forward: x[] in L0 (already twisted) -> x[] in L2.  tw = LDS table [14][64], scr = this wave's scratch
-__device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+// Ablation switches for diagnostic builds (tools/ablate.sh): wrong results, timing only.
+#ifdef EOC_ABL_NOTRANSPOSE
+#define EOC_LDS_T(stmt) do { } while (0)
+#else
+#define EOC_LDS_T(stmt) do { stmt; } while (0)
+#endif
+#ifdef EOC_ABL_NOBAR
+#define EOC_SYNC() do { } while (0)
+#else
+#define EOC_SYNC() __syncthreads()
+#endif
+
+// ---- forward transform, in pieces (x[] in L0, already twisted -> x[] in L2) --------------------
+// tw = LDS table [14][64], scr = this wave's scratch
+__device__ __forceinline__ void fwd_pass0(d2 (&x)[8], const d2 *tw, int lane)
+{ // stages 0,1,2 (bits 8,7,6)
+    d2 w0 = tw[0 * 64 + lane], w1 = tw[1 * 64 + lane], w2 = tw[2 * 64 + lane], w3 = tw[3 * 64 + lane];
+    dif_w(x[0], x[4], w0);
+    dif_w(x[1], x[5], w1);
+    dif_w(x[2], x[6], w2);
+    dif_w(x[3], x[7], w3);
+    d2 w4 = tw[4 * 64 + lane], w5 = tw[5 * 64 + lane];
+    dif_w(x[0], x[2], w4);
+    dif_w(x[1], x[3], w5);
+    dif_w(x[4], x[6], w4);
+    dif_w(x[5], x[7], w5);
+    d2 w6 = tw[6 * 64 + lane];
+    dif_w(x[0], x[1], w6);
+    dif_w(x[2], x[3], w6);
+    dif_w(x[4], x[5], w6);
+    dif_w(x[6], x[7], w6);
+}
+__device__ __forceinline__ void fwd_pass1(d2 (&x)[8], const d2 *tw, int lane)
+{ // stages 3,4,5 (bits 5,4,3)
+    d2 w0 = tw[7 * 64 + lane], w1 = tw[8 * 64 + lane], w2 = tw[9 * 64 + lane], w3 = tw[10 * 64 + lane];
+    dif_w(x[0], x[4], w0);
+    dif_w(x[1], x[5], w1);
+    dif_w(x[2], x[6], w2);
+    dif_w(x[3], x[7], w3);
+    d2 w4 = tw[11 * 64 + lane], w5 = tw[12 * 64 + lane];
+    dif_w(x[0], x[2], w4);
+    dif_w(x[1], x[3], w5);
+    dif_w(x[4], x[6], w4);
+    dif_w(x[5], x[7], w5);
+    d2 w6 = tw[13 * 64 + lane];
+    dif_w(x[0], x[1], w6);
+    dif_w(x[2], x[3], w6);
+    dif_w(x[4], x[5], w6);
+    dif_w(x[6], x[7], w6);
+}
+__device__ __forceinline__ void fwd_pass2(d2 (&x)[8])
+{ // stages 6,7,8 (bits 2,1,0), lane-independent twiddles
+    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
+    dif_1(x[0], x[4]);
+    dif_w(x[1], x[5], wc);
+    dif_i(x[2], x[6]);
+    dif_w(x[3], x[7], wd);
+    dif_1(x[0], x[2]);
+    dif_i(x[1], x[3]);
+    dif_1(x[4], x[6]);
+    dif_i(x[5], x[7]);
+    dif_1(x[0], x[1]);
+    dif_1(x[2], x[3]);
+    dif_1(x[4], x[5]);
+    dif_1(x[6], x[7]);
+}
+// transposes: write in the source layout, read in the destination layout.  One wave's LDS operations
+// execute in issue order, so a later write to the same scratch cannot overtake an earlier read.
+__device__ __forceinline__ void t01_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-    // ---- pass 0: stages 0,1,2 (bits 8,7,6) ----
-    {
-        d2 w0 = tw[0 * 64 + lane], w1 = tw[1 * 64 + lane], w2 = tw[2 * 64 + lane], w3 = tw[3 * 64 + lane];
-        dif_w(x[0], x[4], w0);
-        dif_w(x[1], x[5], w1);
-        dif_w(x[2], x[6], w2);
-        dif_w(x[3], x[7], w3);
-        d2 w4 = tw[4 * 64 + lane], w5 = tw[5 * 64 + lane];
-        dif_w(x[0], x[2], w4);
-        dif_w(x[1], x[3], w5);
-        dif_w(x[4], x[6], w4);
-        dif_w(x[5], x[7], w5);
-        d2 w6 = tw[6 * 64 + lane];
-        dif_w(x[0], x[1], w6);
-        dif_w(x[2], x[3], w6);
-        dif_w(x[4], x[5], w6);
-        dif_w(x[6], x[7], w6);
-    }
-    // ---- transpose L0 -> L1 ----
-    const int hi = lane >> 3, lo = lane & 7;
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * r + lane] = x[r];
     wave_lds_fence();
+#endif
+}
+__device__ __forceinline__ void t01_read(d2 (&x)[8], const d2 *scr, int lane)
+{
+#ifndef EOC_ABL_NOTRANSPOSE
+    const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * hi + 8 * r + lo];
     wave_lds_fence();
-    // ---- pass 1: stages 3,4,5 (bits 5,4,3) ----
-    {
-        d2 w0 = tw[7 * 64 + lane], w1 = tw[8 * 64 + lane], w2 = tw[9 * 64 + lane], w3 = tw[10 * 64 + lane];
-        dif_w(x[0], x[4], w0);
-        dif_w(x[1], x[5], w1);
-        dif_w(x[2], x[6], w2);
-        dif_w(x[3], x[7], w3);
-        d2 w4 = tw[11 * 64 + lane], w5 = tw[12 * 64 + lane];
-        dif_w(x[0], x[2], w4);
-        dif_w(x[1], x[3], w5);
-        dif_w(x[4], x[6], w4);
-        dif_w(x[5], x[7], w5);
-        d2 w6 = tw[13 * 64 + lane];
-        dif_w(x[0], x[1], w6);
-        dif_w(x[2], x[3], w6);
-        dif_w(x[4], x[5], w6);
-        dif_w(x[6], x[7], w6);
-    }
-    // ---- transpose L1 -> L2 ----
+#endif
+}
+__device__ __forceinline__ void t12_write(const d2 (&x)[8], d2 *scr, int lane)
+{
+#ifndef EOC_ABL_NOTRANSPOSE
+    const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(hi * 64 + r * 8 + lo)] = x[r];
     wave_lds_fence();
+#endif
+}
+__device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
+{
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(lane * 8 + r)];
     wave_lds_fence();
-    // ---- pass 2: stages 6,7,8 (bits 2,1,0), lane-independent twiddles ----
-    {
-        const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
-        dif_1(x[0], x[4]);
-        dif_w(x[1], x[5], wc);
-        dif_i(x[2], x[6]);
-        dif_w(x[3], x[7], wd);
-        dif_1(x[0], x[2]);
-        dif_i(x[1], x[3]);
-        dif_1(x[4], x[6]);
-        dif_i(x[5], x[7]);
-        dif_1(x[0], x[1]);
-        dif_1(x[2], x[3]);
-        dif_1(x[4], x[5]);
-        dif_1(x[6], x[7]);
-    }
+#endif
+}
+
+__device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+{
+    fwd_pass0(x, tw, lane);
+    t01_write(x, scr, lane);
+    t01_read(x, scr, lane);
+    fwd_pass1(x, tw, lane);
+    t12_write(x, scr, lane);
+    t12_read(x, scr, lane);
+    fwd_pass2(x);
+}
+
+// Two independent forward transforms of one wave on ONE scratch, skewed so that each transform's
+// LDS round trip runs under the other's register pass (same arithmetic as two fft_fwd_wave calls).
+__device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+{
+    fwd_pass0(xa, tw, lane);
+    t01_write(xa, scr, lane);
+    t01_read(xa, scr, lane);
+    fwd_pass0(xb, tw, lane); // under a's round trip
+    t01_write(xb, scr, lane);
+    t01_read(xb, scr, lane);
+    fwd_pass1(xa, tw, lane); // under b's round trip
+    t12_write(xa, scr, lane);
+    t12_read(xa, scr, lane);
+    fwd_pass1(xb, tw, lane);
+    t12_write(xb, scr, lane);
+    t12_read(xb, scr, lane);
+    fwd_pass2(xa);
+    fwd_pass2(xb);
 }
 
 // inverse: x[] in L2 -> x[] in L0 (before the un-twist)
@@ -197,12 +259,14 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
         dit_i(x[2], x[6]);
         dit_w(x[3], x[7], wd);
     }
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
+#endif
     {
         d2 w6 = tw[13 * 64 + lane];
         dit_w(x[0], x[1], w6);
@@ -220,12 +284,14 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
         dit_w(x[2], x[6], w2);
         dit_w(x[3], x[7], w3);
     }
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = x[r];
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
     wave_lds_fence();
+#endif
     {
         d2 w6 = tw[6 * 64 + lane];
         dit_w(x[0], x[1], w6);
@@ -490,18 +556,21 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(0);
         // mine[] accumulates output polynomial h (kept by this wave), theirs[] polynomial 1-h
         d2 mine[8], theirs[8];
-        auto digit_pass = [&](auto pc) __attribute__((always_inline)) {
-            constexpr int p = decltype(pc)::value;
-            const int shift = 32 - p * Bgbit;
-            const d2 *row = bk + ((size_t)i * KPL + (h * L + (p - 1))) * 2 * kNH;
-            const d2 *row_m = row + h * kNH, *row_t = row + (1 - h) * kNH;
-            d2 bm[8], bt[8];
+        const d2 *rows_i = bk + ((size_t)i * KPL + h * L) * 2 * kNH; // rows (h, p), p = 1..L
+        auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
+            const d2 *src = rows_i + ((size_t)(p - 1) * 2 + c) * kNH;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                bm[r] = row_m[r * 64 + lane];
-                bt[r] = row_t[r * 64 + lane];
+#ifdef EOC_ABL_NOBK
+                b[r] = s_twist[(r * 64 + lane) ^ c];
+                (void)src;
+#else
+                b[r] = src[r * 64 + lane];
+#endif
             }
-            d2 x[8];
+        };
+        auto make_x = [&](int p, d2 (&x)[8]) __attribute__((always_inline)) {
+            const int shift = 32 - p * Bgbit;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 int dl = (int)((dlo[r] >> shift) & maskBg) - (int)halfBg;
@@ -509,41 +578,67 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 d2 v = {(double)dl, (double)dh};
                 x[r] = cmul(v, s_twist[lane + 64 * r]);
             }
+        };
+        auto mac = [&](bool first, const d2 (&x)[8], const d2 (&b)[8], d2 (&acc_)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (first) {
+                    acc_[r].x = EOC_FMA(-x[r].y, b[r].y, x[r].x * b[r].x);
+                    acc_[r].y = EOC_FMA(x[r].y, b[r].x, x[r].x * b[r].y);
+                } else {
+                    acc_[r].x = EOC_FMA(-x[r].y, b[r].y, EOC_FMA(x[r].x, b[r].x, acc_[r].x));
+                    acc_[r].y = EOC_FMA(x[r].y, b[r].x, EOC_FMA(x[r].x, b[r].y, acc_[r].y));
+                }
+            }
+        };
+        // digits are transformed two at a time (skewed schedule on one scratch), an odd last one alone
+        auto pair_pass = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            d2 ba[8], bb[8], xa[8], xb[8];
+            load_row(p, h, ba);
+            load_row(p + 1, h, bb);
+            make_x(p, xa);
+            make_x(p + 1, xb);
+            EOC_STAMP(1);
+            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
+            EOC_STAMP(2);
+            mac(p == 1, xa, ba, mine);
+            mac(false, xb, bb, mine);
+            load_row(p, 1 - h, ba);
+            load_row(p + 1, 1 - h, bb);
+            mac(p == 1, xa, ba, theirs);
+            mac(false, xb, bb, theirs);
+            EOC_STAMP(3);
+        };
+        auto single_pass = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            d2 bm[8], bt[8], x[8];
+            load_row(p, h, bm);
+            load_row(p, 1 - h, bt);
+            make_x(p, x);
             EOC_STAMP(1);
             fft_fwd_wave(x, s_tw, scr, lane);
             EOC_STAMP(2);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                if constexpr (p == 1) {
-                    mine[r].x = EOC_FMA(-x[r].y, bm[r].y, x[r].x * bm[r].x);
-                    mine[r].y = EOC_FMA(x[r].y, bm[r].x, x[r].x * bm[r].y);
-                    theirs[r].x = EOC_FMA(-x[r].y, bt[r].y, x[r].x * bt[r].x);
-                    theirs[r].y = EOC_FMA(x[r].y, bt[r].x, x[r].x * bt[r].y);
-                } else {
-                    mine[r].x = EOC_FMA(-x[r].y, bm[r].y, EOC_FMA(x[r].x, bm[r].x, mine[r].x));
-                    mine[r].y = EOC_FMA(x[r].y, bm[r].x, EOC_FMA(x[r].x, bm[r].y, mine[r].y));
-                    theirs[r].x = EOC_FMA(-x[r].y, bt[r].y, EOC_FMA(x[r].x, bt[r].x, theirs[r].x));
-                    theirs[r].y = EOC_FMA(x[r].y, bt[r].x, EOC_FMA(x[r].x, bt[r].y, theirs[r].y));
-                }
-            }
+            mac(p == 1, x, bm, mine);
+            mac(p == 1, x, bt, theirs);
             EOC_STAMP(3);
         };
-        digit_pass(std::integral_constant<int, 1>{});
-        if constexpr (L >= 2) digit_pass(std::integral_constant<int, 2>{});
-        if constexpr (L >= 3) digit_pass(std::integral_constant<int, 3>{});
-        if constexpr (L >= 4) digit_pass(std::integral_constant<int, 4>{});
+        if constexpr (L == 1) single_pass(std::integral_constant<int, 1>{});
+        if constexpr (L >= 2) pair_pass(std::integral_constant<int, 1>{});
+        if constexpr (L == 3) single_pass(std::integral_constant<int, 3>{});
+        if constexpr (L == 4) pair_pass(std::integral_constant<int, 3>{});
         // hand the other polynomial's partial spectrum to the partner wave
 #pragma unroll
         for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
         EOC_STAMP(4);
-        __syncthreads();
+        EOC_SYNC();
         EOC_STAMP(5);
         d2 x[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) // S = part(q_in=0) + part(q_in=1); IEEE addition commutes
             x[r] = mine[r] + scr_partner[r * 64 + lane];
         EOC_STAMP(6);
-        __syncthreads();
+        EOC_SYNC();
         EOC_STAMP(7);
         fft_inv_wave(x, s_tw, scr, lane);
         EOC_STAMP(8);
