@@ -395,20 +395,26 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
     hipLaunchKernelGGL(k_ks_init, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
     HIP_TRY(hipGetLastError());
     const uint32_t ntiles = (S + KS_GT - 1) / KS_GT;
-    dim3 grid(ntiles * (kN / KS_IT), ngates), block((unsigned)(e->n1p / KS_CPT));
-    if (e->p.ks_basebit == 2 && e->p.ks_t == 8)
-        hipLaunchKernelGGL((k_keyswitch<2, 8, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
-    else if (e->p.ks_basebit == 1 && e->p.ks_t == 16)
-        hipLaunchKernelGGL((k_keyswitch<1, 16, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
-    else if (e->p.ks_basebit == 2 && e->p.ks_t == 4)
-        hipLaunchKernelGGL((k_keyswitch<2, 4, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
-    else if (e->p.ks_basebit == 3 && e->p.ks_t == 5)
-        hipLaunchKernelGGL((k_keyswitch<3, 5, KS_CPT, KS_GT>), grid, block, 0, st, d_descs, a);
+    const int nw = (int)(e->n1p / KS_CW);
+    dim3 grid(ntiles * (kN / KS_IT), ngates), block(64 * nw);
+    const int bb = e->p.ks_basebit, t = e->p.ks_t;
+#define EOC_KS_LAUNCH(BB, TT, NWV, JBV)                                                                   \
+    do {                                                                                                  \
+        auto kfn = k_keyswitch<BB, TT, NWV, JBV>;                                                         \
+        constexpr int lds = KSCfg<BB, TT, NWV, JBV>::LDS_BYTES;                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, d_descs, a);                                        \
+    } while (0)
+    if (bb == 2 && t == 8 && nw == 2) EOC_KS_LAUNCH(2, 8, 2, 4);
+    else if (bb == 2 && t == 8 && nw == 4) EOC_KS_LAUNCH(2, 8, 4, 4);
+    else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 6, 2);
+    else if (bb == 2 && t == 8 && nw == 8) EOC_KS_LAUNCH(2, 8, 8, 2);
     else {
-        eoc_set_error("key switch: unsupported (basebit=%d, t=%d); supported: (2,8) (1,16) (2,4) (3,5)",
-                      e->p.ks_basebit, e->p.ks_t);
+        eoc_set_error("key switch: unsupported (basebit=%d, t=%d, n=%d); supported: basebit 2, t 8, n <= 1023",
+                      bb, t, e->p.n);
         return EOC_ERR_ARG;
     }
+#undef EOC_KS_LAUNCH
     HIP_TRY(hipGetLastError());
     return EOC_OK;
 }

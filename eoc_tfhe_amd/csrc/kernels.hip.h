@@ -222,7 +222,7 @@ __device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
 
 // Two independent forward transforms of one wave on ONE scratch, skewed so that each transform's
 // LDS round trip runs under the other's register pass (same arithmetic as two fft_fwd_wave calls).
-__device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+__device__ __forceinline__ void fft_fwd_wave_x2_head(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
 {
     fwd_pass0(xa, tw, lane);
     t01_write(xa, scr, lane);
@@ -233,11 +233,19 @@ __device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const 
     fwd_pass1(xa, tw, lane); // under b's round trip
     t12_write(xa, scr, lane);
     t12_read(xa, scr, lane);
+}
+__device__ __forceinline__ void fft_fwd_wave_x2_tail(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+{
     fwd_pass1(xb, tw, lane);
     t12_write(xb, scr, lane);
     t12_read(xb, scr, lane);
     fwd_pass2(xa);
     fwd_pass2(xb);
+}
+__device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+{
+    fft_fwd_wave_x2_head(xa, xb, tw, scr, lane);
+    fft_fwd_wave_x2_tail(xa, xb, tw, scr, lane);
 }
 
 // inverse: x[] in L2 -> x[] in L0 (before the un-twist)
@@ -594,20 +602,23 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // digits are transformed two at a time (skewed schedule on one scratch), an odd last one alone
         auto pair_pass = [&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
-            d2 ba[8], bb[8], xa[8], xb[8];
+            d2 ba[8], bb[8], ca[8], cb[8], xa[8], xb[8];
             load_row(p, h, ba);
             load_row(p + 1, h, bb);
             make_x(p, xa);
             make_x(p + 1, xb);
             EOC_STAMP(1);
-            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
+            fft_fwd_wave_x2_head(xa, xb, s_tw, scr, lane);
+            // the partner polynomial's key rows: issued here so that the rest of the transforms and the
+            // first multiply-accumulate cover their latency
+            load_row(p, 1 - h, ca);
+            load_row(p + 1, 1 - h, cb);
+            fft_fwd_wave_x2_tail(xa, xb, s_tw, scr, lane);
             EOC_STAMP(2);
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
-            load_row(p, 1 - h, ba);
-            load_row(p + 1, 1 - h, bb);
-            mac(p == 1, xa, ba, theirs);
-            mac(false, xb, bb, theirs);
+            mac(p == 1, xa, ca, theirs);
+            mac(false, xb, cb, theirs);
             EOC_STAMP(3);
         };
         auto single_pass = [&](auto pc) __attribute__((always_inline)) {
@@ -683,9 +694,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 //                  integer atomics (exact, order independent).
 // KSK device image: [N*t][base-1][n1p], rows padded with zeros to n1p (multiple of 256).
 // =================================================================================================
-constexpr int KS_GT = 32; // ciphertexts per workgroup (tile)
-constexpr int KS_CPT = 2; // key columns per thread
-constexpr int KS_IT = 16; // indices i per workgroup
+constexpr int KS_GT = 64; // ciphertexts per workgroup (one per lane)
 
 struct KSArgs {
     const int32_t *ksk;
@@ -720,59 +729,133 @@ __global__ __launch_bounds__(256) void k_ks_init(const GateDesc *__restrict__ de
     }
 }
 
-template <int W> struct ivec;
-template <> struct ivec<2> { typedef int type __attribute__((ext_vector_type(2))); };
-template <> struct ivec<4> { typedef int type __attribute__((ext_vector_type(4))); };
+// grid: x = ceil(S / 64) * (N / KS_IT), y = gates; block = 64 * NW threads (NW = n1p / 128 waves)
+// One workgroup = 64 ciphertexts (ONE PER LANE) x a slice of KS_IT indices i; wave w owns key columns
+// [128 w, 128 w + 128).  The base-1 candidate rows of JB consecutive j are staged in LDS next to an
+// all-zero row (digit 0), and every lane reads the row ITS digit selects (lanes with equal digits
+// share an address = broadcast; rows are skewed by 16 B so that different digits hit different
+// banks).  Per (i, j) a wave issues 32 ds_read_b128 + 128 subtractions for 64 ciphertexts -- no
+// scalar selects.  Partial sums are transposed through LDS and leave as coalesced integer atomics.
+constexpr int KS_IT = 32;
+constexpr int KS_CW = 128; // key columns per wave
 
-// grid: x = ceil(S / GT) * (N / KS_IT), y = gates; block = n1p / CPT threads (multiple of 64)
-// CPT = key columns per thread (vector load width), GT = ciphertexts per workgroup
-template <int BASEBIT, int T, int CPT, int GT>
-__global__ __launch_bounds__(512) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
+template <int BASEBIT, int T, int NW, int JB>
+struct KSCfg {
+    static constexpr int BASE = 1 << BASEBIT;
+    static constexpr int NT = 64 * NW;                   // threads
+    static constexpr int N1P = KS_CW * NW;
+    static constexpr int ROWI = N1P + 4;                 // LDS row stride in ints (16-B skew)
+    static constexpr int BUFI = JB * BASE * ROWI;        // one staging buffer, ints
+    static constexpr int TRANSPOSE_BYTES = NW * 64 * 36 * 4; // final 64 x 32 transposes, one per wave
+    static constexpr int LDS_BYTES = 2 * BUFI * 4 > TRANSPOSE_BYTES ? 2 * BUFI * 4 : TRANSPOSE_BYTES;
+    static constexpr int STAGE_I4 = JB * (BASE - 1) * N1P / 4; // int4 per stage
+    static constexpr int LD_PER_THREAD = (STAGE_I4 + NT - 1) / NT;
+};
+
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+template <int BASEBIT, int T, int NW, int JB>
+__global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
 {
-    typedef typename ivec<CPT>::type iv;
-    constexpr int ND = (1 << BASEBIT) - 1; // stored rows per (i, j)
+    typedef KSCfg<BASEBIT, T, NW, JB> C;
+    static_assert(T % JB == 0, "JB must divide T");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_rows = reinterpret_cast<int *>(smem); // [2][JB][BASE][ROWI]
+
     const GateDesc d = descs[blockIdx.y];
-    const uint32_t ntiles = (A.S + GT - 1) / GT;
+    const uint32_t ntiles = (A.S + 63) / 64;
     const uint32_t tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
-    const uint32_t s0 = tile * GT;
-    const uint32_t job0 = d.job_base + s0;
-    const int col = threadIdx.x * CPT;
-    const size_t n1p = (size_t)A.n1p;
+    const uint32_t s0 = tile * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool valid = s0 + lane < A.S;
+    const uint32_t job = d.job_base + (valid ? s0 + lane : A.S - 1);
 
-    iv acc[GT];
-#pragma unroll
-    for (int g = 0; g < GT; g++) acc[g] = (iv)(0);
+    // zero rows (digit 0) of both buffers
+    for (int k = tid; k < 2 * JB * C::ROWI; k += C::NT) {
+        int buf = k / (JB * C::ROWI), rem = k % (JB * C::ROWI);
+        s_rows[buf * C::BUFI + (rem / C::ROWI) * C::BASE * C::ROWI + rem % C::ROWI] = 0;
+    }
 
-    for (int ii = 0; ii < KS_IT; ii++) {
-        const int i = slice * KS_IT + ii;
-        const uint32_t *ub = A.ubarT + (size_t)i * A.jstride + job0; // uniform: scalar loads
-        uint32_t ubg[GT];
+    constexpr int NSTAGE = KS_IT * (T / JB);
+    const size_t row_ints = (size_t)C::N1P;
+    // stage st covers i = slice*KS_IT + st / (T/JB), j = (st % (T/JB))*JB .. +JB-1: JB*(BASE-1) adjacent rows
+    auto stage_src = [&](int st) {
+        const int i = slice * KS_IT + st / (T / JB), j0 = (st % (T / JB)) * JB;
+        return reinterpret_cast<const i4 *>(A.ksk + ((size_t)i * T + j0) * (C::BASE - 1) * row_ints);
+    };
+    i4 pre[C::LD_PER_THREAD];
+    auto stage_load = [&](int st) {
+        const i4 *src = stage_src(st);
 #pragma unroll
-        for (int g = 0; g < GT; g++) ubg[g] = ub[g];
-        const int32_t *rows = A.ksk + (size_t)i * T * ND * n1p + col;
+        for (int k = 0; k < C::LD_PER_THREAD; k++) {
+            int e = tid + C::NT * k;
+            if (e < C::STAGE_I4) pre[k] = src[e];
+        }
+    };
+    auto stage_store = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < T; j++) {
-            iv r[ND];
-#pragma unroll
-            for (int k = 0; k < ND; k++) r[k] = *reinterpret_cast<const iv *>(rows + ((size_t)j * ND + k) * n1p);
-#pragma unroll
-            for (int g = 0; g < GT; g++) {
-                const uint32_t dg = (ubg[g] >> (32 - (j + 1) * BASEBIT)) & (uint32_t)ND; // wave-uniform
-                iv sel = r[0];
-#pragma unroll
-                for (int k = 1; k < ND; k++) sel = (dg == (uint32_t)(k + 1)) ? r[k] : sel;
-                if (dg) acc[g] -= sel;
+        for (int k = 0; k < C::LD_PER_THREAD; k++) {
+            int e = tid + C::NT * k;
+            if (e < C::STAGE_I4) {
+                int rowg = e / (C::N1P / 4), c4 = e % (C::N1P / 4); // rowg = jj*(BASE-1) + (dd-1)
+                int jj = rowg / (C::BASE - 1), dd = rowg % (C::BASE - 1) + 1;
+                *reinterpret_cast<i4 *>(&s_rows[buf * C::BUFI + (jj * C::BASE + dd) * C::ROWI + c4 * 4]) = pre[k];
             }
         }
-    }
+    };
+
+    i4 acc[KS_CW / 4];
 #pragma unroll
-    for (int g = 0; g < GT; g++) {
-        if (s0 + g < A.S) {
-            int32_t *o = d.out + (size_t)(s0 + g) * (A.n + 1) + col;
+    for (int c = 0; c < KS_CW / 4; c++) acc[c] = (i4){0, 0, 0, 0};
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    uint32_t ub = 0;
+#pragma unroll 1
+    for (int st = 0; st < NSTAGE; st++) {
+        const int buf = st & 1;
+        if (st + 1 < NSTAGE) stage_load(st + 1);
+        const int jb = st % (T / JB);
+        if (jb == 0) ub = A.ubarT[(size_t)(slice * KS_IT + st / (T / JB)) * A.jstride + job];
+        const int *base = s_rows + buf * C::BUFI + w * KS_CW;
+#pragma unroll 1
+        for (int jj = 0; jj < JB; jj++) {
+            const int j = jb * JB + jj;
+            const uint32_t dg = (ub >> (32 - (j + 1) * BASEBIT)) & (uint32_t)(C::BASE - 1);
+            const i4 *row = reinterpret_cast<const i4 *>(base + (jj * C::BASE + (int)dg) * C::ROWI);
+            // 8 reads in flight at a time keeps the accumulators (128 VGPRs) and the reads under 256
 #pragma unroll
-            for (int c = 0; c < CPT; c++)
-                if (col + c <= A.n && acc[g][c] != 0) atomicAdd(o + c, acc[g][c]);
+            for (int c0 = 0; c0 < KS_CW / 4; c0 += 8) {
+                i4 v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = row[c0 + c];
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c0 + c] -= v[c];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (st + 1 < NSTAGE) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // transpose 64 ciphertexts x 32 columns at a time through LDS, then coalesced atomics
+    int *tb = s_rows + w * (64 * 36); // per wave: 64 rows x 36 ints (32 + 4 pad)
+#pragma unroll
+    for (int piece = 0; piece < KS_CW / 32; piece++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) *reinterpret_cast<i4 *>(&tb[lane * 36 + q * 4]) = acc[piece * 8 + q];
+        wave_lds_fence();
+        const int colbase = w * KS_CW + piece * 32 + (lane & 31);
+#pragma unroll 4
+        for (int rr = 0; rr < 32; rr++) {
+            const int rowi = rr * 2 + (lane >> 5);
+            const int v = tb[rowi * 36 + (lane & 31)];
+            if (v != 0 && s0 + rowi < A.S && colbase <= A.n)
+                atomicAdd(d.out + (size_t)(s0 + rowi) * (A.n + 1) + colbase, v);
+        }
+        wave_lds_fence();
     }
 }
 
