@@ -251,17 +251,22 @@ extern "C" int eoc_engine_synchronize(eoc_engine *e)
 }
 
 // ---- transforms (debug / key load) ----------------------------------------------------------
+static int launch_fft_fwd(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count, double scale,
+                          hipStream_t st)
+{
+    dim3 grid((unsigned)((count + 3) / 4));
+    hipLaunchKernelGGL(k_fft_fwd_polys, grid, dim3(256), 0, st, d_polys, d_specs, count, e->d_tw, e->d_twist, scale);
+    HIP_TRY(hipGetLastError());
+    return EOC_OK;
+}
+
 extern "C" int eoc_dbg_fft_fwd_device(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count,
                                       void *hip_stream)
 {
     if (!e || !d_polys || !d_specs) return EOC_ERR_ARG;
     if (!count) return EOC_OK;
     HIP_TRY(hipSetDevice(e->device));
-    hipStream_t st = (hipStream_t)hip_stream;
-    dim3 grid((unsigned)((count + 3) / 4));
-    hipLaunchKernelGGL(k_fft_fwd_polys, grid, dim3(256), 0, st, d_polys, d_specs, count, e->d_tw, e->d_twist);
-    HIP_TRY(hipGetLastError());
-    return EOC_OK;
+    return launch_fft_fwd(e, d_polys, d_specs, count, 1.0, (hipStream_t)hip_stream);
 }
 extern "C" int eoc_dbg_fft_inv_device(eoc_engine *e, const double *d_specs, int32_t *d_polys, size_t count,
                                       void *hip_stream)
@@ -290,7 +295,8 @@ static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_
         eoc_set_error("cloud key upload failed");
         return EOC_ERR_HIP;
     }
-    int rc = eoc_dbg_fft_fwd_device(e, d_bk, d_bkfft, npoly, nullptr);
+    // the key image carries the inverse transform's 1/512 (exact power-of-two scaling)
+    int rc = launch_fft_fwd(e, d_bk, d_bkfft, npoly, 0x1p-9, nullptr);
     hipError_t se = hipDeviceSynchronize();
     hipFree(d_bk);
     if (rc) return rc;

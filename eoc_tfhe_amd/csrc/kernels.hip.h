@@ -319,13 +319,15 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
     }
 }
 
-// rint + wrap to 32 bits: exact for |v| < 2^63
+// rint + wrap to 32 bits, exact for |v| < 2^83:  q = rint(v / 2^32);  lo = v - q * 2^32 (exact, |lo| <= 2^31);
+// lo + 1.5 * 2^52 rounds lo to the nearest-even integer in the low mantissa bits, whose low dword
+// is rint(v) mod 2^32 (rint(v) = rint(lo) + q * 2^32).
 __device__ __forceinline__ uint32_t wrap_round(double v)
 {
-    double r = __builtin_rint(v);
-    double h = __builtin_floor(r * 0x1p-32);
-    double lo = EOC_FMA(h, -4294967296.0, r);
-    return (uint32_t)lo;
+    double q = __builtin_rint(v * 0x1p-32);
+    double lo = EOC_FMA(q, -4294967296.0, v);
+    double m = lo + 6755399441055744.0;
+    return (uint32_t)__double2loint(m);
 }
 
 // copy the two constant tables into LDS (called by all 256 threads, followed by __syncthreads)
@@ -338,10 +340,12 @@ __device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_t
 // =================================================================================================
 // K4 / debug: forward transform of `count` integer polynomials, one wave each
 // =================================================================================================
+// `scale` must be a power of two (exact): 1 for the plain transform, 2^-9 for the key image so that
+// the inverse transform's 1/512 is already in the products (bit-identical to scaling at the end)
 __global__ __launch_bounds__(256) void k_fft_fwd_polys(const int32_t *__restrict__ polys,
                                                         double *__restrict__ specs, size_t count,
                                                         const d2 *__restrict__ g_tw,
-                                                        const d2 *__restrict__ g_twist)
+                                                        const d2 *__restrict__ g_twist, double scale)
 {
     __shared__ d2 s_tw[kTwSlots * 64];
     __shared__ d2 s_twist[kNH];
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) void k_fft_fwd_polys(const int32_t *__restrict
     fft_fwd_wave(x, s_tw, s_scr[w], lane);
     d2 *o = reinterpret_cast<d2 *>(specs) + poly * kNH;
 #pragma unroll
-    for (int r = 0; r < 8; r++) o[r * 64 + lane] = x[r];
+    for (int r = 0; r < 8; r++) o[r * 64 + lane] = x[r] * scale;
 }
 
 __global__ __launch_bounds__(256) void k_fft_inv_polys(const double *__restrict__ specs,
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
     constexpr int KPL = 2 * L;
     const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
+    const double digit_bias = 4503599627370496.0 + (double)halfBg;
 
 #ifdef EOC_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -581,9 +586,10 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             const int shift = 32 - p * Bgbit;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                int dl = (int)((dlo[r] >> shift) & maskBg) - (int)halfBg;
-                int dh = (int)((dhi[r] >> shift) & maskBg) - (int)halfBg;
-                d2 v = {(double)dl, (double)dh};
+                // digit in [0, Bg) placed in the low mantissa bits of 2^52, minus (2^52 + Bg/2): exact
+                uint32_t ul = (dlo[r] >> shift) & maskBg, uh = (dhi[r] >> shift) & maskBg;
+                d2 v = {__hiloint2double(0x43300000, (int)ul) - digit_bias,
+                        __hiloint2double(0x43300000, (int)uh) - digit_bias};
                 x[r] = cmul(v, s_twist[lane + 64 * r]);
             }
         };
@@ -602,23 +608,22 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // digits are transformed two at a time (skewed schedule on one scratch), an odd last one alone
         auto pair_pass = [&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
-            d2 ba[8], bb[8], ca[8], cb[8], xa[8], xb[8];
+            d2 ba[8], bb[8], xa[8], xb[8];
             load_row(p, h, ba);
             load_row(p + 1, h, bb);
             make_x(p, xa);
             make_x(p + 1, xb);
             EOC_STAMP(1);
-            fft_fwd_wave_x2_head(xa, xb, s_tw, scr, lane);
-            // the partner polynomial's key rows: issued here so that the rest of the transforms and the
-            // first multiply-accumulate cover their latency
-            load_row(p, 1 - h, ca);
-            load_row(p + 1, 1 - h, cb);
-            fft_fwd_wave_x2_tail(xa, xb, s_tw, scr, lane);
+            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
             EOC_STAMP(2);
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
-            mac(p == 1, xa, ca, theirs);
-            mac(false, xb, cb, theirs);
+            // the partner polynomial's rows re-use the same registers (measured: issuing them earlier
+            // costs spills and gains nothing, the co-resident wave covers the latency)
+            load_row(p, 1 - h, ba);
+            load_row(p + 1, 1 - h, bb);
+            mac(p == 1, xa, ba, theirs);
+            mac(false, xb, bb, theirs);
             EOC_STAMP(3);
         };
         auto single_pass = [&](auto pc) __attribute__((always_inline)) {
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
-            d2 y = cmulc(x[r], s_twist[j] * 0x1p-9);
+            d2 y = cmulc(x[r], s_twist[j]); // the 1/512 is in the key image
             acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round(y.x));
             acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round(y.y));
         }
