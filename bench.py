@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer API (H2D + D2H included)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
 
     import torch
@@ -66,14 +68,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the gate path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % ndev  # rehearsal: ranks may share a GPU
+    elif local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the gate path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     dev = torch.device("cuda", local_rank)
 
     p = eoc.default_params(PSETS[args.pset])
@@ -142,6 +151,11 @@ def main():
     out = dout.cpu().numpy()
     truth = {"NAND": 1 - (bits0 & bits1), "AND": bits0 & bits1, "OR": bits0 | bits1, "XOR": bits0 ^ bits1}.get(args.op)
     decrypt_ok = bool(truth is None or np.array_equal(sk.decrypt_bits(out), truth))
+
+    if dist:  # every rank must have produced correct gates
+        ok = torch.tensor([1 if decrypt_ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        decrypt_ok = bool(ok.item())
 
     if rank == 0:
         total_gates = G * world * args.steps

@@ -108,17 +108,40 @@ extern "C" int eoc_device_count(void)
 
 static int upload_tables(eoc_engine *e)
 {
-    // per-lane twiddle slots of kernels.hip.h (W512[k] = E2048[4k]) and the twist table E2048[j]
-    std::vector<double> tw((size_t)kTwSlots * 64 * 2), twist((size_t)kNH * 2);
-    auto W = [](int k, double *o) { o[0] = EOC_E2048[4 * k][0]; o[1] = EOC_E2048[4 * k][1]; };
+    // twiddle tables of kernels.hip.h (W512[k] = E2048[4k]) and the twist table E2048[j]
+    std::vector<double> tw((size_t)kTwEntries * 2), twist((size_t)kNH * 2);
+    auto W = [&](int k, int entry) {
+        tw[(size_t)entry * 2] = EOC_E2048[4 * k][0];
+        tw[(size_t)entry * 2 + 1] = EOC_E2048[4 * k][1];
+    };
+    auto bitrev8 = [](int b) {
+        int r = 0;
+        for (int k = 0; k < 8; k++) r |= ((b >> k) & 1) << (7 - k);
+        return r;
+    };
+    // forward pass 1 (stages 3,4,5): block = (hi << s') | c, hi = lane >> 3
+    for (int hi = 0; hi < 8; hi++) {
+        W(bitrev8(hi), kTwF1 + 0 * 8 + hi);
+        for (int c = 0; c < 2; c++) W(bitrev8((hi << 1) | c), kTwF1 + (1 + c) * 8 + hi);
+        for (int c = 0; c < 4; c++) W(bitrev8((hi << 2) | c), kTwF1 + (3 + c) * 8 + hi);
+    }
+    // forward pass 2 (stages 6,7,8): block = (lane << s') | c
     for (int lane = 0; lane < 64; lane++) {
-        int lo = lane & 7;
-        for (int s = 0; s < 4; s++) W(lane + 64 * s, &tw[((size_t)s * 64 + lane) * 2]);
-        for (int s = 0; s < 2; s++) W(2 * (lane + 64 * s), &tw[((size_t)(4 + s) * 64 + lane) * 2]);
-        W(4 * lane, &tw[((size_t)6 * 64 + lane) * 2]);
-        for (int s = 0; s < 4; s++) W((s * 8 + lo) * 8, &tw[((size_t)(7 + s) * 64 + lane) * 2]);
-        for (int s = 0; s < 2; s++) W((s * 8 + lo) * 16, &tw[((size_t)(11 + s) * 64 + lane) * 2]);
-        W(lo * 32, &tw[((size_t)13 * 64 + lane) * 2]);
+        W(bitrev8(lane), kTwF2 + 0 * 64 + lane);
+        for (int c = 0; c < 2; c++) W(bitrev8((lane << 1) | c), kTwF2 + (1 + c) * 64 + lane);
+        for (int c = 0; c < 4; c++) W(bitrev8((lane << 2) | c), kTwF2 + (3 + c) * 64 + lane);
+    }
+    // inverse last pass (stages 0,1,2): W[(i mod h) << s], i = lane + 64 r
+    for (int lane = 0; lane < 64; lane++) {
+        for (int c = 0; c < 4; c++) W(lane + 64 * c, kTwI0 + c * 64 + lane);
+        for (int c = 0; c < 2; c++) W(2 * (lane + 64 * c), kTwI0 + (4 + c) * 64 + lane);
+        W(4 * lane, kTwI0 + 6 * 64 + lane);
+    }
+    // inverse middle pass (stages 3,4,5): i mod 64 = 8 r' + lo, lo = lane & 7
+    for (int lo = 0; lo < 8; lo++) {
+        for (int c = 0; c < 4; c++) W((c * 8 + lo) * 8, kTwI1 + c * 8 + lo);
+        for (int c = 0; c < 2; c++) W((c * 8 + lo) * 16, kTwI1 + (4 + c) * 8 + lo);
+        W(lo * 32, kTwI1 + 6 * 8 + lo);
     }
     for (int j = 0; j < kNH; j++) {
         twist[2 * j] = EOC_E2048[j][0];

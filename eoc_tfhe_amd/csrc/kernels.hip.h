@@ -8,10 +8,13 @@
 //   k_keyswitch      lweKeySwitch
 //   k_fft_fwd_polys  tGswToFFTConvert (key load)
 //
-// Arithmetic contract (DESIGN.md "Canonical transform v1"): every floating-point operation below
+// Arithmetic contract (DESIGN.md "Canonical transform v2"): every floating-point operation below
 // is a separately rounded IEEE-754 binary64 +, -, * or an explicit fma; the file MUST be compiled
-// with -ffp-contract=off.  The data-flow graph is the oracle's radix-2 DIF/DIT graph; three radix-2
-// stages are executed per register pass (8 points per lane, one 512-point transform per wave64).
+// with -ffp-contract=off.  The data-flow graph is the oracle's radix-2 graph (forward: evaluation
+// tree of X^512 - 1, natural order in, bit-reversed out; inverse: decimation in time); every
+// butterfly is (u + w v, u - w v) in the 6-operation fused form  a' = u + w v by 4 fma,
+// b' = fma(2, u, -a').  Three radix-2 stages are executed per register pass (8 points per lane, one
+// 512-point transform per wave64).
 //
 // Wave layouts of the 512 complex points (e = 9-bit index):
 //   L0: reg r = e[8:6], lane = e[5:0]           (input of forward / output of inverse)
@@ -30,7 +33,10 @@ typedef double d2 __attribute__((ext_vector_type(2))); // (re, im)
 constexpr int kN = 1024;
 constexpr int kNH = 512;
 constexpr int kScr = 568;      // d2 elements of per-wave transpose scratch (f01 needs 72*7+64)
-constexpr int kTwSlots = 14;   // per-lane twiddle slots (7 for pass 0, 7 for pass 1)
+// twiddle tables in LDS (d2 entries): forward pass 1 [7][8] (by lane>>3), forward pass 2 [7][64] (by lane),
+// inverse last pass [7][64] (by lane), inverse middle pass [7][8] (by lane&7)
+constexpr int kTwF1 = 0, kTwF2 = 56, kTwI0 = 56 + 448, kTwI1 = 56 + 448 + 448;
+constexpr int kTwEntries = 56 + 448 + 448 + 56;
 
 #define EOC_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
@@ -49,46 +55,46 @@ __device__ __forceinline__ d2 cmulc(d2 a, d2 w)
     return r;
 }
 
-// --- radix-2 butterflies -------------------------------------------------------------------------
-__device__ __forceinline__ void dif_w(d2 &a, d2 &b, d2 w)
-{
-    d2 u = a, v = b;
-    a = u + v;
-    b = cmul(u - v, w);
+// --- radix-2 butterflies (u, v) -> (u + w v, u - w v) -----------------------------------------------
+__device__ __forceinline__ void ct_w(d2 &a, d2 &b, d2 w)
+{ // fused form, twiddle w
+    d2 u = a, n;
+    n.x = EOC_FMA(-w.y, b.y, EOC_FMA(w.x, b.x, u.x));
+    n.y = EOC_FMA(w.x, b.y, EOC_FMA(w.y, b.x, u.y));
+    a = n;
+    b.x = EOC_FMA(2.0, u.x, -n.x);
+    b.y = EOC_FMA(2.0, u.y, -n.y);
 }
-__device__ __forceinline__ void dif_1(d2 &a, d2 &b)
-{
+__device__ __forceinline__ void ct_wc(d2 &a, d2 &b, d2 w)
+{ // fused form, twiddle conj(w)
+    d2 u = a, n;
+    n.x = EOC_FMA(w.y, b.y, EOC_FMA(w.x, b.x, u.x));
+    n.y = EOC_FMA(w.x, b.y, EOC_FMA(-w.y, b.x, u.y));
+    a = n;
+    b.x = EOC_FMA(2.0, u.x, -n.x);
+    b.y = EOC_FMA(2.0, u.y, -n.y);
+}
+__device__ __forceinline__ void ct_1(d2 &a, d2 &b)
+{ // w = 1 (register-constant stages only)
     d2 u = a, v = b;
     a = u + v;
     b = u - v;
 }
-__device__ __forceinline__ void dif_i(d2 &a, d2 &b)
-{ // w = i: (t.x, t.y) * i = (-t.y, t.x)
-    d2 u = a, v = b;
-    a = u + v;
-    d2 t = u - v;
-    b.x = -t.y;
-    b.y = t.x;
+__device__ __forceinline__ void ct_i(d2 &a, d2 &b)
+{ // w = i: t = i v = (-v.y, v.x)
+    d2 u = a, t;
+    t.x = -b.y;
+    t.y = b.x;
+    a = u + t;
+    b = u - t;
 }
-__device__ __forceinline__ void dit_w(d2 &a, d2 &b, d2 w)
-{
-    d2 u = a, p = cmulc(b, w);
-    a = u + p;
-    b = u - p;
-}
-__device__ __forceinline__ void dit_1(d2 &a, d2 &b)
-{
-    d2 u = a, p = b;
-    a = u + p;
-    b = u - p;
-}
-__device__ __forceinline__ void dit_i(d2 &a, d2 &b)
-{ // v * conj(i) = (v.y, -v.x)
-    d2 u = a, p;
-    p.x = b.y;
-    p.y = -b.x;
-    a = u + p;
-    b = u - p;
+__device__ __forceinline__ void ct_ic(d2 &a, d2 &b)
+{ // w = conj(i): t = (v.y, -v.x)
+    d2 u = a, t;
+    t.x = b.y;
+    t.y = -b.x;
+    a = u + t;
+    b = u - t;
 }
 
 // W512[64] = (c, c), W512[192] = (-c, c), c = correctly rounded sqrt(1/2) = EOC_E2048[256][0]
@@ -120,57 +126,59 @@ __device__ __forceinline__ void wave_lds_fence()
 
 // ---- forward transform, in pieces (x[] in L0, already twisted -> x[] in L2) --------------------
 // tw = LDS table [14][64], scr = this wave's scratch
-__device__ __forceinline__ void fwd_pass0(d2 (&x)[8], const d2 *tw, int lane)
-{ // stages 0,1,2 (bits 8,7,6)
-    d2 w0 = tw[0 * 64 + lane], w1 = tw[1 * 64 + lane], w2 = tw[2 * 64 + lane], w3 = tw[3 * 64 + lane];
-    dif_w(x[0], x[4], w0);
-    dif_w(x[1], x[5], w1);
-    dif_w(x[2], x[6], w2);
-    dif_w(x[3], x[7], w3);
-    d2 w4 = tw[4 * 64 + lane], w5 = tw[5 * 64 + lane];
-    dif_w(x[0], x[2], w4);
-    dif_w(x[1], x[3], w5);
-    dif_w(x[4], x[6], w4);
-    dif_w(x[5], x[7], w5);
-    d2 w6 = tw[6 * 64 + lane];
-    dif_w(x[0], x[1], w6);
-    dif_w(x[2], x[3], w6);
-    dif_w(x[4], x[5], w6);
-    dif_w(x[6], x[7], w6);
+__device__ __forceinline__ void fwd_pass0(d2 (&x)[8])
+{ // stages 0,1,2 (bits 8,7,6): twiddles W[bitrev8(block)] are register constants
+    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
+    ct_1(x[0], x[4]);
+    ct_1(x[1], x[5]);
+    ct_1(x[2], x[6]);
+    ct_1(x[3], x[7]);
+    ct_1(x[0], x[2]);
+    ct_1(x[1], x[3]);
+    ct_i(x[4], x[6]);
+    ct_i(x[5], x[7]);
+    ct_1(x[0], x[1]);
+    ct_i(x[2], x[3]);
+    ct_w(x[4], x[5], wc); // W[64]
+    ct_w(x[6], x[7], wd); // W[192]
 }
 __device__ __forceinline__ void fwd_pass1(d2 (&x)[8], const d2 *tw, int lane)
-{ // stages 3,4,5 (bits 5,4,3)
-    d2 w0 = tw[7 * 64 + lane], w1 = tw[8 * 64 + lane], w2 = tw[9 * 64 + lane], w3 = tw[10 * 64 + lane];
-    dif_w(x[0], x[4], w0);
-    dif_w(x[1], x[5], w1);
-    dif_w(x[2], x[6], w2);
-    dif_w(x[3], x[7], w3);
-    d2 w4 = tw[11 * 64 + lane], w5 = tw[12 * 64 + lane];
-    dif_w(x[0], x[2], w4);
-    dif_w(x[1], x[3], w5);
-    dif_w(x[4], x[6], w4);
-    dif_w(x[5], x[7], w5);
-    d2 w6 = tw[13 * 64 + lane];
-    dif_w(x[0], x[1], w6);
-    dif_w(x[2], x[3], w6);
-    dif_w(x[4], x[5], w6);
-    dif_w(x[6], x[7], w6);
+{ // stages 3,4,5 (bits 5,4,3): twiddles depend on lane >> 3 (and the upper register bits)
+    const d2 *t = tw + kTwF1 + (lane >> 3);
+    d2 w0 = t[0 * 8];
+    ct_w(x[0], x[4], w0);
+    ct_w(x[1], x[5], w0);
+    ct_w(x[2], x[6], w0);
+    ct_w(x[3], x[7], w0);
+    d2 w1 = t[1 * 8], w2 = t[2 * 8];
+    ct_w(x[0], x[2], w1);
+    ct_w(x[1], x[3], w1);
+    ct_w(x[4], x[6], w2);
+    ct_w(x[5], x[7], w2);
+    d2 w3 = t[3 * 8], w4 = t[4 * 8], w5 = t[5 * 8], w6 = t[6 * 8];
+    ct_w(x[0], x[1], w3);
+    ct_w(x[2], x[3], w4);
+    ct_w(x[4], x[5], w5);
+    ct_w(x[6], x[7], w6);
 }
-__device__ __forceinline__ void fwd_pass2(d2 (&x)[8])
-{ // stages 6,7,8 (bits 2,1,0), lane-independent twiddles
-    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
-    dif_1(x[0], x[4]);
-    dif_w(x[1], x[5], wc);
-    dif_i(x[2], x[6]);
-    dif_w(x[3], x[7], wd);
-    dif_1(x[0], x[2]);
-    dif_i(x[1], x[3]);
-    dif_1(x[4], x[6]);
-    dif_i(x[5], x[7]);
-    dif_1(x[0], x[1]);
-    dif_1(x[2], x[3]);
-    dif_1(x[4], x[5]);
-    dif_1(x[6], x[7]);
+__device__ __forceinline__ void fwd_pass2(d2 (&x)[8], const d2 *tw, int lane)
+{ // stages 6,7,8 (bits 2,1,0): twiddles depend on the lane (and the upper register bits)
+    const d2 *t = tw + kTwF2 + lane;
+    d2 w0 = t[0 * 64];
+    ct_w(x[0], x[4], w0);
+    ct_w(x[1], x[5], w0);
+    ct_w(x[2], x[6], w0);
+    ct_w(x[3], x[7], w0);
+    d2 w1 = t[1 * 64], w2 = t[2 * 64];
+    ct_w(x[0], x[2], w1);
+    ct_w(x[1], x[3], w1);
+    ct_w(x[4], x[6], w2);
+    ct_w(x[5], x[7], w2);
+    d2 w3 = t[3 * 64], w4 = t[4 * 64], w5 = t[5 * 64], w6 = t[6 * 64];
+    ct_w(x[0], x[1], w3);
+    ct_w(x[2], x[3], w4);
+    ct_w(x[4], x[5], w5);
+    ct_w(x[6], x[7], w6);
 }
 // transposes: write in the source layout, read in the destination layout.  One wave's LDS operations
 // execute in issue order, so a later write to the same scratch cannot overtake an earlier read.
@@ -211,23 +219,23 @@ __device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
 
 __device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
 {
-    fwd_pass0(x, tw, lane);
+    fwd_pass0(x);
     t01_write(x, scr, lane);
     t01_read(x, scr, lane);
     fwd_pass1(x, tw, lane);
     t12_write(x, scr, lane);
     t12_read(x, scr, lane);
-    fwd_pass2(x);
+    fwd_pass2(x, tw, lane);
 }
 
 // Two independent forward transforms of one wave on ONE scratch, skewed so that each transform's
 // LDS round trip runs under the other's register pass (same arithmetic as two fft_fwd_wave calls).
 __device__ __forceinline__ void fft_fwd_wave_x2_head(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
 {
-    fwd_pass0(xa, tw, lane);
+    fwd_pass0(xa);
     t01_write(xa, scr, lane);
     t01_read(xa, scr, lane);
-    fwd_pass0(xb, tw, lane); // under a's round trip
+    fwd_pass0(xb); // under a's round trip
     t01_write(xb, scr, lane);
     t01_read(xb, scr, lane);
     fwd_pass1(xa, tw, lane); // under b's round trip
@@ -239,8 +247,8 @@ __device__ __forceinline__ void fft_fwd_wave_x2_tail(d2 (&xa)[8], d2 (&xb)[8], c
     fwd_pass1(xb, tw, lane);
     t12_write(xb, scr, lane);
     t12_read(xb, scr, lane);
-    fwd_pass2(xa);
-    fwd_pass2(xb);
+    fwd_pass2(xa, tw, lane);
+    fwd_pass2(xb, tw, lane);
 }
 __device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
 {
@@ -248,24 +256,24 @@ __device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const 
     fft_fwd_wave_x2_tail(xa, xb, tw, scr, lane);
 }
 
-// inverse: x[] in L2 -> x[] in L0 (before the un-twist)
+// inverse: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time, conjugate twiddles
 __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
-    {
+    { // stages 8,7,6 (bits 0,1,2): register constants
         const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
-        dit_1(x[0], x[1]);
-        dit_1(x[2], x[3]);
-        dit_1(x[4], x[5]);
-        dit_1(x[6], x[7]);
-        dit_1(x[0], x[2]);
-        dit_i(x[1], x[3]);
-        dit_1(x[4], x[6]);
-        dit_i(x[5], x[7]);
-        dit_1(x[0], x[4]);
-        dit_w(x[1], x[5], wc);
-        dit_i(x[2], x[6]);
-        dit_w(x[3], x[7], wd);
+        ct_1(x[0], x[1]);
+        ct_1(x[2], x[3]);
+        ct_1(x[4], x[5]);
+        ct_1(x[6], x[7]);
+        ct_1(x[0], x[2]);
+        ct_ic(x[1], x[3]);
+        ct_1(x[4], x[6]);
+        ct_ic(x[5], x[7]);
+        ct_1(x[0], x[4]);
+        ct_wc(x[1], x[5], wc);
+        ct_ic(x[2], x[6]);
+        ct_wc(x[3], x[7], wd);
     }
 #ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
@@ -275,22 +283,23 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
 #endif
-    {
-        d2 w6 = tw[13 * 64 + lane];
-        dit_w(x[0], x[1], w6);
-        dit_w(x[2], x[3], w6);
-        dit_w(x[4], x[5], w6);
-        dit_w(x[6], x[7], w6);
-        d2 w4 = tw[11 * 64 + lane], w5 = tw[12 * 64 + lane];
-        dit_w(x[0], x[2], w4);
-        dit_w(x[1], x[3], w5);
-        dit_w(x[4], x[6], w4);
-        dit_w(x[5], x[7], w5);
-        d2 w0 = tw[7 * 64 + lane], w1 = tw[8 * 64 + lane], w2 = tw[9 * 64 + lane], w3 = tw[10 * 64 + lane];
-        dit_w(x[0], x[4], w0);
-        dit_w(x[1], x[5], w1);
-        dit_w(x[2], x[6], w2);
-        dit_w(x[3], x[7], w3);
+    { // stages 5,4,3 (bits 3,4,5): W[(i mod h) << s] depends on lane & 7 (and the lower register bits)
+        const d2 *t = tw + kTwI1 + lo;
+        d2 w6 = t[6 * 8];
+        ct_wc(x[0], x[1], w6);
+        ct_wc(x[2], x[3], w6);
+        ct_wc(x[4], x[5], w6);
+        ct_wc(x[6], x[7], w6);
+        d2 w4 = t[4 * 8], w5 = t[5 * 8];
+        ct_wc(x[0], x[2], w4);
+        ct_wc(x[1], x[3], w5);
+        ct_wc(x[4], x[6], w4);
+        ct_wc(x[5], x[7], w5);
+        d2 w0 = t[0 * 8], w1 = t[1 * 8], w2 = t[2 * 8], w3 = t[3 * 8];
+        ct_wc(x[0], x[4], w0);
+        ct_wc(x[1], x[5], w1);
+        ct_wc(x[2], x[6], w2);
+        ct_wc(x[3], x[7], w3);
     }
 #ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
@@ -300,22 +309,23 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
     for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
     wave_lds_fence();
 #endif
-    {
-        d2 w6 = tw[6 * 64 + lane];
-        dit_w(x[0], x[1], w6);
-        dit_w(x[2], x[3], w6);
-        dit_w(x[4], x[5], w6);
-        dit_w(x[6], x[7], w6);
-        d2 w4 = tw[4 * 64 + lane], w5 = tw[5 * 64 + lane];
-        dit_w(x[0], x[2], w4);
-        dit_w(x[1], x[3], w5);
-        dit_w(x[4], x[6], w4);
-        dit_w(x[5], x[7], w5);
-        d2 w0 = tw[0 * 64 + lane], w1 = tw[1 * 64 + lane], w2 = tw[2 * 64 + lane], w3 = tw[3 * 64 + lane];
-        dit_w(x[0], x[4], w0);
-        dit_w(x[1], x[5], w1);
-        dit_w(x[2], x[6], w2);
-        dit_w(x[3], x[7], w3);
+    { // stages 2,1,0 (bits 6,7,8): depends on the lane (and the lower register bits)
+        const d2 *t = tw + kTwI0 + lane;
+        d2 w6 = t[6 * 64];
+        ct_wc(x[0], x[1], w6);
+        ct_wc(x[2], x[3], w6);
+        ct_wc(x[4], x[5], w6);
+        ct_wc(x[6], x[7], w6);
+        d2 w4 = t[4 * 64], w5 = t[5 * 64];
+        ct_wc(x[0], x[2], w4);
+        ct_wc(x[1], x[3], w5);
+        ct_wc(x[4], x[6], w4);
+        ct_wc(x[5], x[7], w5);
+        d2 w0 = t[0 * 64], w1 = t[1 * 64], w2 = t[2 * 64], w3 = t[3 * 64];
+        ct_wc(x[0], x[4], w0);
+        ct_wc(x[1], x[5], w1);
+        ct_wc(x[2], x[6], w2);
+        ct_wc(x[3], x[7], w3);
     }
 }
 
@@ -333,7 +343,7 @@ __device__ __forceinline__ uint32_t wrap_round(double v)
 // copy the two constant tables into LDS (called by all 256 threads, followed by __syncthreads)
 __device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_tw, const d2 *g_twist, int tid)
 {
-    for (int i = tid; i < kTwSlots * 64; i += 256) s_tw[i] = g_tw[i];
+    for (int i = tid; i < kTwEntries; i += 256) s_tw[i] = g_tw[i];
     for (int i = tid; i < kNH; i += 256) s_twist[i] = g_twist[i];
 }
 
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(256) void k_fft_fwd_polys(const int32_t *__restrict
                                                         const d2 *__restrict__ g_tw,
                                                         const d2 *__restrict__ g_twist, double scale)
 {
-    __shared__ d2 s_tw[kTwSlots * 64];
+    __shared__ d2 s_tw[kTwEntries];
     __shared__ d2 s_twist[kNH];
     __shared__ d2 s_scr[4][kScr];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(256) void k_fft_inv_polys(const double *__restrict_
                                                         const d2 *__restrict__ g_tw,
                                                         const d2 *__restrict__ g_twist)
 {
-    __shared__ d2 s_tw[kTwSlots * 64];
+    __shared__ d2 s_tw[kTwEntries];
     __shared__ d2 s_twist[kNH];
     __shared__ d2 s_scr[4][kScr];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -495,7 +505,7 @@ struct BRArgs {
     unsigned long long *stamps; // diagnostic build only: [waves][16] cycle sums per segment
 };
 
-constexpr int kBRLds = (kTwSlots * 64 + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
+constexpr int kBRLds = (kTwEntries + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
 
 template <int L>
 __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__restrict__ g_tw,
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     d2 *s_tw = reinterpret_cast<d2 *>(smem);
-    d2 *s_twist = s_tw + kTwSlots * 64;
+    d2 *s_twist = s_tw + kTwEntries;
     d2 *s_scr_all = s_twist + kNH;
     int32_t *s_acc_all = reinterpret_cast<int32_t *>(s_scr_all + 4 * kScr);
 

@@ -205,23 +205,67 @@ int orc_decrypt_bit(const orc_params *p, const int32_t *lwe_key, const int32_t *
 }
 
 /* ------------------------------------------------------------------------------------------
- * Canonical transform v1 (SURVEY.md A.7 gives the maths).
+ * Canonical transform v2 (SURVEY.md A.7 gives the maths).
  *
  * Replaces upstream IntPolynomial_ifft / TorusPolynomial_ifft / TorusPolynomial_fft (SURVEY.md
  * 8a a8,a10; the nayuki-portable FFT the reference selects in config.yml:22-26).  The upstream
- * butterfly order is unknowable here, so this repo owns the data-flow graph:
+ * butterfly order is unknowable here, so this repo owns the data-flow graph.  W[k] = E[4k] =
+ * exp(2 pi i k / 512).  Every butterfly multiplies BEFORE it adds, which allows the 6-operation
+ * fused form (Linzer-Feig):
+ *
+ *     a' = u + w v :  a'.re = fma(-w.im, v.im, fma(w.re, v.re, u.re))
+ *                     a'.im = fma( w.re, v.im, fma(w.im, v.re, u.im))
+ *     b' = u - w v =  2u - a' :  b' = fma(2, u, -a')           (component-wise)
+ *     in the three register-constant stages (forward 0,1,2; inverse 8,7,6) w = 1 and w = i are exact moves:
+ *     w = 1 -> (u + v, u - v);  w = i -> t = (-v.im, v.re), (u + t, u - t)  (conj(i): t = (v.im, -v.re));
+ *     all other stages use the fused form for every twiddle (conjugate twiddle: w.im negated)
  *
  *   forward:  c_j = (p_j + i p_{j+512}) * E[j]                       (twist, j < 512)
- *             9 radix-2 decimation-in-frequency stages s = 0..8, h = 256 >> s:
- *               (u, v) = (x_i, x_{i+h});  x_i = u + v;  x_{i+h} = (u - v) * W[(i mod h) << s]
- *             output bin e is stored at sigma(e) = (e & 7)*64 + (e >> 3)
- *   inverse:  stages s = 8..0 (decimation-in-time, conjugate twiddles):
- *               (u, v) = (x_i, x_{i+h} * conj(W));  x_i = u + v;  x_{i+h} = u - v
+ *             9 stages s = 0..8, h = 256 >> s, evaluation tree of X^512 - 1 (natural order in,
+ *             bit-reversed frequency out): for i with (i & h) == 0,
+ *               (u, v) = (x_i, x_{i+h}),  w = W[bitrev8(i >> (9 - s))],  (x_i, x_{i+h}) = (u + w v, u - w v)
+ *             output bin e (= frequency bitrev9(e)) is stored at sigma(e) = (e & 7)*64 + (e >> 3)
+ *   inverse:  stages s = 8..0 (decimation in time, bit-reversed in, natural out), h = 256 >> s:
+ *               (u, v) = (x_i, x_{i+h}),  w = conj(W[(i mod h) << s]),  (x_i, x_{i+h}) = (u + w v, u - w v)
  *             y_j = x_j * conj(E[j]) / 512;  p_j = rint(Re y_j), p_{j+512} = rint(Im y_j), wrapped
- *   complex products are   re = fma(a.re, b.re, -(a.im*b.im)),  im = fma(a.re, b.im, a.im*b.re)
- *   (and the conjugate form  re = fma(a.re, b.re, a.im*b.im),  im = fma(a.im, b.re, -(a.re*b.im))).
+ *   twist products are   re = fma(a.re, b.re, -(a.im*b.im)),  im = fma(a.re, b.im, a.im*b.re)
+ *   (untwist: re = fma(a.re, b.re, a.im*b.im),  im = fma(a.im, b.re, -(a.re*b.im))).
  * ---------------------------------------------------------------------------------------- */
 static inline int sigma_of(int e) { return ((e & 7) << 6) | (e >> 3); }
+static inline int bitrev8(int b)
+{
+    int r = 0;
+    for (int k = 0; k < 8; k++) r |= ((b >> k) & 1) << (7 - k);
+    return r;
+}
+
+/* (u, v) -> (u + w v, u - w v), w = W[k] (conj = 0) or conj(W[k]) (conj = 1).
+ * `moves`: this stage applies w = 1 and w = i as exact moves (the three register-constant stages:
+ * forward 0,1,2 and inverse 8,7,6); every other stage uses the fused form for EVERY twiddle, also
+ * where the table value happens to be 1 or i, because that is what a lane-uniform kernel executes. */
+static inline void butterfly(double *ur, double *ui, double *vr, double *vi, int k, int conj, int moves)
+{
+    double ar, ai;
+    if (moves && k == 0) {
+        ar = *ur + *vr; ai = *ui + *vi;
+        *vr = *ur - *vr; *vi = *ui - *vi;
+        *ur = ar; *ui = ai;
+        return;
+    }
+    if (moves && k == 128) { /* w = i or -i */
+        double tr = conj ? *vi : -*vi, ti = conj ? -*vr : *vr;
+        ar = *ur + tr; ai = *ui + ti;
+        *vr = *ur - tr; *vi = *ui - ti;
+        *ur = ar; *ui = ai;
+        return;
+    }
+    double wr = EOC_E2048[4 * k][0], wi = conj ? -EOC_E2048[4 * k][1] : EOC_E2048[4 * k][1];
+    ar = FMA(-wi, *vi, FMA(wr, *vr, *ur));
+    ai = FMA(wr, *vi, FMA(wi, *vr, *ui));
+    *vr = FMA(2.0, *ur, -ar);
+    *vi = FMA(2.0, *ui, -ai);
+    *ur = ar; *ui = ai;
+}
 
 void orc_fft_fwd(const int32_t *poly, double *spec)
 {
@@ -236,14 +280,7 @@ void orc_fft_fwd(const int32_t *poly, double *spec)
         int h = 256 >> s;
         for (int i = 0; i < NH; i++) {
             if (i & h) continue;
-            int k = (i & (h - 1)) << s;
-            double wr = EOC_E2048[4 * k][0], wi = EOC_E2048[4 * k][1];
-            double ur = xr[i], ui = xi[i], vr = xr[i + h], vi = xi[i + h];
-            xr[i] = ur + vr;
-            xi[i] = ui + vi;
-            double tr = ur - vr, ti = ui - vi;
-            xr[i + h] = FMA(tr, wr, -(ti * wi));
-            xi[i + h] = FMA(tr, wi, ti * wr);
+            butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], bitrev8(i >> (9 - s)), 0, s <= 2);
         }
     }
     for (int e = 0; e < NH; e++) {
@@ -269,15 +306,7 @@ void orc_fft_inv(const double *spec, int32_t *poly)
         int h = 256 >> s;
         for (int i = 0; i < NH; i++) {
             if (i & h) continue;
-            int k = (i & (h - 1)) << s;
-            double wr = EOC_E2048[4 * k][0], wi = EOC_E2048[4 * k][1];
-            double ur = xr[i], ui = xi[i], vr = xr[i + h], vi = xi[i + h];
-            double pr = FMA(vr, wr, vi * wi);
-            double pi = FMA(vi, wr, -(vr * wi));
-            xr[i] = ur + pr;
-            xi[i] = ui + pi;
-            xr[i + h] = ur - pr;
-            xi[i + h] = ui - pi;
+            butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], (i & (h - 1)) << s, 1, s >= 6);
         }
     }
     for (int j = 0; j < NH; j++) {

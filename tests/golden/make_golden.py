@@ -28,7 +28,7 @@ def sha(a):
 
 def main():
     L = ol.lib()
-    g = {"version": {"transform": "canonical-v1", "prng": "splitmix-ctr-v1"}}
+    g = {"version": {"transform": "canonical-v2", "prng": "splitmix-ctr-v1"}}
     # PRNG / scalar KATs
     g["prng"] = {
         "stream_key(1,3,5)": str(L.orc_stream_key(1, 3, 5)),
