@@ -618,22 +618,42 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // digits are transformed two at a time (skewed schedule on one scratch), an odd last one alone
         auto pair_pass = [&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
+#ifndef EOC_BK_PREFETCH
+#define EOC_BK_PREFETCH 0
+#endif
             d2 ba[8], bb[8], xa[8], xb[8];
             load_row(p, h, ba);
             load_row(p + 1, h, bb);
+#if EOC_BK_PREFETCH == 2
+            d2 ca[8], cb[8];
+            load_row(p, 1 - h, ca);
+            load_row(p + 1, 1 - h, cb);
+#endif
             make_x(p, xa);
             make_x(p + 1, xb);
             EOC_STAMP(1);
+#if EOC_BK_PREFETCH == 1
+            d2 ca[8], cb[8];
+            fft_fwd_wave_x2_head(xa, xb, s_tw, scr, lane);
+            load_row(p, 1 - h, ca);
+            load_row(p + 1, 1 - h, cb);
+            fft_fwd_wave_x2_tail(xa, xb, s_tw, scr, lane);
+#else
             fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
+#endif
             EOC_STAMP(2);
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
-            // the partner polynomial's rows re-use the same registers (measured: issuing them earlier
-            // costs spills and gains nothing, the co-resident wave covers the latency)
+#if EOC_BK_PREFETCH == 0
+            // the partner polynomial's rows re-use the same registers
             load_row(p, 1 - h, ba);
             load_row(p + 1, 1 - h, bb);
             mac(p == 1, xa, ba, theirs);
             mac(false, xb, bb, theirs);
+#else
+            mac(p == 1, xa, ca, theirs);
+            mac(false, xb, cb, theirs);
+#endif
             EOC_STAMP(3);
         };
         auto single_pass = [&](auto pc) __attribute__((always_inline)) {

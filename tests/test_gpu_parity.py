@@ -203,3 +203,75 @@ def test_full_size_batch_parity_set_a(eoc, rig_a):
     assert np.array_equal(got[sl], r.orc.gate_batch(ol.OPS["NAND"], c0[sl], c1[sl]))
     # determinism: same inputs, same bits
     assert np.array_equal(got, r.gate(eoc.OPS["NAND"], c0, c1))
+
+
+def test_full_size_set_b_parity(eoc):
+    """Set B (n=630, l=3, Bgbit=7 -- what the reference's minimum_lambda=128 selects): NAND/XOR/MUX
+    on 16 gates bit-exact vs the oracle, 256 gates by decryption."""
+    r = Rig(eoc, 1, 1)
+    b0, c0 = _rand_cts(r, 256, 52, 0)
+    b1, c1 = _rand_cts(r, 256, 53, 0)
+    b2, c2 = _rand_cts(r, 256, 54, 0)
+    got = r.gate(eoc.OPS["NAND"], c0, c1)
+    assert np.array_equal(r.sk.decrypt_bits(got), 1 - (b0 & b1))
+    sl = slice(0, 16)
+    assert np.array_equal(got[sl], r.orc.gate_batch(ol.OPS["NAND"], c0[sl], c1[sl]))
+    assert np.array_equal(r.gate(eoc.OPS["XOR"], c0[sl], c1[sl]), r.orc.gate_batch(ol.OPS["XOR"], c0[sl], c1[sl]))
+    gm = r.gate(eoc.OPS["MUX"], c0, c1, c2)
+    assert np.array_equal(r.sk.decrypt_bits(gm), np.where(b0 == 1, b1, b2))
+    assert np.array_equal(gm[sl], r.orc.gate_batch(ol.OPS["MUX"], c0[sl], c1[sl], c2[sl]))
+
+
+def test_edge_cases_and_errors(eoc, rig_small):
+    r = rig_small
+    torch = torch_cuda()
+    _, a = _rand_cts(r, 3, 61)
+    _, b = _rand_cts(r, 3, 62)
+    da, db = to_dev(a), to_dev(b)
+    out = torch.zeros_like(da)
+    # empty batch is a no-op
+    r.eng.gate_batch_device(0, da.data_ptr(), db.data_ptr(), None, out.data_ptr(), 0)
+    sync()
+    assert not out.cpu().numpy().any()
+    # bad opcode, missing operand
+    with pytest.raises(eoc.EocError):
+        r.eng.gate_batch_device(99, da.data_ptr(), db.data_ptr(), None, out.data_ptr(), 3)
+    with pytest.raises(eoc.EocError):
+        r.eng.gate_batch_device(eoc.OPS["MUX"], da.data_ptr(), db.data_ptr(), None, out.data_ptr(), 3)
+    with pytest.raises(eoc.EocError):
+        r.eng.gate_batch_device(0, da.data_ptr(), db.data_ptr(), None, out.data_ptr(), 3, ops=np.array([0, 77, 0], np.uint8))
+    # an engine without a cloud key refuses to run gates
+    e2 = eoc.Engine(r.p)
+    with pytest.raises(eoc.EocError, match="no cloud key"):
+        e2.gate_batch_device(0, da.data_ptr(), db.data_ptr(), None, out.data_ptr(), 3)
+    # adopting another engine's images works (the multi-GPU hand-off path)
+    kb, kk = r.eng.cloud_key_device()
+    e2.set_cloud_key_device(kb, kk)
+    e2.gate_batch_device(0, da.data_ptr(), db.data_ptr(), None, out.data_ptr(), 3)
+    sync()
+    assert np.array_equal(out.cpu().numpy(), r.orc.gate_batch(0, a, b))
+    e2.close()
+    # single gate, and a batch that is not a multiple of any tile size
+    for cnt in (1, 67):
+        _, x = _rand_cts(r, cnt, 63)
+        _, y = _rand_cts(r, cnt, 64)
+        assert np.array_equal(r.gate(eoc.OPS["XNOR"], x, y), r.orc.gate_batch(ol.OPS["XNOR"], x, y))
+
+
+def test_properties_at_bench_size(eoc, rig_a):
+    """BASELINE config 2 size (1024 gates, Set A): size-independent properties -- double negation through
+    bootstrapped gates, De Morgan, XOR self-inverse -- checked by decryption on the full batch."""
+    r = rig_a
+    cnt = 1024
+    b0, c0 = _rand_cts(r, cnt, 71)
+    b1, c1 = _rand_cts(r, cnt, 72)
+    nand = r.gate(eoc.OPS["NAND"], c0, c1)
+    and_ = r.gate(eoc.OPS["AND"], c0, c1)
+    assert np.array_equal(r.sk.decrypt_bits(r.gate(eoc.OPS["NOT"], nand)), r.sk.decrypt_bits(and_))
+    nor_of_not = r.gate(eoc.OPS["NOR"], r.gate(eoc.OPS["NOT"], c0), r.gate(eoc.OPS["NOT"], c1))
+    assert np.array_equal(r.sk.decrypt_bits(nor_of_not), b0 & b1)            # De Morgan
+    x = r.gate(eoc.OPS["XOR"], c0, c1)
+    assert np.array_equal(r.sk.decrypt_bits(r.gate(eoc.OPS["XOR"], x, c1)), b0)  # (a^b)^b = a
+    # outputs of bootstrapped gates are fresh: noise stays small after three levels
+    ph = np.array([r.sk.phase(v) for v in r.gate(eoc.OPS["XOR"], x, c1)[:64]]) / 2**32
+    assert np.abs(np.abs(ph) - 0.125).max() < 1 / 16
