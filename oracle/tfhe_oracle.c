@@ -5,7 +5,7 @@
  * Every function cites what it follows: SURVEY.md Appendix A (the recalled conventions of the
  * absent upstream module tfhe/tfhe@bc71bfae) and the nearest call site in /root/reference.
  *
- * Build: gcc -O2 -mavx2 -mfma -ffp-contract=off -fopenmp  (see oracle/Makefile).
+ * Build: gcc -O3 -mavx2 -mfma -ffp-contract=off -fopenmp  (see oracle/Makefile).
  * -ffp-contract=off is REQUIRED: the canonical transform names every fused multiply-add
  * explicitly (__builtin_fma) and every other * and + must round separately, so that the
  * HIP engine (compiled with the same flag) matches bit for bit.
@@ -243,7 +243,7 @@ static inline int bitrev8(int b)
  * `moves`: this stage applies w = 1 and w = i as exact moves (the three register-constant stages:
  * forward 0,1,2 and inverse 8,7,6); every other stage uses the fused form for EVERY twiddle, also
  * where the table value happens to be 1 or i, because that is what a lane-uniform kernel executes. */
-static inline void butterfly(double *ur, double *ui, double *vr, double *vi, int k, int conj, int moves)
+static inline __attribute__((always_inline)) void butterfly(double *ur, double *ui, double *vr, double *vi, int k, int conj, int moves)
 {
     double ar, ai;
     if (moves && k == 0) {
@@ -276,11 +276,18 @@ void orc_fft_fwd(const int32_t *poly, double *spec)
         xr[j] = FMA(a, tc, -(b * ts));
         xi[j] = FMA(a, ts, b * tc);
     }
-    for (int s = 0; s < 9; s++) {
+    for (int s = 0; s < 3; s++) { /* register-constant stages: w = 1, i are moves */
         int h = 256 >> s;
-        for (int i = 0; i < NH; i++) {
-            if (i & h) continue;
-            butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], bitrev8(i >> (9 - s)), 0, s <= 2);
+        for (int blk = 0; blk < (1 << s); blk++) {
+            int k = bitrev8(blk), base = blk * 2 * h;
+            for (int i = base; i < base + h; i++) butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], k, 0, 1);
+        }
+    }
+    for (int s = 3; s < 9; s++) { /* fused form for every twiddle */
+        int h = 256 >> s;
+        for (int blk = 0; blk < (1 << s); blk++) {
+            int k = bitrev8(blk), base = blk * 2 * h;
+            for (int i = base; i < base + h; i++) butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], k, 0, 0);
         }
     }
     for (int e = 0; e < NH; e++) {
@@ -302,12 +309,17 @@ void orc_fft_inv(const double *spec, int32_t *poly)
         xr[e] = spec[2 * sigma_of(e)];
         xi[e] = spec[2 * sigma_of(e) + 1];
     }
-    for (int s = 8; s >= 0; s--) {
+    for (int s = 8; s >= 6; s--) { /* register-constant stages: w = 1, conj(i) are moves */
         int h = 256 >> s;
-        for (int i = 0; i < NH; i++) {
-            if (i & h) continue;
-            butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], (i & (h - 1)) << s, 1, s >= 6);
-        }
+        for (int base = 0; base < NH; base += 2 * h)
+            for (int j = 0; j < h; j++)
+                butterfly(&xr[base + j], &xi[base + j], &xr[base + j + h], &xi[base + j + h], j << s, 1, 1);
+    }
+    for (int s = 5; s >= 0; s--) { /* fused form for every twiddle */
+        int h = 256 >> s;
+        for (int base = 0; base < NH; base += 2 * h)
+            for (int j = 0; j < h; j++)
+                butterfly(&xr[base + j], &xi[base + j], &xr[base + j + h], &xi[base + j + h], j << s, 1, 0);
     }
     for (int j = 0; j < NH; j++) {
         double tc = EOC_E2048[j][0] * 0.001953125, ts = EOC_E2048[j][1] * 0.001953125;

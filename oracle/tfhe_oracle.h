@@ -79,7 +79,7 @@ void orc_encrypt_bit(const orc_params *p, const int32_t *lwe_key, uint64_t enc_s
                      int bit, int32_t *ct);
 int orc_decrypt_bit(const orc_params *p, const int32_t *lwe_key, const int32_t *ct);
 
-/* ---- canonical transform v1 ---- */
+/* ---- canonical transform v2 ---- */
 void orc_fft_fwd(const int32_t *poly, double *spec);   /* 1024 ints -> 512 complex, order sigma */
 void orc_fft_inv(const double *spec, int32_t *poly);   /* 512 complex -> 1024 torus32 (wrapped) */
 
