@@ -140,6 +140,27 @@ def lib():
         "gateXNOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
         "gateNOT": (vp, [C.c_char_p, C.c_char_p]),
         "gateMUX": (vp, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        # f1: the reference's 11 calls
+        "generateSecretKey": (vp, [C.c_char_p, C.c_char_p]),
+        "generatePublicKey": (vp, []),
+        "encryptInteger": (vp, [C.c_int32, C.c_char_p]),
+        "encryptInteger_dummy": (vp, [C.c_int32, C.c_char_p]),
+        "decryptInteger": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "addCiphertexts": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "subtractCiphertexts": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
+        "encrypt8BitASCIIString": (vp, [C.c_char_p, C.c_int16, C.c_char_p]),
+        "decrypt8BitASCIIString": (vp, [C.c_char_p, C.c_int16, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "info": (None, []),
+        "testJWT": (None, []),
+        # f2: key export / import
+        "eoc_secret_key_export": (sz, [vp, vp, sz]),
+        "eoc_secret_key_import": (C.c_int, [vp, sz, C.c_int, C.POINTER(vp)]),
+        "eoc_cloud_key_blob_bytes": (sz, [PP]),
+        "eoc_cloud_key_export": (C.c_int, [vp, vp, sz]),
+        "eoc_cloud_key_blob_params": (C.c_int, [vp, sz, PP]),
+        "eoc_engine_create_from_cloud_key_blob": (C.c_int, [C.c_int, vp, sz, C.POINTER(vp)]),
+        "exportSecretKey": (vp, []),
+        "importSecretKey": (C.c_int, [C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -226,6 +247,32 @@ class SecretKey:
         v = _np_view(self.L.eoc_sk_ksk(self.h), self.L.eoc_ksk_len(C.byref(p)), np.int32)
         return None if v is None else v.reshape(-1, p.n + 1)
 
+    def export_bytes(self):
+        """EOCSK1 blob (params | seed | key bits)."""
+        need = self.L.eoc_secret_key_export(self.h, None, 0)
+        buf = (C.c_ubyte * need)()
+        self.L.eoc_secret_key_export(self.h, buf, need)
+        return bytes(buf)
+
+    @classmethod
+    def from_bytes(cls, blob, with_cloud_key=True):
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.h = C.c_void_p()
+        _check(self.L.eoc_secret_key_import(blob, len(blob), int(with_cloud_key), C.byref(self.h)),
+               "eoc_secret_key_import")
+        self.params = self.L.eoc_sk_params(self.h).contents.copy()
+        self.n = self.params.n
+        self.seed = None
+        return self
+
+    def export_cloud_key(self):
+        """EOCCK1 blob (params | bk | ksk): everything a server needs, no secret material."""
+        need = self.L.eoc_cloud_key_blob_bytes(C.byref(self.params))
+        buf = np.empty(need, np.uint8)
+        _check(self.L.eoc_cloud_key_export(self.h, buf.ctypes.data, need), "eoc_cloud_key_export")
+        return buf
+
     def encrypt_bits(self, bits, enc_seed, first_idx=0):
         bits = np.ascontiguousarray(np.asarray(bits).ravel(), np.uint8)
         out = np.empty((bits.size, self.n + 1), np.int32)
@@ -254,6 +301,22 @@ class Engine:
         _check(self.L.eoc_engine_create(device, C.byref(self.params), C.byref(self.h)), "eoc_engine_create")
         self.device = device
         self.n = params.n
+
+    @classmethod
+    def from_cloud_key_blob(cls, blob, device=0):
+        """Server side: engine + key images from an EOCCK1 blob alone."""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        self = cls.__new__(cls)
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.params = Params()
+        _check(self.L.eoc_cloud_key_blob_params(blob.ctypes.data, blob.size, C.byref(self.params)),
+               "eoc_cloud_key_blob_params")
+        _check(self.L.eoc_engine_create_from_cloud_key_blob(device, blob.ctypes.data, blob.size, C.byref(self.h)),
+               "eoc_engine_create_from_cloud_key_blob")
+        self.device = device
+        self.n = self.params.n
+        return self
 
     def close(self):
         if getattr(self, "h", None):
@@ -390,6 +453,67 @@ def circuit_run(gates, wires, instances):
 class Tfhe:
     """String façade in the shape of ao-tfhe/tfhe.lua (Tfhe.* -> backend.*), for the Boolean path."""
 
+    # ---- the reference's 11 functions (ao-tfhe/tfhe.lua:4-53), same names and argument order ----
+    @staticmethod
+    def info():
+        return lib().info()
+
+    @staticmethod
+    def testJWT():
+        return lib().testJWT()
+
+    @staticmethod
+    def generateSecretKey(jwtToken, jwksBase64):
+        return _take_str(lib().generateSecretKey(jwtToken.encode(), jwksBase64.encode()))
+
+    @staticmethod
+    def generatePublicKey():
+        return _take_str(lib().generatePublicKey())
+
+    @staticmethod
+    def encryptInteger(value, key=""):
+        return _take_str(lib().encryptInteger(int(value), key.encode()))
+
+    @staticmethod
+    def encryptInteger_dummy(value, key=""):
+        return _take_str(lib().encryptInteger_dummy(int(value), key.encode()))
+
+    @staticmethod
+    def decryptInteger(value, key, jwtToken, jwksBase64):
+        return lib().decryptInteger(value.encode(), key.encode(), jwtToken.encode(), jwksBase64.encode())
+
+    @staticmethod
+    def addCiphertexts(c1, c2, public_key=""):
+        return _take_str(lib().addCiphertexts(c1.encode(), c2.encode(), public_key.encode()))
+
+    @staticmethod
+    def subtractCiphertexts(c1, c2, public_key=""):
+        # ao-tfhe/tfhe.lua:41-43 forwards subtract to backend.addCiphertexts; tests/tfhe.test.js:185
+        # pins the result (50 "-" 8 = 58).  Kept for drop-in behaviour; the real one is below.
+        return _take_str(lib().addCiphertexts(c1.encode(), c2.encode(), public_key.encode()))
+
+    @staticmethod
+    def subtractCiphertexts_backend(c1, c2, public_key=""):
+        return _take_str(lib().subtractCiphertexts(c1.encode(), c2.encode(), public_key.encode()))
+
+    @staticmethod
+    def encryptASCIIString(value, length, key=""):
+        return _take_str(lib().encrypt8BitASCIIString(value.encode(), int(length), key.encode()))
+
+    @staticmethod
+    def decryptASCIIString(value, length, key, jwtToken, jwksBase64):
+        return _take_str(lib().decrypt8BitASCIIString(value.encode(), int(length), key.encode(),
+                                                      jwtToken.encode(), jwksBase64.encode()))
+
+    @staticmethod
+    def exportSecretKey():
+        return _take_str(lib().exportSecretKey())
+
+    @staticmethod
+    def importSecretKey(b64):
+        return lib().importSecretKey(b64.encode())
+
+    # ---- Boolean path -----------------------------------------------------------------------------
     @staticmethod
     def generateGateKey(minimum_lambda=80, seed=1):
         return _take_str(lib().generateGateKey(minimum_lambda, seed))

@@ -6,6 +6,7 @@
 // Nothing here evaluates a gate: all boots* work is forwarded to the HIP engine (engine.hip), and
 // fails when no GPU is present.
 #include "common.h"
+#include "host_internal.h"
 #include "../../include/eoc_tfhe_gpu.h"
 
 #include <cmath>
@@ -127,12 +128,6 @@ extern "C" int32_t eoc_modswitch_from_torus32(int32_t phase, int32_t Msize)
 // ------------------------------------------------------------------------------------------------
 // secret key set (TFheGateBootstrappingSecretKeySet; built at eoc-tfhe-run.cpp:231)
 // ------------------------------------------------------------------------------------------------
-struct eoc_secret_key {
-    eoc_params p;
-    uint64_t seed;
-    std::vector<int32_t> lwe, tlwe, bk, ksk;
-};
-
 static void make_ksk(eoc_secret_key &k)
 {
     const eoc_params &p = k.p;
@@ -247,7 +242,7 @@ extern "C" int eoc_decrypt_bits(const eoc_secret_key *sk, const int32_t *cts, si
 // base64 + the LWE sample wire format (export_lweSample_toStream bytes, eoc-tfhe-run.cpp:293-295:
 // little-endian a[n] | b | f64 current_variance)
 // ------------------------------------------------------------------------------------------------
-namespace {
+namespace eoc_host {
 const char kB64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
 
 std::string b64_encode(const unsigned char *d, size_t len)
@@ -296,35 +291,67 @@ char *dup_cstr(const std::string &s)
     if (r) memcpy(r, s.c_str(), s.size() + 1);
     return r;
 }
-char *sample_to_b64(const int32_t *ct, int n)
+// LWE sample <-> export_lweSample_toStream bytes: a[n] | b | f64 current_variance (little endian)
+void sample_to_bytes(const int32_t *ct, int n, double variance, std::string &out)
 {
-    std::vector<unsigned char> buf(size_t(n + 1) * 4 + 8);
-    memcpy(buf.data(), ct, size_t(n + 1) * 4);
-    double var = 0.0;
-    memcpy(buf.data() + size_t(n + 1) * 4, &var, 8);
-    return dup_cstr(b64_encode(buf.data(), buf.size()));
+    out.append(reinterpret_cast<const char *>(ct), size_t(n + 1) * 4);
+    out.append(reinterpret_cast<const char *>(&variance), 8);
 }
-bool b64_to_sample(const char *s, int n, std::vector<int32_t> &ct)
+bool bytes_to_sample(const char *raw, size_t len, int n, std::vector<int32_t> &ct, double *variance)
+{
+    if (len < size_t(n + 1) * 4 + 8) return false;
+    ct.resize(n + 1);
+    memcpy(ct.data(), raw, size_t(n + 1) * 4);
+    if (variance) memcpy(variance, raw + size_t(n + 1) * 4, 8);
+    return true;
+}
+char *sample_to_b64(const int32_t *ct, int n, double variance)
+{
+    std::string raw;
+    sample_to_bytes(ct, n, variance, raw);
+    return dup_cstr(b64_encode(reinterpret_cast<const unsigned char *>(raw.data()), raw.size()));
+}
+bool b64_to_sample(const char *s, int n, std::vector<int32_t> &ct, double *variance)
 {
     if (!s) return false;
     std::string raw = b64_decode(s);
     if (raw.size() != size_t(n + 1) * 4 + 8) return false;
-    ct.resize(n + 1);
-    memcpy(ct.data(), raw.data(), size_t(n + 1) * 4);
-    return true;
+    return bytes_to_sample(raw.data(), raw.size(), n, ct, variance);
 }
 
 // process-global key context (globalSecretKey / globalPublicKey, eoc-tfhe-run.cpp:38-39)
-std::mutex g_mu;
-eoc_secret_key *g_sk = nullptr;
-uint64_t g_enc_counter = 0;
-uint64_t g_enc_seed = 0;
-} // namespace
+GlobalCtx &ctx()
+{
+    static GlobalCtx c;
+    return c;
+}
+uint64_t mix64(uint64_t z) { return Stream::fin(z); }
+
+// the GPU engine behind the global key: created and loaded on first use by a gate call
+int ensure_engine_locked()
+{
+    GlobalCtx &c = ctx();
+    if (!c.sk) return EOC_ERR_NO_KEY;
+    if (c.engine_ready) return EOC_OK;
+    if (!eoc_global_engine()) {
+        int rc = eoc_gpu_init(0, &c.sk->p);
+        if (rc) return rc;
+    }
+    if (c.sk->bk.empty() || c.sk->ksk.empty()) return EOC_ERR_NO_KEY;
+    int rc = eoc_engine_load_cloud_key(eoc_global_engine(), c.sk->bk.data(), c.sk->ksk.data());
+    if (rc) return rc;
+    c.engine_ready = true;
+    return EOC_OK;
+}
+} // namespace eoc_host
+
+using namespace eoc_host;
 
 extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
 {
-    std::lock_guard<std::mutex> g(g_mu);
-    if (g_sk) { // eoc-tfhe-run.cpp:245-249
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.sk) { // eoc-tfhe-run.cpp:245-249
         fprintf(stdout, "Secret key is already generated for this instance...\n");
         return nullptr;
     }
@@ -332,17 +359,15 @@ extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
     if (eoc_params_for_lambda(minimum_lambda, &p)) return nullptr;
     eoc_secret_key *sk = nullptr;
     if (eoc_keygen(&p, seed, 1, &sk)) return nullptr;
-    if (!eoc_global_engine() && eoc_gpu_init(0, &p)) {
+    c.sk = sk;
+    c.enc_seed = mix64(seed ^ 0xA5A5A5A5DEADBEEFull);
+    c.enc_counter = 0;
+    c.engine_ready = false;
+    if (ensure_engine_locked()) { // the gate key is useless without the engine: fail loudly
         eoc_secret_key_free(sk);
+        c.sk = nullptr;
         return nullptr;
     }
-    if (eoc_engine_load_cloud_key(eoc_global_engine(), sk->bk.data(), sk->ksk.data())) {
-        eoc_secret_key_free(sk);
-        return nullptr;
-    }
-    g_sk = sk;
-    g_enc_seed = Stream::fin(seed ^ 0xA5A5A5A5DEADBEEFull);
-    g_enc_counter = 0;
     char tok[96];
     snprintf(tok, sizeof tok, "EOCGATEKEY n=%d l=%d Bgbit=%d seed=%llu", p.n, p.l, p.Bgbit, (unsigned long long)seed);
     return dup_cstr(b64_encode(reinterpret_cast<const unsigned char *>(tok), strlen(tok)));
@@ -350,58 +375,64 @@ extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
 
 extern "C" void resetGateKey(void)
 {
-    std::lock_guard<std::mutex> g(g_mu);
-    eoc_secret_key_free(g_sk);
-    g_sk = nullptr;
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    eoc_secret_key_free(c.sk);
+    c.sk = nullptr;
+    c.engine_ready = false;
     eoc_gpu_shutdown();
 }
 
 extern "C" const char *encryptBit(int bit, const char *)
 {
-    std::lock_guard<std::mutex> g(g_mu);
-    if (!g_sk) { // eoc-tfhe-run.cpp:277-278
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) { // eoc-tfhe-run.cpp:277-278
         fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
         return nullptr;
     }
-    std::vector<int32_t> ct(g_sk->p.n + 1);
+    std::vector<int32_t> ct(c.sk->p.n + 1);
     uint8_t b = bit ? 1 : 0;
-    eoc_encrypt_bits(g_sk, g_enc_seed, g_enc_counter++, &b, 1, ct.data());
-    return sample_to_b64(ct.data(), g_sk->p.n);
+    eoc_encrypt_bits(c.sk, c.enc_seed, c.enc_counter++, &b, 1, ct.data());
+    return sample_to_b64(ct.data(), c.sk->p.n, c.sk->p.ks_stdev * c.sk->p.ks_stdev);
 }
 
 extern "C" int decryptBit(const char *b64ct, const char *)
 {
-    std::lock_guard<std::mutex> g(g_mu);
-    if (!g_sk) { // eoc-tfhe-run.cpp:421-424
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) { // eoc-tfhe-run.cpp:421-424
         fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
         return -1;
     }
     std::vector<int32_t> ct;
-    if (!b64_to_sample(b64ct, g_sk->p.n, ct)) {
+    if (!b64_to_sample(b64ct, c.sk->p.n, ct, nullptr)) {
         fprintf(stderr, "decryptBit: malformed ciphertext\n");
         return -1;
     }
-    return eoc_lwe_phase(g_sk, ct.data()) > 0 ? 1 : 0;
+    return eoc_lwe_phase(c.sk, ct.data()) > 0 ? 1 : 0;
 }
 
 static const char *gate_strings(int op, const char *c1, const char *c2, const char *c3)
 {
-    std::lock_guard<std::mutex> g(g_mu);
-    if (!g_sk || !eoc_global_engine()) { // eoc-tfhe-run.cpp:465-468
-        fprintf(stderr, "Public key not initialized. Generate the secret key first.\n");
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) { // eoc-tfhe-run.cpp:465-468
+        fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
         return nullptr;
     }
-    const int n = g_sk->p.n;
-    std::vector<int32_t> a, b, c, out(n + 1);
-    if (!b64_to_sample(c1, n, a) || (op != EOC_NOT && !b64_to_sample(c2, n, b)) ||
-        (op == EOC_MUX && !b64_to_sample(c3, n, c))) {
+    if (ensure_engine_locked()) return nullptr; // no GPU: no gates (message already on stderr)
+    const int n = c.sk->p.n;
+    std::vector<int32_t> a, b, cc, out(n + 1);
+    if (!b64_to_sample(c1, n, a, nullptr) || (op != EOC_NOT && !b64_to_sample(c2, n, b, nullptr)) ||
+        (op == EOC_MUX && !b64_to_sample(c3, n, cc, nullptr))) {
         fprintf(stderr, "gate: malformed ciphertext\n");
         return nullptr;
     }
-    if (eoc_gate_batch(op, nullptr, a.data(), b.empty() ? nullptr : b.data(), c.empty() ? nullptr : c.data(),
+    if (eoc_gate_batch(op, nullptr, a.data(), b.empty() ? nullptr : b.data(), cc.empty() ? nullptr : cc.data(),
                        out.data(), 1))
         return nullptr;
-    return sample_to_b64(out.data(), n);
+    return sample_to_b64(out.data(), n, 0.0);
 }
 
 extern "C" const char *gateNAND(const char *a, const char *b, const char *) { return gate_strings(EOC_NAND, a, b, nullptr); }

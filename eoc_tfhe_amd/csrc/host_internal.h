@@ -1,0 +1,39 @@
+// host_internal.h -- shared between host.cpp (Boolean string API) and legacy.cpp (the reference's
+// own 11-call surface): the secret-key object, base64 / sample wire format helpers, global context.
+#pragma once
+#include "../../include/eoc_tfhe_gpu.h"
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// TFheGateBootstrappingSecretKeySet (built at ao-tfhe/eoc-tfhe-run.cpp:231)
+struct eoc_secret_key {
+    eoc_params p;
+    uint64_t seed;
+    std::vector<int32_t> lwe, tlwe, bk, ksk;
+};
+
+namespace eoc_host {
+
+std::string b64_encode(const unsigned char *d, size_t len);
+std::string b64_decode(const char *s);
+char *dup_cstr(const std::string &s);
+void sample_to_bytes(const int32_t *ct, int n, double variance, std::string &out);
+bool bytes_to_sample(const char *raw, size_t len, int n, std::vector<int32_t> &ct, double *variance);
+char *sample_to_b64(const int32_t *ct, int n, double variance);
+bool b64_to_sample(const char *s, int n, std::vector<int32_t> &ct, double *variance);
+uint64_t mix64(uint64_t z);
+
+// globalSecretKey / globalPublicKey (ao-tfhe/eoc-tfhe-run.cpp:38-39) and the engine behind them
+struct GlobalCtx {
+    std::mutex mu;
+    eoc_secret_key *sk = nullptr;
+    uint64_t enc_seed = 0, enc_counter = 0;
+    bool engine_ready = false;
+};
+GlobalCtx &ctx();
+int ensure_engine_locked(); // caller holds ctx().mu
+
+} // namespace eoc_host

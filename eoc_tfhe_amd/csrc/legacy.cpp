@@ -1,0 +1,435 @@
+// legacy.cpp -- SURVEY.md rows f1 and f2: the reference's own 11-call surface on the native library,
+// and key export / import.
+//
+// f1: same symbols, signatures and observable behaviour as ao-tfhe/eoc-tfhe-run.h:8-19 /
+// ao-tfhe/eoc-tfhe-run.cpp:167-513 (wide-message LWE: Msize = 2^31-1, alpha = 1/(10 Msize),
+// :35-36; additions only -- these ciphertexts are NOT bootstrappable).  All of it is
+// client-side CPU work, exactly as in the reference; nothing here touches the gate path.
+//
+// Deliberate differences (documented in INTEGRATION.md):
+//   * returned strings are malloc'ed (the Lua binding frees them with free(), eoc-tfhe-bindings.c:21;
+//     the reference returns new char[], eoc-tfhe-run.cpp:241-243);
+//   * generateSecretKey returns the compact key blob of f2 (the reference exports the whole upstream
+//     keyset, ~0.15 GB of base64, in a text format this repo cannot pin, :235-237);
+//   * the JWT check is the reference's shape check (:94-133), enabled at run time;
+//   * decrypt8BitASCIIString does not re-decrypt the stale globalString (:376, no observable effect).
+#include "common.h"
+#include "host_internal.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+using namespace eoc_host;
+
+namespace {
+
+const int kMinimumLambda = 128;                         // eoc-tfhe-run.cpp:34
+const int32_t kMsize = int32_t((1LL << 31) - 1);        // :35
+const double kAlpha = 1.0 / (10.0 * double(kMsize));    // :36
+
+// validateJWT (eoc-tfhe-run.cpp:94-133): non-empty, one dot not at either end, both sides made of
+// base64url characters.  (Everything after the FIRST dot is the "payload", so a real three-segment
+// JWT fails on its second dot -- the reference's own fixture has two segments, tests/tfhe.test.js:28-34.)
+bool validate_jwt(const char *token, const char *)
+{
+    if (!token) return false;
+    std::string t(token);
+    std::cout << "Validating JWT token...:" << t << std::endl;
+    if (t.empty()) {
+        std::cout << "JWT validation failed: Empty token" << std::endl;
+        return false;
+    }
+    size_t dot = t.find('.');
+    if (dot == std::string::npos || dot == 0 || dot == t.size() - 1) {
+        std::cout << "JWT validation failed: Missing or invalid dot separator" << std::endl;
+        return false;
+    }
+    auto b64url = [](const std::string &s) {
+        return !s.empty() &&
+               s.find_first_not_of("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_=") == std::string::npos;
+    };
+    if (!b64url(t.substr(0, dot))) {
+        std::cout << "JWT validation failed: Invalid header encoding" << std::endl;
+        return false;
+    }
+    if (!b64url(t.substr(dot + 1))) {
+        std::cout << "JWT validation failed: Invalid payload encoding" << std::endl;
+        return false;
+    }
+    return true;
+}
+
+// approxPhase(phase, Msize): nearest multiple of 1/Msize (what lweSymDecrypt returns)
+int32_t approx_phase(int32_t phase, int32_t Msize)
+{
+    uint64_t interv = ((uint64_t(1) << 63) / uint64_t(Msize)) * 2;
+    uint64_t half = interv / 2;
+    uint64_t ph = (uint64_t(uint32_t(phase)) << 32) + half;
+    ph -= ph % interv;
+    return int32_t(uint32_t(ph >> 32));
+}
+
+const char *no_secret_key()
+{
+    std::cerr << "Secret key not initialized. Generate the secret key first." << std::endl;
+    return nullptr;
+}
+
+// one wide-message sample of the global key: lweSymEncrypt(ct, modSwitchToTorus32(v, Msize), alpha, key)
+void encrypt_wide(GlobalCtx &c, int32_t value, int32_t *ct)
+{
+    eoc_lwe_encrypt(c.sk, c.enc_seed, c.enc_counter++, eoc_modswitch_to_torus32(value, kMsize), kAlpha, ct);
+}
+
+const char *linear_op(const char *b64a, const char *b64b, int sign)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) { // eoc-tfhe-run.cpp:465-468
+        std::cerr << "Public key not initialized. Generate the public key first." << std::endl;
+        return nullptr;
+    }
+    const int n = c.sk->p.n;
+    std::vector<int32_t> a, b;
+    double va = 0, vb = 0;
+    if (!b64_to_sample(b64a, n, a, &va) || !b64_to_sample(b64b, n, b, &vb)) {
+        std::cerr << "Malformed ciphertext." << std::endl;
+        return nullptr;
+    }
+    for (int m = 0; m <= n; m++) // lweCopy + lweAddTo / lweSubTo (eoc-tfhe-run.cpp:447-448,490-491)
+        a[m] = int32_t(uint32_t(a[m]) + uint32_t(sign) * uint32_t(b[m]));
+    return sample_to_b64(a.data(), n, va + vb);
+}
+
+// ---- f2: versioned flat key formats --------------------------------------------------------------
+// secret key blob: "EOCSK1\0\0" | n,l,Bgbit,ks_t,ks_basebit (5 x i32) | ks_stdev, bk_stdev (2 x f64) |
+//                  seed u64 | lwe bits (n bytes) | tlwe bits (1024 bytes)
+// cloud key blob : "EOCCK1\0\0" | same params | bk int32[eoc_bk_len] | ksk int32[eoc_ksk_len]
+const char kMagicSK[8] = {'E', 'O', 'C', 'S', 'K', '1', 0, 0};
+const char kMagicCK[8] = {'E', 'O', 'C', 'C', 'K', '1', 0, 0};
+const size_t kParamBytes = 5 * 4 + 2 * 8;
+
+void put_params(const eoc_params &p, unsigned char *o)
+{
+    int32_t v[5] = {p.n, p.l, p.Bgbit, p.ks_t, p.ks_basebit};
+    memcpy(o, v, 20);
+    memcpy(o + 20, &p.ks_stdev, 8);
+    memcpy(o + 28, &p.bk_stdev, 8);
+}
+bool get_params(const unsigned char *o, eoc_params &p)
+{
+    int32_t v[5];
+    memcpy(v, o, 20);
+    p.n = v[0]; p.l = v[1]; p.Bgbit = v[2]; p.ks_t = v[3]; p.ks_basebit = v[4];
+    memcpy(&p.ks_stdev, o + 20, 8);
+    memcpy(&p.bk_stdev, o + 28, 8);
+    return p.n >= 1 && p.n <= 1023 && p.l >= 1 && p.l <= 4 && p.Bgbit >= 1 && p.l * p.Bgbit <= 32 &&
+           p.ks_t >= 1 && p.ks_basebit >= 1 && p.ks_t * p.ks_basebit <= 31;
+}
+
+} // namespace
+
+// ================================================================================================
+// f2: key export / import
+// ================================================================================================
+extern "C" size_t eoc_secret_key_export(const eoc_secret_key *sk, void *buf, size_t cap)
+{
+    if (!sk) return 0;
+    const size_t need = 8 + kParamBytes + 8 + size_t(sk->p.n) + EOC_N;
+    if (!buf || cap < need) return need;
+    unsigned char *o = static_cast<unsigned char *>(buf);
+    memcpy(o, kMagicSK, 8);
+    put_params(sk->p, o + 8);
+    memcpy(o + 8 + kParamBytes, &sk->seed, 8);
+    unsigned char *bits = o + 8 + kParamBytes + 8;
+    for (int i = 0; i < sk->p.n; i++) bits[i] = (unsigned char)sk->lwe[i];
+    for (int j = 0; j < EOC_N; j++) bits[sk->p.n + j] = (unsigned char)sk->tlwe[j];
+    return need;
+}
+
+extern "C" int eoc_secret_key_import(const void *buf, size_t len, int with_cloud_key, eoc_secret_key **out)
+{
+    if (!buf || !out || len < 8 + kParamBytes + 8) {
+        eoc_set_error("eoc_secret_key_import: truncated blob");
+        return EOC_ERR_ARG;
+    }
+    const unsigned char *o = static_cast<const unsigned char *>(buf);
+    eoc_params p;
+    if (memcmp(o, kMagicSK, 8) != 0 || !get_params(o + 8, p) || len != 8 + kParamBytes + 8 + size_t(p.n) + EOC_N) {
+        eoc_set_error("eoc_secret_key_import: not an EOCSK1 blob");
+        return EOC_ERR_ARG;
+    }
+    uint64_t seed;
+    memcpy(&seed, o + 8 + kParamBytes, 8);
+    eoc_secret_key *sk = nullptr;
+    int rc = eoc_keygen(&p, seed, with_cloud_key, &sk); // keys are a deterministic function of (params, seed)
+    if (rc) return rc;
+    const unsigned char *bits = o + 8 + kParamBytes + 8;
+    bool same = true;
+    for (int i = 0; i < p.n && same; i++) same = bits[i] == (unsigned char)sk->lwe[i];
+    for (int j = 0; j < EOC_N && same; j++) same = bits[p.n + j] == (unsigned char)sk->tlwe[j];
+    if (!same) { // a blob written by another PRNG version: refuse rather than hand out a different key
+        eoc_secret_key_free(sk);
+        eoc_set_error("eoc_secret_key_import: key bits do not match the seed (PRNG version mismatch)");
+        return EOC_ERR_ARG;
+    }
+    *out = sk;
+    return EOC_OK;
+}
+
+extern "C" size_t eoc_cloud_key_blob_bytes(const eoc_params *p)
+{
+    return p ? 8 + kParamBytes + (eoc_bk_len(p) + eoc_ksk_len(p)) * 4 : 0;
+}
+
+extern "C" int eoc_cloud_key_export(const eoc_secret_key *sk, void *buf, size_t cap)
+{
+    if (!sk || !buf || sk->bk.empty() || sk->ksk.empty()) return EOC_ERR_NO_KEY;
+    if (cap < eoc_cloud_key_blob_bytes(&sk->p)) return EOC_ERR_ARG;
+    unsigned char *o = static_cast<unsigned char *>(buf);
+    memcpy(o, kMagicCK, 8);
+    put_params(sk->p, o + 8);
+    memcpy(o + 8 + kParamBytes, sk->bk.data(), sk->bk.size() * 4);
+    memcpy(o + 8 + kParamBytes + sk->bk.size() * 4, sk->ksk.data(), sk->ksk.size() * 4);
+    return EOC_OK;
+}
+
+// server side: bring an engine up from a cloud-key blob alone (no secret material)
+extern "C" int eoc_engine_create_from_cloud_key_blob(int device, const void *buf, size_t len, eoc_engine **out)
+{
+    if (!buf || !out || len < 8 + kParamBytes) {
+        eoc_set_error("cloud key blob: truncated");
+        return EOC_ERR_ARG;
+    }
+    const unsigned char *o = static_cast<const unsigned char *>(buf);
+    eoc_params p;
+    if (memcmp(o, kMagicCK, 8) != 0 || !get_params(o + 8, p) || len != eoc_cloud_key_blob_bytes(&p)) {
+        eoc_set_error("cloud key blob: not an EOCCK1 blob");
+        return EOC_ERR_ARG;
+    }
+    eoc_engine *e = nullptr;
+    int rc = eoc_engine_create(device, &p, &e);
+    if (rc) return rc;
+    const int32_t *bk = reinterpret_cast<const int32_t *>(o + 8 + kParamBytes);
+    rc = eoc_engine_load_cloud_key(e, bk, bk + eoc_bk_len(&p));
+    if (rc) {
+        eoc_engine_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return EOC_OK;
+}
+
+extern "C" int eoc_cloud_key_blob_params(const void *buf, size_t len, eoc_params *p)
+{
+    if (!buf || !p || len < 8 + kParamBytes) return EOC_ERR_ARG;
+    const unsigned char *o = static_cast<const unsigned char *>(buf);
+    if (memcmp(o, kMagicCK, 8) != 0 || !get_params(o + 8, *p)) return EOC_ERR_ARG;
+    return EOC_OK;
+}
+
+extern "C" const char *exportSecretKey(void)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) return no_secret_key();
+    std::vector<unsigned char> blob(eoc_secret_key_export(c.sk, nullptr, 0));
+    eoc_secret_key_export(c.sk, blob.data(), blob.size());
+    return dup_cstr(b64_encode(blob.data(), blob.size()));
+}
+
+// the import path the reference lacks (every base64Key argument is ignored, eoc-tfhe-bindings.c:63-110)
+extern "C" int importSecretKey(const char *base64Key)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.sk) {
+        std::cout << "Secret key is already generated for this instance..." << std::endl;
+        return -1;
+    }
+    if (!base64Key) return -1;
+    std::string raw = b64_decode(base64Key);
+    eoc_secret_key *sk = nullptr;
+    if (eoc_secret_key_import(raw.data(), raw.size(), 1, &sk)) return -1;
+    c.sk = sk;
+    c.enc_seed = mix64(sk->seed ^ 0xA5A5A5A5DEADBEEFull);
+    c.enc_counter = uint64_t(1) << 40; // never reuse the exporter's streams
+    c.engine_ready = false;
+    return 0;
+}
+
+// ================================================================================================
+// f1: the reference's 11 calls
+// ================================================================================================
+extern "C" void info()
+{ // eoc-tfhe-run.cpp:167-181
+    std::cout << "TFHE Library: Enabling fully homomorphic encryption computations on encrypted data." << std::endl;
+    std::cout << "JWT support: Enabled (format check)" << std::endl;
+    std::cout << "OpenSSL support: Disabled" << std::endl;
+    std::cout << "Gate bootstrapping: MI355X HIP engine, " << eoc_device_count() << " device(s) visible" << std::endl;
+}
+
+extern "C" void testJWT()
+{ // eoc-tfhe-run.cpp:183-212: internal string round trip + a static token through the validator
+    std::cout << "Testing JWT validation using a static token and a static jwks.json" << std::endl;
+    std::cout << "Short ASCII string inside job test using Hello Weavers! as demo string" << std::endl;
+    {
+        GlobalCtx &c = ctx();
+        std::lock_guard<std::mutex> g(c.mu);
+        if (c.sk) { // the reference dereferences a null key here; this build just skips the demo
+            const std::string msg = "Hello Weavers!";
+            const int n = c.sk->p.n;
+            std::string dec;
+            std::vector<int32_t> ct(n + 1);
+            for (char ch : msg) {
+                encrypt_wide(c, int32_t(ch), ct.data());
+                dec.push_back(char(eoc_modswitch_from_torus32(eoc_lwe_phase(c.sk, ct.data()), kMsize)));
+            }
+            std::cout << "Decrypted message internal test: " << dec << std::endl;
+        }
+    }
+    const char *token = "eyJhbGciOiJub25lIn0.eyJzdWIiOiJlb2MtdGZoZSJ9";
+    std::cout << (validate_jwt(token, "") ? "Token is valid." : "Token is invalid.") << std::endl;
+}
+
+extern "C" const char *generateSecretKey(const char *jwtToken, const char *jwksBase64)
+{ // eoc-tfhe-run.cpp:214-250
+    if (!validate_jwt(jwtToken, jwksBase64)) {
+        std::cerr << "Invalid JWT token. Exiting..." << std::endl;
+        return nullptr;
+    }
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (c.sk) {
+        std::cout << "Secret key is already generated for this instance..." << std::endl;
+        return nullptr;
+    }
+    std::cout << "Generating secret key started..." << std::endl;
+    uint32_t seed = uint32_t(lrand48()); // the reference's seeding, unseeded lrand48 and all (:226-228)
+    eoc_params p;
+    if (eoc_params_for_lambda(kMinimumLambda, &p)) return nullptr;
+    eoc_secret_key *sk = nullptr;
+    if (eoc_keygen(&p, seed, 1, &sk)) return nullptr;
+    c.sk = sk;
+    c.enc_seed = mix64(uint64_t(seed) ^ 0xA5A5A5A5DEADBEEFull);
+    c.enc_counter = 0;
+    c.engine_ready = false; // the GPU engine comes up on the first gate call, if there ever is one
+    std::vector<unsigned char> blob(eoc_secret_key_export(sk, nullptr, 0));
+    eoc_secret_key_export(sk, blob.data(), blob.size());
+    std::cout << "Generating secret key finished" << std::endl;
+    return dup_cstr(b64_encode(blob.data(), blob.size()));
+}
+
+// declared in eoc-tfhe-run.h:10, never defined by the reference (l_generatePublicKey pushes nothing,
+// eoc-tfhe-bindings.c:51-57).  Here: a short description of the cloud key, or NULL without a key.
+extern "C" const char *generatePublicKey()
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) return no_secret_key();
+    char tok[128];
+    snprintf(tok, sizeof tok, "EOCCLOUDKEY n=%d l=%d Bgbit=%d bytes=%zu", c.sk->p.n, c.sk->p.l, c.sk->p.Bgbit,
+             eoc_cloud_key_blob_bytes(&c.sk->p));
+    return dup_cstr(b64_encode(reinterpret_cast<const unsigned char *>(tok), strlen(tok)));
+}
+
+extern "C" const char *encryptInteger(int32_t value, const char *)
+{ // eoc-tfhe-run.cpp:282-310
+    std::cout << "Encrypting integer " << value << " started..." << std::endl;
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) return no_secret_key();
+    std::vector<int32_t> ct(c.sk->p.n + 1);
+    encrypt_wide(c, value, ct.data());
+    return sample_to_b64(ct.data(), c.sk->p.n, kAlpha * kAlpha);
+}
+
+extern "C" const char *encryptInteger_dummy(int32_t value, const char *key)
+{ // eoc-tfhe-run.cpp:252-280: same as encryptInteger apart from the log line
+    std::cout << "Encrypting integer DUMMY DUMMY DUMMY " << value << " started..." << std::endl;
+    return encryptInteger(value, key);
+}
+
+extern "C" const int decryptInteger(char *base64Ciphertext, const char *, const char *jwtToken, const char *jwksBase64)
+{ // eoc-tfhe-run.cpp:393-425
+    if (!validate_jwt(jwtToken, jwksBase64)) {
+        std::cerr << "Invalid JWT token. Exiting..." << std::endl;
+        return -1;
+    }
+    std::cout << "Decrypting integer started..." << std::endl;
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) {
+        no_secret_key();
+        return -1;
+    }
+    std::vector<int32_t> ct;
+    if (!b64_to_sample(base64Ciphertext, c.sk->p.n, ct, nullptr)) {
+        std::cerr << "Malformed ciphertext." << std::endl;
+        return -1;
+    }
+    int32_t t = approx_phase(eoc_lwe_phase(c.sk, ct.data()), kMsize); // lweSymDecrypt
+    return eoc_modswitch_from_torus32(t, kMsize);
+}
+
+extern "C" const char *addCiphertexts(const char *a, const char *b, const char *)
+{ // eoc-tfhe-run.cpp:427-470
+    std::cout << "Adding ciphertexts started..." << std::endl;
+    return linear_op(a, b, +1);
+}
+
+extern "C" const char *subtractCiphertexts(const char *a, const char *b, const char *)
+{ // eoc-tfhe-run.cpp:472-513 (a real subtraction at this layer; the Lua facade is what maps
+  // Tfhe.subtractCiphertexts to addCiphertexts, ao-tfhe/tfhe.lua:41-43)
+    return linear_op(a, b, -1);
+}
+
+extern "C" const char *encrypt8BitASCIIString(const char *text, const int16_t msgLength, const char *)
+{ // eoc-tfhe-run.cpp:312-350: one wide-message sample per character, concatenated
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) return no_secret_key();
+    if (!text || msgLength < 0 || size_t(msgLength) > strlen(text)) {
+        std::cerr << "encrypt8BitASCIIString: bad length" << std::endl;
+        return nullptr;
+    }
+    const int n = c.sk->p.n;
+    std::string raw;
+    std::vector<int32_t> ct(n + 1);
+    for (int i = 0; i < msgLength; i++) {
+        encrypt_wide(c, int32_t(text[i]), ct.data());
+        sample_to_bytes(ct.data(), n, kAlpha * kAlpha, raw);
+    }
+    return dup_cstr(b64_encode(reinterpret_cast<const unsigned char *>(raw.data()), raw.size()));
+}
+
+extern "C" const char *decrypt8BitASCIIString(char *base64Ciphertext, const int16_t msgLength, const char *,
+                                              const char *jwtToken, const char *jwksBase64)
+{ // eoc-tfhe-run.cpp:352-391 (phase -> modSwitchFromTorus32 per character, :160-162)
+    std::cout << "Decrypting ASCII string started..." << std::endl;
+    if (!validate_jwt(jwtToken, jwksBase64)) {
+        std::cerr << "Invalid JWT token. Exiting..." << std::endl;
+        return nullptr;
+    }
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) return no_secret_key();
+    const int n = c.sk->p.n;
+    const size_t per = size_t(n + 1) * 4 + 8;
+    std::string raw = base64Ciphertext ? b64_decode(base64Ciphertext) : std::string();
+    if (msgLength < 0 || raw.size() < per * size_t(msgLength)) {
+        std::cerr << "Malformed ciphertext." << std::endl;
+        return nullptr;
+    }
+    std::string out;
+    std::vector<int32_t> ct;
+    for (int i = 0; i < msgLength; i++) {
+        bytes_to_sample(raw.data() + per * i, per, n, ct, nullptr);
+        out.push_back(char(eoc_modswitch_from_torus32(eoc_lwe_phase(c.sk, ct.data()), kMsize)));
+    }
+    return dup_cstr(out);
+}

@@ -212,6 +212,43 @@ const char *gateXNOR(const char *ct1, const char *ct2, const char *base64PublicK
 const char *gateNOT(const char *ct1, const char *base64PublicKey);
 const char *gateMUX(const char *ct1, const char *ct2, const char *ct3, const char *base64PublicKey);
 
+/* ------------------------------------------------------------------------------------------------
+ * f1: the reference's own 11 calls, same symbols and signatures (ao-tfhe/eoc-tfhe-run.h:8-19,
+ * ao-tfhe/eoc-tfhe-run.cpp:167-513).  Wide-message LWE (Msize = 2^31-1), CPU work as in the reference.
+ * generateSecretKey uses minimum_lambda = 128 (Set B) and returns the compact key blob below.
+ * ---------------------------------------------------------------------------------------------- */
+const char *generateSecretKey(const char *jwtToken, const char *jwksBase64);
+const char *generatePublicKey();
+const char *encryptInteger(int32_t value, const char *base64SecretKey);
+const char *encryptInteger_dummy(int32_t value, const char *base64SecretKey);
+const int decryptInteger(char *base64Ciphertext, const char *base64SecretKey, const char *jwtToken,
+                         const char *jwksBase64);
+const char *addCiphertexts(const char *base64Ciphertext1, const char *base64Ciphertext2,
+                           const char *base64PublicKey);
+const char *subtractCiphertexts(const char *base64Ciphertext1, const char *base64Ciphertext2,
+                                const char *base64PublicKey);
+const char *encrypt8BitASCIIString(const char *text, const int16_t msgLength, const char *base64Key);
+const char *decrypt8BitASCIIString(char *base64Ciphertext, const int16_t msgLength, const char *base64Key,
+                                   const char *jwtToken, const char *jwksBase64);
+void info(void);
+void testJWT();
+
+/* ------------------------------------------------------------------------------------------------
+ * f2: key export / import (the reference exports at eoc-tfhe-run.cpp:235-243 but has no import
+ * path).  Versioned flat little-endian formats:
+ *   secret key "EOCSK1": params | seed | lwe bits | tlwe bits  (the cloud key is regenerated from
+ *                        the seed; import verifies the key bits)
+ *   cloud key  "EOCCK1": params | bk int32[] | ksk int32[]      (what a server needs; no secrets)
+ * ---------------------------------------------------------------------------------------------- */
+size_t eoc_secret_key_export(const eoc_secret_key *sk, void *buf, size_t cap); /* returns bytes needed */
+int eoc_secret_key_import(const void *buf, size_t len, int with_cloud_key, eoc_secret_key **out);
+size_t eoc_cloud_key_blob_bytes(const eoc_params *p);
+int eoc_cloud_key_export(const eoc_secret_key *sk, void *buf, size_t cap);
+int eoc_cloud_key_blob_params(const void *buf, size_t len, eoc_params *p);
+int eoc_engine_create_from_cloud_key_blob(int device, const void *buf, size_t len, eoc_engine **out);
+const char *exportSecretKey(void);          /* base64 of the EOCSK1 blob of the global key */
+int importSecretKey(const char *base64Key); /* 0, or -1 (malformed / a key already exists) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,38 @@ def test_string_api_and_host_batch_api(eoc):
         assert out.shape == (2, 501)
     finally:
         T.resetGateKey()
+
+
+def test_engine_from_cloud_key_blob(eoc):
+    """f2: a server holding only the EOCCK1 blob evaluates gates bit-exactly"""
+    p, sk, eng, orc = _setup(eoc, 1, 8, 14)
+    srv = eoc.Engine.from_cloud_key_blob(sk.export_cloud_key())
+    assert (srv.params.n, srv.params.l, srv.params.Bgbit) == (14, 3, 7)
+    rng = np.random.default_rng(2)
+    b0, b1 = rng.integers(0, 2, 9), rng.integers(0, 2, 9)
+    c0, c1 = sk.encrypt_bits(b0, 5, 0), sk.encrypt_bits(b1, 6, 0)
+    torch = torch_cuda()
+    d0, d1 = to_dev(c0), to_dev(c1)
+    out = torch.empty_like(d0)
+    srv.gate_batch_device(eoc.OPS["XOR"], d0.data_ptr(), d1.data_ptr(), None, out.data_ptr(), 9)
+    sync()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, orc.gate_batch(ol.OPS["XOR"], c0, c1))
+    assert np.array_equal(sk.decrypt_bits(got), b0 ^ b1)
+    srv.close()
+
+
+def test_legacy_key_then_gates(eoc):
+    """f1 + hot path in one process: the reference's generateSecretKey (lambda 128 -> Set B) followed by
+    Boolean gates on the same global key; the GPU engine comes up lazily at the first gate."""
+    T = eoc.Tfhe
+    tkn, jwks = "eyJhbGciOiJSUzI1NiJ9.eyJvd25lciI6InRlc3QifQ", "e30"
+    try:
+        key = T.generateSecretKey(tkn, jwks)
+        assert key is not None
+        assert T.decryptInteger(T.addCiphertexts(T.encryptInteger(15), T.encryptInteger(27)), "", tkn, jwks) == 42
+        c0, c1 = T.encryptBit(0), T.encryptBit(1)
+        assert T.decryptBit(T.nand(c1, c1)) == 0 and T.decryptBit(T.or_(c0, c1)) == 1
+        assert T.decryptBit(T.mux(c1, c0, c1)) == 0
+    finally:
+        T.resetGateKey()

@@ -1,0 +1,142 @@
+"""SURVEY.md rows f1/f2 on CPU: the reference's own six tests (tests/tfhe.test.js:51-186) re-expressed against
+the native library through the Tfhe façade (shaped like ao-tfhe/tfhe.lua), plus key export/import.
+
+Runs in a child process per scenario because the reference's API holds one process-global key
+(ao-tfhe/eoc-tfhe-run.cpp:38-40) that cannot be reset from the legacy surface.
+"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the reference's fixtures: a two-segment token and a truncated JWKS (tests/tfhe.test.js:28-37 shape)
+TKN = "eyJhbGciOiJSUzI1NiJ9.eyJvd25lciI6InRlc3QifQ"
+JWKS = "ewogICJrZXlzIjogW10KfQ"
+
+
+def run_child(body):
+    code = textwrap.dedent("""
+        import json, sys
+        sys.path.insert(0, %r)
+        from eoc_tfhe_amd import Tfhe
+        tkn, jwks = %r, %r
+        out = {}
+    """ % (ROOT, TKN, JWKS)) + textwrap.dedent(body) + "\nprint('RESULT' + json.dumps(out))\n"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+    return json.loads(line[len("RESULT"):]), r.stdout, r.stderr
+
+
+@pytest.fixture(scope="module")
+def session(built_lib):
+    """one process, one key, the reference's tests in the reference's order (they share state there too,
+    tests/tfhe.test.js:39,52)"""
+    out, stdout, stderr = run_child("""
+        Tfhe.info(); Tfhe.testJWT()
+        out['before_key'] = Tfhe.encryptInteger(1, '')
+        key = Tfhe.generateSecretKey(tkn, jwks)
+        out['key_len'] = len(key)
+        out['second_key'] = Tfhe.generateSecretKey(tkn, jwks)
+        enc = Tfhe.encryptInteger(42, '')
+        out['ct_len'] = len(enc)
+        out['int'] = Tfhe.decryptInteger(enc, '', tkn, jwks)
+        text = "Hello TFHE!"
+        es = Tfhe.encryptASCIIString(text, len(text), '')
+        out['str'] = Tfhe.decryptASCIIString(es, len(text), '', tkn, jwks)
+        a, b = Tfhe.encryptInteger(15, ''), Tfhe.encryptInteger(27, '')
+        out['sum'] = Tfhe.decryptInteger(Tfhe.addCiphertexts(a, b, ''), '', tkn, jwks)
+        a, b = Tfhe.encryptInteger(50, ''), Tfhe.encryptInteger(8, '')
+        out['diff_facade'] = Tfhe.decryptInteger(Tfhe.subtractCiphertexts(a, b, ''), '', tkn, jwks)
+        out['diff_backend'] = Tfhe.decryptInteger(Tfhe.subtractCiphertexts_backend(a, b, ''), '', tkn, jwks)
+        out['dummy'] = Tfhe.decryptInteger(Tfhe.encryptInteger_dummy(7, ''), '', tkn, jwks)
+        out['neg'] = Tfhe.decryptInteger(Tfhe.encryptInteger(-5, ''), '', tkn, jwks)
+        out['big'] = Tfhe.decryptInteger(Tfhe.encryptInteger(1000000007, ''), '', tkn, jwks)
+        out['bad_jwt_dec'] = Tfhe.decryptInteger(enc, '', 'no-dot-token', jwks)
+        out['bad_jwt_3seg'] = Tfhe.decryptInteger(enc, '', 'aaa.bbb.ccc', jwks)
+        out['bad_ct'] = Tfhe.decryptInteger('AAAA', '', tkn, jwks)
+        out['bad_add'] = Tfhe.addCiphertexts('AAAA', enc, '')
+        out['pub'] = Tfhe.generatePublicKey() is not None
+        out['exported'] = Tfhe.exportSecretKey()
+        Tfhe.testJWT()
+    """)
+    out["_stdout"], out["_stderr"] = stdout, stderr
+    return out
+
+
+def test_info_and_jwt_smoke(session):                       # tests/tfhe.test.js:56-76
+    assert "TFHE Library: Enabling fully homomorphic encryption" in session["_stdout"]
+    assert "Token is valid." in session["_stdout"]
+    assert "Decrypted message internal test: Hello Weavers!" in session["_stdout"]
+
+
+def test_integer_round_trip_42(session):                    # tests/tfhe.test.js:78-104
+    assert session["int"] == 42
+    assert session["ct_len"] == (4 * 631 + 8 + 2) // 3 * 4  # base64 of a[630] | b | f64 variance (Set B)
+
+
+def test_string_round_trip(session):                        # tests/tfhe.test.js:106-128
+    assert session["str"] == "Hello TFHE!"
+
+
+def test_homomorphic_addition(session):                     # tests/tfhe.test.js:130-157
+    assert session["sum"] == 42
+
+
+def test_homomorphic_subtraction_quirk(session):            # tests/tfhe.test.js:159-186 pins 58
+    assert session["diff_facade"] == 58                     # Tfhe.subtractCiphertexts -> addCiphertexts (tfhe.lua:41-43)
+    assert session["diff_backend"] == 42                    # the C function really subtracts (eoc-tfhe-run.cpp:490-491)
+
+
+def test_error_conventions(session):
+    assert session["before_key"] is None                    # "Secret key not initialized" -> NULL (cpp:277-278)
+    assert "Secret key not initialized. Generate the secret key first." in session["_stderr"]
+    assert session["second_key"] is None                    # cpp:245-249
+    assert "Secret key is already generated for this instance..." in session["_stdout"]
+    assert session["bad_jwt_dec"] == -1 and session["bad_ct"] == -1 and session["bad_add"] is None
+    assert session["bad_jwt_3seg"] == -1                    # a real 3-segment JWT fails the shape check
+    assert "Invalid JWT token. Exiting..." in session["_stderr"]
+    assert session["dummy"] == 7 and session["big"] == 1000000007
+    assert session["neg"] == 2**31 - 1 - 5                  # messages live in Z_Msize: -5 comes back as Msize - 5
+    assert session["pub"] is True and session["key_len"] > 1000
+
+
+def test_secret_key_export_import_across_processes(session):
+    """f2: a second process imports the exported key and decrypts what it encrypts; ciphertexts of the first
+    process decrypt too (same key)."""
+    out, _, _ = run_child("""
+        blob = %r
+        out['bad'] = Tfhe.importSecretKey('AAAA')
+        out['imp'] = Tfhe.importSecretKey(blob)
+        out['again'] = Tfhe.importSecretKey(blob)
+        out['rt'] = Tfhe.decryptInteger(Tfhe.encryptInteger(1234, ''), '', tkn, jwks)
+        out['same'] = Tfhe.exportSecretKey() == blob
+    """ % session["exported"])
+    assert out == {"bad": -1, "imp": 0, "again": -1, "rt": 1234, "same": True}
+
+
+def test_key_blob_objects(built_lib):
+    import numpy as np
+    import eoc_tfhe_amd as eoc
+    p = eoc.default_params(0)
+    p.n = 12
+    sk = eoc.SecretKey(p, 99)
+    blob = sk.export_bytes()
+    assert blob[:6] == b"EOCSK1" and len(blob) == 8 + 36 + 8 + 12 + 1024
+    sk2 = eoc.SecretKey.from_bytes(blob)
+    assert np.array_equal(sk2.lwe_key, sk.lwe_key) and np.array_equal(sk2.bk, sk.bk) and np.array_equal(sk2.ksk, sk.ksk)
+    with pytest.raises(eoc.EocError):
+        eoc.SecretKey.from_bytes(blob[:-1])
+    tampered = bytearray(blob); tampered[8 + 36 + 8] ^= 1
+    with pytest.raises(eoc.EocError, match="do not match the seed"):
+        eoc.SecretKey.from_bytes(bytes(tampered))
+    ck = sk.export_cloud_key()
+    assert bytes(ck[:6]) == b"EOCCK1" and ck.size == 8 + 36 + 4 * (sk.bk.size + sk.ksk.size)
+    q = eoc.Params()
+    import ctypes as C
+    assert eoc.lib().eoc_cloud_key_blob_params(ck.ctypes.data, ck.size, C.byref(q)) == 0 and q.n == 12 and q.l == 2
