@@ -94,6 +94,7 @@ def lib():
         "eoc_decrypt_bits": (C.c_int, [vp, vp, sz, vp]),
         "eoc_lwe_encrypt": (C.c_int, [vp, u64, u64, C.c_int32, C.c_double, vp]),
         "eoc_lwe_phase": (C.c_int32, [vp, vp]),
+        "eoc_host_threads": (C.c_int, []),
         "eoc_modswitch_to_torus32": (C.c_int32, [C.c_int32, C.c_int32]),
         "eoc_modswitch_from_torus32": (C.c_int32, [C.c_int32, C.c_int32]),
         "eoc_device_count": (C.c_int, []),

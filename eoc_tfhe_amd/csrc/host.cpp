@@ -9,7 +9,9 @@
 #include "host_internal.h"
 #include "../../include/eoc_tfhe_gpu.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -60,6 +62,41 @@ extern "C" size_t eoc_ksk_len(const eoc_params *p)
 {
     return (size_t)EOC_N * p->ks_t * (((size_t)1 << p->ks_basebit) - 1) * ((size_t)p->n + 1);
 }
+
+// ------------------------------------------------------------------------------------------------
+// worker threads for key generation / batch encryption: never more than the CPU share the process
+// really has (affinity mask and cgroup quota), whatever the machine's core count says -- a GPU box
+// hands a container 16 of 128 cores and an oversubscribed OpenMP team spins instead of working.
+// ------------------------------------------------------------------------------------------------
+#include <sched.h>
+#include <omp.h>
+static int usable_threads()
+{
+    static int cached = 0;
+    if (cached) return cached;
+    int n = omp_get_num_procs();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, CPU_COUNT(&set));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            n = std::min<long long>(n, (quota + period - 1) / period);
+        fclose(f);
+    } else if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+        long long quota = 0, period = 100000;
+        if (fscanf(fq, "%lld", &quota) != 1) quota = 0;
+        fclose(fq);
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(fp, "%lld", &period) != 1) period = 100000;
+            fclose(fp);
+        }
+        if (quota > 0 && period > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+    }
+    if (const char *e = getenv("EOC_TFHE_THREADS")) n = std::max(1, atoi(e));
+    cached = std::max(1, n);
+    return cached;
+}
+extern "C" int eoc_host_threads(void) { return usable_threads(); }
 
 // ------------------------------------------------------------------------------------------------
 // sampler: counter-based splitmix64 streams (DESIGN.md "PRNG")
@@ -134,7 +171,7 @@ static void make_ksk(eoc_secret_key &k)
     const int n = p.n, t = p.ks_t, bb = p.ks_basebit, nd = (1 << bb) - 1;
     const size_t rows = size_t(EOC_N) * t * nd;
     k.ksk.assign(rows * (n + 1), 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(usable_threads())
     for (size_t r = 0; r < rows; r++) {
         const int d = int(r % nd) + 1, j = int((r / nd) % t), i = int(r / (size_t(nd) * t));
         // message s'_i * d / base^(j+1)   
@@ -152,7 +189,7 @@ static void make_bk(eoc_secret_key &k)
     std::vector<int> ones;
     for (int m = 0; m < EOC_N; m++)
         if (k.tlwe[m]) ones.push_back(m);
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(usable_threads())
     for (int ir = 0; ir < p.n * kpl; ir++) {
         Stream st(k.seed, Stream::Bk, uint64_t(ir));
         uint32_t *a = reinterpret_cast<uint32_t *>(&k.bk[(size_t(ir) * 2) * EOC_N]);
@@ -225,7 +262,7 @@ extern "C" int eoc_encrypt_bits(const eoc_secret_key *sk, uint64_t enc_seed, uin
     if (!sk || !bits || !cts) return EOC_ERR_ARG;
     const size_t st = size_t(sk->p.n) + 1;
     const int32_t one8 = eoc_modswitch_to_torus32(1, 8);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(usable_threads()) if (count >= 64)
     for (size_t i = 0; i < count; i++)
         eoc_lwe_encrypt(sk, enc_seed, first_idx + i, bits[i] ? one8 : -one8, sk->p.ks_stdev, cts + i * st);
     return EOC_OK;

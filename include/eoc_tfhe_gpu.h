@@ -93,6 +93,8 @@ int eoc_decrypt_bits(const eoc_secret_key *sk, const int32_t *cts, size_t count,
 int eoc_lwe_encrypt(const eoc_secret_key *sk, uint64_t enc_seed, uint64_t idx, int32_t mu,
                     double sigma, int32_t *ct);
 int32_t eoc_lwe_phase(const eoc_secret_key *sk, const int32_t *ct);
+/* worker threads the client-side code uses: min(cores, affinity mask, cgroup quota), or EOC_TFHE_THREADS */
+int eoc_host_threads(void);
 /* modSwitchToTorus32 / modSwitchFromTorus32 (eoc-tfhe-run.cpp:145,162) */
 int32_t eoc_modswitch_to_torus32(int32_t mu, int32_t Msize);
 int32_t eoc_modswitch_from_torus32(int32_t phase, int32_t Msize);

@@ -10,9 +10,12 @@
  * explicitly (__builtin_fma) and every other * and + must round separately, so that the
  * HIP engine (compiled with the same flag) matches bit for bit.
  */
+#define _GNU_SOURCE
 #include "tfhe_oracle.h"
 #include "canon_twiddles.h"
 #include <math.h>
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -134,7 +137,7 @@ void orc_keygen_ksk(const orc_params *p, uint64_t seed, const int32_t *lwe_key,
 {
     const int n = p->n, t = p->ks_t, bb = p->ks_basebit, base = 1 << bb;
     const size_t rows = (size_t)N * t * (base - 1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_max_threads())
     for (size_t r = 0; r < rows; r++) {
         int d = (int)(r % (base - 1)) + 1;
         int j = (int)((r / (base - 1)) % t);
@@ -151,7 +154,7 @@ void orc_keygen_bk(const orc_params *p, uint64_t seed, const int32_t *lwe_key,
                    const int32_t *tlwe_key, int32_t *bk)
 {
     const int n = p->n, l = p->l, kpl = 2 * l;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(orc_max_threads())
     for (int ir = 0; ir < n * kpl; ir++) {
         int i = ir / kpl, row = ir % kpl;
         uint64_t key = orc_stream_key(seed, TAG_BK, (uint64_t)ir);
@@ -334,7 +337,7 @@ void orc_fft_inv(const double *spec, int32_t *poly)
 void orc_bk_to_fft(const orc_params *p, const int32_t *bk, double *bkfft)
 {
     const int npoly = p->n * 2 * p->l * 2;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_max_threads())
     for (int i = 0; i < npoly; i++) orc_fft_fwd(bk + (size_t)i * N, bkfft + (size_t)i * N);
 }
 
@@ -561,10 +564,36 @@ int orc_gate(const orc_params *p, const double *bkfft, const int32_t *ksk, int o
     return rc;
 }
 
+/* usable worker threads: min(cores, affinity mask, cgroup v2 quota) -- a container on a GPU box gets a
+ * share of the host's cores and an oversubscribed OpenMP team spins instead of working */
 int orc_max_threads(void)
 {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    static int cached = 0;
+    if (cached) return cached;
+    int n = omp_get_num_procs();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+            long long q = (quota + period - 1) / period;
+            if (q < n) n = (int)q;
+        }
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) { /* cgroup v1 */
+        long long quota = 0, period = 100000;
+        if (fscanf(f, "%lld", &quota) != 1) quota = 0;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) {
+            if (fscanf(f, "%lld", &period) != 1) period = 100000;
+            fclose(f);
+        }
+        if (quota > 0 && period > 0 && (quota + period - 1) / period < n) n = (int)((quota + period - 1) / period);
+    }
+    cached = n < 1 ? 1 : n;
+    return cached;
 #else
     return 1;
 #endif
@@ -576,12 +605,8 @@ int orc_gate_batch(const orc_params *p, const double *bkfft, const int32_t *ksk,
 {
     const size_t st = (size_t)p->n + 1;
     int bad = 0;
-#ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
-#else
-    (void)nthreads;
-#endif
-#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+    if (nthreads <= 0 || nthreads > orc_max_threads()) nthreads = orc_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad) num_threads(nthreads)
     for (size_t g = 0; g < count; g++) {
         int o = ops ? (int)ops[g] : op;
         if (orc_gate(p, bkfft, ksk, o, in0 + g * st, in1 ? in1 + g * st : NULL,

@@ -1,0 +1,110 @@
+"""BASELINE.json configs 3, 4, 5 at their FULL sizes on one GPU, checked through size-independent properties
+(decrypted results vs plaintext) plus an oracle spot-check on a slice.  Config 2 at full size lives in
+test_gpu_parity.py; config 1 is the oracle's golden test (CPU)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpu_util import sync, to_dev, torch_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eoc(built_lib):
+    torch_cuda()
+    import eoc_tfhe_amd
+    return eoc_tfhe_amd
+
+
+@pytest.fixture(scope="module")
+def rig(eoc):
+    p = eoc.default_params(0)          # Set A, key seed 1
+    sk = eoc.SecretKey(p, 1)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    return p, sk, eng
+
+
+def _enc_planes(sk, bits, seed0):
+    """bits [S, nbits] -> wires [nbits][S][n+1], one encryption stream per bit plane"""
+    return np.stack([sk.encrypt_bits(bits[:, i], seed0 + i, 0) for i in range(bits.shape[1])])
+
+
+def test_config3_adder_4096_pairs(eoc, rig):
+    """8-bit ripple-carry add over 4096 input pairs (operands from seed 3, LSB first)."""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng = rig
+    torch = torch_cuda()
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8)
+    S = 4096
+    rng = np.random.default_rng(3)
+    A, B = rng.integers(0, 256, S), rng.integers(0, 256, S)
+    wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
+    abits = ((A[:, None] >> np.arange(8)) & 1).astype(np.uint8)
+    bbits = ((B[:, None] >> np.arange(8)) & 1).astype(np.uint8)
+    wires[aw[0]: aw[0] + 8] = to_dev(_enc_planes(sk, abits, 1000))
+    wires[bw[0]: bw[0] + 8] = to_dev(_enc_planes(sk, bbits, 2000))
+    before = eng.stats()["bootstraps"]
+    eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
+    sync()
+    assert eng.stats()["bootstraps"] - before == 37 * S
+    sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
+    total = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
+    assert np.array_equal(total, A + B)
+
+
+def test_config5_string_equality_1024x32(eoc, rig):
+    """ASCII-string equality (per-bit XOR + OR tree + NOT) on 1024 pairs of 32-byte strings, half equal."""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng = rig
+    torch = torch_cuda()
+    gates, n_wires, xw, yw, out = circuits.string_equal(32)
+    assert eoc.circuit_bootstraps(gates) == 511
+    S = 1024
+    rng = np.random.default_rng(5)
+    X = rng.integers(32, 127, (S, 32)).astype(np.uint8)
+    Y = X.copy()
+    diff = np.arange(S) % 2 == 1
+    pos = rng.integers(0, 32, S)
+    Y[diff, pos[diff]] ^= (1 << rng.integers(0, 7, S)[diff]).astype(np.uint8)
+    xb = np.unpackbits(X, axis=1, bitorder="little")
+    yb = np.unpackbits(Y, axis=1, bitorder="little")
+    wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
+    wires[xw[0]: xw[0] + 256] = to_dev(_enc_planes(sk, xb, 3000))
+    wires[yw[0]: yw[0] + 256] = to_dev(_enc_planes(sk, yb, 4000))
+    eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
+    sync()
+    got = sk.decrypt_bits(wires[out].cpu().numpy())
+
+    assert np.array_equal(got, (~diff).astype(np.uint8))
+
+
+def test_config4_mixed_gates_one_shard(eoc, rig):
+    """1M mixed gates {NAND, XOR, MUX} sharded over 8 GPUs = 131072 gates per GPU: this is rank 0's block
+    (eoc_tfhe_amd.distributed.shard), op stream from seed 4; decrypt-checked in full, oracle-checked on a slice."""
+    from eoc_tfhe_amd.distributed import shard
+    p, sk, eng = rig
+    torch = torch_cuda()
+    total = 1 << 20
+    lo, hi = shard(total, 0, 8)
+    cnt = hi - lo
+    rng = np.random.default_rng(4)
+    ops_all = rng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), total)
+    ops = np.sort(ops_all[lo:hi])          # the host groups equal opcodes so that each run is one batch
+    b = [np.random.default_rng(40 + k).integers(0, 2, cnt).astype(np.uint8) for k in range(3)]
+    c = [to_dev(sk.encrypt_bits(b[k], 5000 + k, lo)) for k in range(3)]
+    out = torch.empty_like(c[0])
+    before = eng.stats()["bootstraps"]
+    eng.gate_batch_device(0, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), out.data_ptr(), cnt, ops=ops)
+    sync()
+    n_mux = int((ops == eoc.OPS["MUX"]).sum())
+    assert eng.stats()["bootstraps"] - before == cnt + n_mux      # MUX = 2 blind rotations
+    got = out.cpu().numpy()
+    want = np.where(ops == eoc.OPS["NAND"], 1 - (b[0] & b[1]),
+                    np.where(ops == eoc.OPS["XOR"], b[0] ^ b[1], np.where(b[0] == 1, b[1], b[2])))
+    assert np.array_equal(sk.decrypt_bits(got), want)
+    orc = ol.Oracle(0, 1)
+    idx = np.concatenate([np.flatnonzero(ops == o)[:6] for o in np.unique(ops)])
+    h = [x.cpu().numpy()[idx] for x in c]
+    assert np.array_equal(got[idx], orc.gate_batch(0, h[0], h[1], h[2], ops=ops[idx]))
