@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer API (H2D + D2H included)")
+    ap.add_argument("--workload", default="nand", choices=["nand", "adder8", "streq32", "mixed"],
+                    help="nand = BASELINE configs[1] (headline); adder8 / streq32 / mixed = configs[2] / [4] / [3] "
+                         "shapes on this rank's shard (secondary lines, same metric)")
+    ap.add_argument("--instances", type=int, default=0, help="circuit instances / mixed gates per GPU (0 = config default)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
@@ -123,6 +127,63 @@ def main():
     def step():
         eng.gate_batch_device(op, d0.data_ptr(), d1.data_ptr(), None, dout.data_ptr(), G, stream=stream)
 
+    boots_per_step = G
+    workload_desc = None
+    circuit_check = None
+    if args.workload != "nand":
+        from eoc_tfhe_amd import circuits
+        wrng = np.random.default_rng(7000 + rank)
+        if args.workload in ("adder8", "streq32"):
+            if args.workload == "adder8":
+                S = args.instances or 4096 // max(1, world) or 1
+                gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8)
+                A, B = wrng.integers(0, 256, S), wrng.integers(0, 256, S)
+                bits_in = {aw[0]: ((A[:, None] >> np.arange(8)) & 1), bw[0]: ((B[:, None] >> np.arange(8)) & 1)}
+                workload_desc = f"8-bit ripple-carry add, {S} input pairs per GPU (BASELINE configs[2])"
+            else:
+                S = args.instances or 1024 // max(1, world) or 1
+                gates, n_wires, xw, yw, outw = circuits.string_equal(32)
+                X = wrng.integers(32, 127, (S, 32)).astype(np.uint8)
+                Y = X.copy()
+                Y[1::2, 0] ^= 1
+                bits_in = {xw[0]: np.unpackbits(X, axis=1, bitorder="little"),
+                           yw[0]: np.unpackbits(Y, axis=1, bitorder="little")}
+                workload_desc = f"ASCII string equality, {S} pairs of 32-byte strings per GPU (BASELINE configs[4])"
+            wires = torch.zeros((n_wires, S, n + 1), dtype=torch.int32, device=dev)
+            for w0, bb in bits_in.items():
+                planes = np.stack([sk.encrypt_bits(bb[:, i].astype(np.uint8), 9000 + w0 + i, 0) for i in range(bb.shape[1])])
+                wires[w0: w0 + bb.shape[1]] = torch.from_numpy(planes).to(dev)
+            boots_per_step = eoc.circuit_bootstraps(gates) * S
+
+            def step():  # noqa: F811
+                eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S, stream=stream)
+
+            if args.workload == "adder8":
+                def circuit_check():
+                    sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
+                    tot = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
+                    return bool(np.array_equal(tot, A + B))
+            else:
+                def circuit_check():
+                    return bool(np.array_equal(sk.decrypt_bits(wires[outw].cpu().numpy()), (X == Y).all(axis=1)))
+        else:  # mixed: NAND / XOR / MUX, opcodes grouped by the host so that every run is one batch
+            S = args.instances or (1 << 20) // 8
+            mops = np.sort(wrng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), S))
+            mb = [wrng.integers(0, 2, S).astype(np.uint8) for _ in range(3)]
+            mc = [torch.from_numpy(sk.encrypt_bits(mb[k], 9500 + k, 0)).to(dev) for k in range(3)]
+            mout = torch.empty_like(mc[0])
+            boots_per_step = S + int((mops == eoc.OPS["MUX"]).sum())
+            workload_desc = f"{S} mixed NAND/XOR/MUX gates per GPU (BASELINE configs[3] shard), MUX = 2 bootstraps"
+
+            def step():  # noqa: F811
+                eng.gate_batch_device(0, mc[0].data_ptr(), mc[1].data_ptr(), mc[2].data_ptr(), mout.data_ptr(), S,
+                                      ops=mops, stream=stream)
+
+            def circuit_check():
+                want = np.where(mops == eoc.OPS["NAND"], 1 - (mb[0] & mb[1]),
+                                np.where(mops == eoc.OPS["XOR"], mb[0] ^ mb[1], np.where(mb[0] == 1, mb[1], mb[2])))
+                return bool(np.array_equal(sk.decrypt_bits(mout.cpu().numpy()), want))
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -149,8 +210,12 @@ def main():
 
     # ---- correctness of what was timed: decrypt on every rank -------------------------------
     out = dout.cpu().numpy()
-    truth = {"NAND": 1 - (bits0 & bits1), "AND": bits0 & bits1, "OR": bits0 | bits1, "XOR": bits0 ^ bits1}.get(args.op)
-    decrypt_ok = bool(truth is None or np.array_equal(sk.decrypt_bits(out), truth))
+    if circuit_check is not None:
+        decrypt_ok = circuit_check()
+    else:
+        truth = {"NAND": 1 - (bits0 & bits1), "AND": bits0 & bits1, "OR": bits0 | bits1,
+                 "XOR": bits0 ^ bits1}.get(args.op)
+        decrypt_ok = bool(truth is None or np.array_equal(sk.decrypt_bits(out), truth))
 
     if dist:  # every rank must have produced correct gates
         ok = torch.tensor([1 if decrypt_ok else 0], dtype=torch.int32, device=dev)
@@ -158,20 +223,23 @@ def main():
         decrypt_ok = bool(ok.item())
 
     if rank == 0:
-        total_gates = G * world * args.steps
+        total_gates = boots_per_step * world * args.steps
         value = total_gates / elapsed
         bk_b, ks_b, io_b = algorithmic_bytes(p)
         br = kt["blind_rotate"]
         br_ms = br["ms"] / max(1, br["launches"])
         ks_ms = kt["keyswitch"]["ms"] / max(1, kt["keyswitch"]["launches"])
         pr_ms = kt["prepare"]["ms"] / max(1, kt["prepare"]["launches"])
-        br_bytes = (bk_b + (n + 1) * 2 + 1025 * 4) * G  # BK-FFT stream + bara in + extracted sample out
+        # BK-FFT stream + bara in + extracted sample out, per blind-rotate job; launches differ in size for
+        # circuits, so use the jobs the engine counted over the timed region
+        jobs_per_launch = boots_per_step * args.steps / max(1, br["launches"])
+        br_bytes = int((bk_b + (n + 1) * 2 + 1025 * 4) * jobs_per_launch)
         achieved = br_bytes / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"blind_rotate_{args.pset}_{G}")
+                traffic = json.load(open(tpath)).get(f"blind_rotate_{args.pset}_{G}") if args.workload == "nand" else None
             except Exception:
                 traffic = None
         res = {
@@ -187,8 +255,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{G} independent bootsNAND gates per GPU per step (BASELINE configs[1])"
-                       if args.op == "NAND" else f"{G} independent {args.op} gates per GPU per step",
+            "config": {"workload": workload_desc or (f"{G} independent bootsNAND gates per GPU per step (BASELINE configs[1])"
+                       if args.op == "NAND" else f"{G} independent {args.op} gates per GPU per step"),
                        "param_set": args.pset, "n": n, "N": 1024, "k": 1, "l": p.l, "Bgbit": p.Bgbit,
                        "ks_t": p.ks_t, "ks_basebit": p.ks_basebit, "gates_per_gpu_per_step": G,
                        "sharding": "independent gates per rank, no data-path collective",
@@ -203,7 +271,7 @@ def main():
                                  "re-uses BK slices from L2/Infinity Cache so measured HBM traffic is far lower "
                                  "and the kernel is FP64-VALU/LDS bound (DESIGN.md)"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "nand":
             res["cpu_baseline"] = cpu_baseline(args, p, c0, c1, out, key_seed, op)
         if args.pcie:
             eoc.gpu_init(p, device=local_rank)

@@ -1,0 +1,72 @@
+/* abi_smoke.c -- a plain-C host of libeoc_tfhe_gpu.so: proves include/eoc_tfhe_gpu.h is valid C and the
+ * library is usable without Python or torch (this is what a Lua/Node binding sits on).
+ *   gcc -std=c11 -Iinclude tests/c/abi_smoke.c -o abi_smoke -Leoc_tfhe_amd -leoc_tfhe_gpu -Wl,-rpath,...
+ * usage: abi_smoke cpu   -> client-side calls only; the gate call must FAIL with EOC_ERR_NO_DEVICE when no GPU
+ *        abi_smoke gpu   -> full NAND truth table through the host-buffer batch API and the string API */
+#include "eoc_tfhe_gpu.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "FAILED: %s (line %d): %s\n", #c, __LINE__, eoc_last_error()); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
+    eoc_params p;
+    CHECK(eoc_default_params(0, &p) == EOC_OK && p.n == 500);
+    if (!gpu) p.n = 32; /* small key: the CPU leg only exercises client-side code */
+    eoc_secret_key *sk = NULL;
+    CHECK(eoc_keygen(&p, 1, 1, &sk) == EOC_OK);
+    const uint8_t b0[4] = {0, 0, 1, 1}, b1[4] = {0, 1, 0, 1};
+    size_t st = (size_t)p.n + 1;
+    int32_t *c0 = malloc(4 * st * 4), *c1 = malloc(4 * st * 4), *out = malloc(4 * st * 4);
+    uint8_t dec[4];
+    CHECK(eoc_encrypt_bits(sk, 2, 0, b0, 4, c0) == EOC_OK && eoc_encrypt_bits(sk, 3, 0, b1, 4, c1) == EOC_OK);
+    CHECK(eoc_decrypt_bits(sk, c0, 4, dec) == EOC_OK && memcmp(dec, b0, 4) == 0);
+    /* key blobs round trip */
+    size_t need = eoc_secret_key_export(sk, NULL, 0);
+    void *blob = malloc(need);
+    CHECK(eoc_secret_key_export(sk, blob, need) == need);
+    eoc_secret_key *sk2 = NULL;
+    CHECK(eoc_secret_key_import(blob, need, 0, &sk2) == EOC_OK);
+    CHECK(memcmp(eoc_sk_lwe_key(sk), eoc_sk_lwe_key(sk2), (size_t)p.n * 4) == 0);
+    eoc_secret_key_free(sk2);
+    if (!gpu) {
+        if (eoc_device_count() == 0) {
+            CHECK(eoc_gate_batch(EOC_NAND, NULL, c0, c1, NULL, out, 4) == EOC_ERR_NO_DEVICE);
+            eoc_engine *e = NULL;
+            CHECK(eoc_engine_create(0, &p, &e) == EOC_ERR_NO_DEVICE && e == NULL);
+        }
+        printf("abi_smoke cpu OK (host threads %d)\n", eoc_host_threads());
+        return 0;
+    }
+    CHECK(eoc_gpu_init(0, &p) == EOC_OK);
+    CHECK(eoc_upload_cloud_key(sk) == EOC_OK);
+    CHECK(eoc_gate_batch(EOC_NAND, NULL, c0, c1, NULL, out, 4) == EOC_OK);
+    CHECK(eoc_decrypt_bits(sk, out, 4, dec) == EOC_OK);
+    for (int i = 0; i < 4; i++) CHECK(dec[i] == (uint8_t)(1 - (b0[i] & b1[i])));
+    /* a two-gate netlist: w3 = XOR(w0, w1); w2 = MUX(w3, w0, w1) over 4 instances */
+    eoc_gate gates[2] = {{EOC_XOR, 0, 1, -1, 3}, {EOC_MUX, 3, 0, 1, 2}};
+    int32_t *wires = calloc(4 * 4 * st, 4);
+    memcpy(wires, c0, 4 * st * 4);
+    memcpy(wires + 4 * st, c1, 4 * st * 4);
+    CHECK(eoc_circuit_run(gates, 2, wires, 4, 4) == EOC_OK);
+    CHECK(eoc_decrypt_bits(sk, wires + 2 * 4 * st, 4, dec) == EOC_OK);
+    for (int i = 0; i < 4; i++) CHECK(dec[i] == ((b0[i] ^ b1[i]) ? b0[i] : b1[i]));
+    eoc_gpu_shutdown();
+    /* string API, the reference's style */
+    const char *tok = generateGateKey(80, 5);
+    CHECK(tok != NULL);
+    free((void *)tok);
+    const char *e0 = encryptBit(0, ""), *e1 = encryptBit(1, "");
+    const char *r = gateNAND(e1, e1, "");
+    CHECK(r && decryptBit(r, "") == 0);
+    free((void *)r);
+    r = gateMUX(e0, e0, e1, "");
+    CHECK(r && decryptBit(r, "") == 1);
+    free((void *)r); free((void *)e0); free((void *)e1);
+    resetGateKey();
+    printf("abi_smoke gpu OK\n");
+    return 0;
+}
