@@ -472,6 +472,12 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
     d.out[i] = (int32_t)(d.op == OP_NOT ? 0u - v : v);
 }
 
+// Tuning switches kept from measured experiments (tools/ablate.sh, 1024 gates, Set A):
+//   EOC_ACC_REGS  register copy of the accumulator next to the LDS copy the rotation reads: -1.7 %  (on)
+//   EOC_LATE_BK   load all key rows after the transforms: 178 VGPRs but +12 % time                  (off)
+//   EOC_BK_PREFETCH 1/2  partner rows issued mid-transform / at the start: no gain, spills          (0)
+#define EOC_ACC_REGS 1
+
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
 #ifdef EOC_STAMPS
@@ -558,6 +564,14 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef EOC_ACC_REGS
+    uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8: low half)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        racc[r] = (uint32_t)acc[lane + 64 * r];
+        racc[8 + r] = (uint32_t)acc[lane + 64 * r + kNH];
+    }
+#endif
     for (int i = 0; i < A.n; i++) {
         EOC_STAMP(15);
         const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
@@ -573,8 +587,13 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             uint32_t v1 = (uint32_t)acc[i1 & (kN - 1)];
             v0 = (i0 & kN) ? 0u - v0 : v0;
             v1 = (i1 & kN) ? 0u - v1 : v1;
+#ifdef EOC_ACC_REGS
+            dlo[r] = v0 - racc[r] + offset;
+            dhi[r] = v1 - racc[8 + r] + offset;
+#else
             dlo[r] = v0 - (uint32_t)acc[j] + offset;
             dhi[r] = v1 - (uint32_t)acc[j + kNH] + offset;
+#endif
         }
         EOC_STAMP(0);
         // mine[] accumulates output polynomial h (kept by this wave), theirs[] polynomial 1-h
@@ -622,8 +641,10 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #define EOC_BK_PREFETCH 0
 #endif
             d2 ba[8], bb[8], xa[8], xb[8];
+#ifndef EOC_LATE_BK
             load_row(p, h, ba);
             load_row(p + 1, h, bb);
+#endif
 #if EOC_BK_PREFETCH == 2
             d2 ca[8], cb[8];
             load_row(p, 1 - h, ca);
@@ -642,6 +663,10 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
 #endif
             EOC_STAMP(2);
+#ifdef EOC_LATE_BK
+            load_row(p, h, ba);
+            load_row(p + 1, h, bb);
+#endif
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
 #if EOC_BK_PREFETCH == 0
@@ -692,8 +717,15 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
             d2 y = cmulc(x[r], s_twist[j]); // the 1/512 is in the key image
+#ifdef EOC_ACC_REGS
+            racc[r] += wrap_round(y.x);
+            racc[8 + r] += wrap_round(y.y);
+            acc[j] = (int32_t)racc[r];
+            acc[j + kNH] = (int32_t)racc[8 + r];
+#else
             acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round(y.x));
             acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round(y.y));
+#endif
         }
         wave_lds_fence();
         EOC_STAMP(9);
