@@ -39,6 +39,8 @@ int main(int argc, char **argv)
             CHECK(eoc_engine_create(0, &p, &e) == EOC_ERR_NO_DEVICE && e == NULL);
         }
         printf("abi_smoke cpu OK (host threads %d)\n", eoc_host_threads());
+        free(c0); free(c1); free(out); free(blob);
+        eoc_secret_key_free(sk);
         return 0;
     }
     CHECK(eoc_gpu_init(0, &p) == EOC_OK);
@@ -67,6 +69,8 @@ int main(int argc, char **argv)
     CHECK(r && decryptBit(r, "") == 1);
     free((void *)r); free((void *)e0); free((void *)e1);
     resetGateKey();
+    free(c0); free(c1); free(out); free(blob); free(wires);
+    eoc_secret_key_free(sk);
     printf("abi_smoke gpu OK\n");
     return 0;
 }

@@ -30,3 +30,22 @@ def test_plain_c_host_runs_gates(tmp_path, built_lib):
     r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "abi_smoke gpu OK" in r.stdout
+
+
+def test_host_code_under_asan_ubsan(tmp_path):
+    """host.cpp + legacy.cpp + the engine's host side under ASan/UBSan (clang), driven by the plain-C host;
+    leak check on, the OpenMP runtime's own start-up allocations suppressed"""
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        pytest.skip("no ROCm clang")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), str(tmp_path)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    exe = out.stdout.strip().splitlines()[-1]
+    supp = tmp_path / "lsan.supp"
+    supp.write_text("leak:libomp.so\nleak:__kmp\n")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:protect_shadow_gap=0", LSAN_OPTIONS=f"suppressions={supp}",
+               OMP_NUM_THREADS="2")
+    r = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "abi_smoke cpu OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    shutil.rmtree(tmp_path, ignore_errors=True)

@@ -195,3 +195,17 @@ def test_bootstrap_noise_and_truth_many(orc_a):
     out2 = o.gate_batch(ol.OPS["XOR"], out, np.roll(out, 1, axis=0))
     w = 1 - (b0 & b1)
     assert np.array_equal(o.decrypt_bits(out2), w ^ np.roll(w, 1))
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    """the oracle's C code under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only)"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-I" + os.path.join(root, "oracle"),
+                           os.path.join(root, "tests", "c", "oracle_sanitize.c"), os.path.join(root, "oracle", "tfhe_oracle.c"),
+                           "-o", exe, "-lm"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "oracle_sanitize OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
