@@ -537,6 +537,22 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 
     load_tables(s_tw, s_twist, g_tw, g_twist, tid);
 
+#if defined(EOC_STAGGER_MODE)
+    // experiment: de-phase the workgroups that share a CU so that one is in a register pass while the
+    // other is in an LDS phase (speed only; correctness does not depend on it)
+    {
+#if EOC_STAGGER_MODE == 1
+        const bool late = blockIdx.x >= gridDim.x / 2;
+#elif EOC_STAGGER_MODE == 2
+        const bool late = blockIdx.x & 1;
+#else
+        const bool late = (blockIdx.x >> 3) & 1;
+#endif
+        if (late)
+            for (int k = 0; k < EOC_STAGGER_SLEEPS; k++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
     {
         const int barb = bara[A.n];

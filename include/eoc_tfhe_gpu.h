@@ -136,7 +136,12 @@ int eoc_engine_set_cloud_key_device(eoc_engine *e, const void *d_bkfft, const vo
 /* borrow the engine's images (for broadcasting them, or for parity checks) */
 int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void **d_ksk);
 
-/* one homogeneous or mixed batch of independent gates, all operands resident on the device.
+/* Concurrency: calls on one engine are serialised by a mutex and share one workspace, so an engine must be
+ * driven from ONE stream at a time (launches of successive calls on the same stream are ordered; use one
+ * engine per stream, or synchronise, if several streams are needed).  Workspaces grow on demand outside
+ * the kernels (hipMalloc), so the first call at a new maximum size is not capturable into a hipGraph.
+ *
+ * one homogeneous or mixed batch of independent gates, all operands resident on the device.
  *   op      : opcode when ops == NULL
  *   ops     : HOST array [count] of opcodes, or NULL
  *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX)

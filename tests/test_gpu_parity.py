@@ -275,3 +275,26 @@ def test_properties_at_bench_size(eoc, rig_a):
     # outputs of bootstrapped gates are fresh: noise stays small after three levels
     ph = np.array([r.sk.phase(v) for v in r.gate(eoc.OPS["XOR"], x, c1)[:64]]) / 2**32
     assert np.abs(np.abs(ph) - 0.125).max() < 1 / 16
+
+
+def test_truth_tables_16k_random_encryptions_per_gate(eoc, rig_a):
+    """every gate decrypts to its truth table over >= 10^4 random encryptions with zero
+    failures; output noise of bootstrap + key switch stays within the set's max_stdev (0.012467)."""
+    r = rig_a
+    cnt = 16384
+    b0, c0 = _rand_cts(r, cnt, 81)
+    b1, c1 = _rand_cts(r, cnt, 82)
+    b2, c2 = _rand_cts(r, cnt, 83)
+    tt = dict(NAND=1 - (b0 & b1), AND=b0 & b1, OR=b0 | b1, NOR=1 - (b0 | b1), XOR=b0 ^ b1, XNOR=1 - (b0 ^ b1),
+              ANDNY=(1 - b0) & b1, ANDYN=b0 & (1 - b1), ORNY=(1 - b0) | b1, ORYN=b0 | (1 - b1))
+    lwe = r.sk.lwe_key.astype(np.int64)
+    for name, want in tt.items():
+        got = r.gate(eoc.OPS[name], c0, c1)
+        assert np.array_equal(r.sk.decrypt_bits(got), want), name
+        if name in ("NAND", "XOR"):
+            g = got.astype(np.int64)
+            phase = ((g[:, -1] - g[:, :-1] @ lwe) + 2**31) % 2**32 - 2**31
+            err = (np.abs(phase) - 2**29) / 2**32
+            assert np.abs(err).max() < 1 / 16 and err.std() < 0.012467, (name, err.std())
+    got = r.gate(eoc.OPS["MUX"], c0, c1, c2)
+    assert np.array_equal(r.sk.decrypt_bits(got), np.where(b0 == 1, b1, b2))
