@@ -160,6 +160,11 @@ def lib():
         "eoc_cloud_key_export": (C.c_int, [vp, vp, sz]),
         "eoc_cloud_key_blob_params": (C.c_int, [vp, sz, PP]),
         "eoc_engine_create_from_cloud_key_blob": (C.c_int, [C.c_int, vp, sz, C.POINTER(vp)]),
+        "eoc_global_params": (C.c_int, [PP]),
+        "eoc_global_encrypt_bits": (C.c_int, [vp, sz, vp]),
+        "eoc_global_decrypt_bits": (C.c_int, [vp, sz, vp]),
+        "eoc_global_gate_batch": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz]),
+        "eoc_global_circuit_run": (C.c_int, [vp, sz, vp, sz, sz]),
         "exportSecretKey": (vp, []),
         "importSecretKey": (C.c_int, [C.c_char_p]),
     }

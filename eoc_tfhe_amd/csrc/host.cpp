@@ -480,3 +480,59 @@ extern "C" const char *gateXOR(const char *a, const char *b, const char *) { ret
 extern "C" const char *gateXNOR(const char *a, const char *b, const char *) { return gate_strings(EOC_XNOR, a, b, nullptr); }
 extern "C" const char *gateNOT(const char *a, const char *) { return gate_strings(EOC_NOT, a, nullptr, nullptr); }
 extern "C" const char *gateMUX(const char *a, const char *b, const char *c, const char *) { return gate_strings(EOC_MUX, a, b, c); }
+
+// ---- raw-buffer calls on the global key (what a Node/Lua batch wrapper uses) --------------------------
+extern "C" int eoc_global_params(eoc_params *out)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk || !out) return EOC_ERR_NO_KEY;
+    *out = c.sk->p;
+    return EOC_OK;
+}
+extern "C" int eoc_global_encrypt_bits(const uint8_t *bits, size_t count, int32_t *cts)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) {
+        fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
+        return EOC_ERR_NO_KEY;
+    }
+    int rc = eoc_encrypt_bits(c.sk, c.enc_seed, c.enc_counter, bits, count, cts);
+    c.enc_counter += count;
+    return rc;
+}
+extern "C" int eoc_global_decrypt_bits(const int32_t *cts, size_t count, uint8_t *bits)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) {
+        fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
+        return EOC_ERR_NO_KEY;
+    }
+    return eoc_decrypt_bits(c.sk, cts, count, bits);
+}
+// batch of gates on the global key's engine (created and loaded on first use); no CPU fallback
+extern "C" int eoc_global_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
+                                     const int32_t *in2, int32_t *out, size_t count)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) {
+        fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
+        return EOC_ERR_NO_KEY;
+    }
+    int rc = ensure_engine_locked();
+    if (rc) return rc;
+    return eoc_gate_batch(op, ops, in0, in1, in2, out, count);
+}
+extern "C" int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,
+                                      size_t instances)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) return EOC_ERR_NO_KEY;
+    int rc = ensure_engine_locked();
+    if (rc) return rc;
+    return eoc_circuit_run(gates, n_gates, wires, n_wires, instances);
+}

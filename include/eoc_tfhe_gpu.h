@@ -253,6 +253,15 @@ size_t eoc_cloud_key_blob_bytes(const eoc_params *p);
 int eoc_cloud_key_export(const eoc_secret_key *sk, void *buf, size_t cap);
 int eoc_cloud_key_blob_params(const void *buf, size_t len, eoc_params *p);
 int eoc_engine_create_from_cloud_key_blob(int device, const void *buf, size_t len, eoc_engine **out);
+/* raw-buffer calls on the GLOBAL key (what a Node/Lua batch wrapper uses instead of base64 strings); the
+ * gate calls bring the GPU engine up on first use and fail without a GPU */
+int eoc_global_params(eoc_params *out);
+int eoc_global_encrypt_bits(const uint8_t *bits, size_t count, int32_t *cts);
+int eoc_global_decrypt_bits(const int32_t *cts, size_t count, uint8_t *bits);
+int eoc_global_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
+                          const int32_t *in2, int32_t *out, size_t count);
+int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,
+                           size_t instances);
 const char *exportSecretKey(void);          /* base64 of the EOCSK1 blob of the global key */
 int importSecretKey(const char *base64Key); /* 0, or -1 (malformed / a key already exists) */
 

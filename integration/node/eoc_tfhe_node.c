@@ -1,0 +1,249 @@
+/* eoc_tfhe_node.c -- N-API addon: the Node.js host binding of libeoc_tfhe_gpu.so.
+ *
+ * Plays the role ao-tfhe/eoc-tfhe-bindings.c plays for Lua (l_* wrappers + luaopen_tfhe's table,
+ * :12-148): every export reads its arguments, calls the C ABI of include/eoc_tfhe_gpu.h, converts the
+ * result and releases heap strings with free() (as the Lua binding does, :21).  NULL results become
+ * JS null (Lua nil in the reference).  On the GPU box this replaces the wasm `handle` path of
+ * tests/tfhe.test.js:52,74.  Build: see integration/node/build.sh (gcc, headers from /usr/include/node).
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "eoc_tfhe_gpu.h"
+
+#define NAPI_OK(call) do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "N-API call failed: " #call); return NULL; } } while (0)
+
+static char *arg_string(napi_env env, napi_value v)
+{ /* malloc'ed copy of a JS string (or "" for undefined/null, like luaL_optstring) */
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_string) return strdup("");
+    size_t len = 0;
+    napi_get_value_string_utf8(env, v, NULL, 0, &len);
+    char *s = malloc(len + 1);
+    napi_get_value_string_utf8(env, v, s, len + 1, &len);
+    return s;
+}
+static napi_value ret_string(napi_env env, const char *s)
+{ /* copy into a JS string and free() the library's buffer; NULL -> null */
+    napi_value out;
+    if (!s) {
+        napi_get_null(env, &out);
+        return out;
+    }
+    napi_create_string_utf8(env, s, NAPI_AUTO_LENGTH, &out);
+    free((void *)s);
+    return out;
+}
+static napi_value ret_int(napi_env env, int v)
+{
+    napi_value out;
+    napi_create_int32(env, v, &out);
+    return out;
+}
+static int arg_int(napi_env env, napi_value v)
+{
+    int32_t x = 0;
+    napi_get_value_int32(env, v, &x);
+    return x;
+}
+#define ARGS(N)                                           \
+    size_t argc = N;                                      \
+    napi_value argv[N ? N : 1];                           \
+    for (int _i = 0; _i < (N ? N : 1); _i++) argv[_i] = NULL; \
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL))
+
+/* ---- the reference's 11 functions (names of luaopen_tfhe's table, eoc-tfhe-bindings.c:130-144) ---- */
+static napi_value n_info(napi_env env, napi_callback_info info_) { (void)info_; info(); return ret_int(env, 0); }
+static napi_value n_testJWT(napi_env env, napi_callback_info info_) { (void)info_; testJWT(); return ret_int(env, 0); }
+static napi_value n_generateSecretKey(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    char *jwt = arg_string(env, argv[0]), *jwks = arg_string(env, argv[1]);
+    const char *r = generateSecretKey(jwt, jwks);
+    free(jwt); free(jwks);
+    return ret_string(env, r);
+}
+static napi_value n_generatePublicKey(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    return ret_string(env, generatePublicKey());
+}
+static napi_value n_encryptInteger(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    return ret_string(env, encryptInteger(arg_int(env, argv[0]), NULL)); /* key ignored, as :63 passes NULL */
+}
+static napi_value n_encryptInteger_dummy(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    return ret_string(env, encryptInteger(arg_int(env, argv[0]), NULL)); /* :73 calls encryptInteger too */
+}
+static napi_value n_decryptInteger(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    char *ct = arg_string(env, argv[0]), *jwt = arg_string(env, argv[2]), *jwks = arg_string(env, argv[3]);
+    int v = decryptInteger(ct, NULL, jwt, jwks);
+    free(ct); free(jwt); free(jwks);
+    return ret_int(env, v);
+}
+static napi_value n_binary(napi_env env, napi_callback_info info,
+                           const char *(*fn)(const char *, const char *, const char *))
+{
+    ARGS(3);
+    char *a = arg_string(env, argv[0]), *b = arg_string(env, argv[1]), *pk = arg_string(env, argv[2]);
+    const char *r = fn(a, b, pk);
+    free(a); free(b); free(pk);
+    return ret_string(env, r);
+}
+static napi_value n_addCiphertexts(napi_env env, napi_callback_info info) { return n_binary(env, info, addCiphertexts); }
+static napi_value n_subtractCiphertexts(napi_env env, napi_callback_info info) { return n_binary(env, info, subtractCiphertexts); }
+static napi_value n_encryptASCIIString(napi_env env, napi_callback_info info)
+{
+    ARGS(3);
+    char *s = arg_string(env, argv[0]);
+    const char *r = encrypt8BitASCIIString(s, (int16_t)arg_int(env, argv[1]), NULL);
+    free(s);
+    return ret_string(env, r);
+}
+static napi_value n_decryptASCIIString(napi_env env, napi_callback_info info)
+{
+    ARGS(5);
+    char *ct = arg_string(env, argv[0]), *jwt = arg_string(env, argv[3]), *jwks = arg_string(env, argv[4]);
+    const char *r = decrypt8BitASCIIString(ct, (int16_t)arg_int(env, argv[1]), NULL, jwt, jwks);
+    free(ct); free(jwt); free(jwks);
+    return ret_string(env, r);
+}
+
+/* ---- Boolean path ---- */
+static napi_value n_generateGateKey(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    int64_t seed = 0;
+    napi_get_value_int64(env, argv[1], &seed);
+    return ret_string(env, generateGateKey(arg_int(env, argv[0]), (uint64_t)seed));
+}
+static napi_value n_resetGateKey(napi_env env, napi_callback_info info) { (void)info; resetGateKey(); return ret_int(env, 0); }
+static napi_value n_encryptBit(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    return ret_string(env, encryptBit(arg_int(env, argv[0]), NULL));
+}
+static napi_value n_decryptBit(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    char *ct = arg_string(env, argv[0]);
+    int v = decryptBit(ct, NULL);
+    free(ct);
+    return ret_int(env, v);
+}
+#define GATE2(NAME) static napi_value n_##NAME(napi_env env, napi_callback_info info) { return n_binary(env, info, NAME); }
+GATE2(gateNAND) GATE2(gateAND) GATE2(gateOR) GATE2(gateNOR) GATE2(gateXOR) GATE2(gateXNOR)
+static napi_value n_gateNOT(napi_env env, napi_callback_info info)
+{
+    ARGS(2);
+    char *a = arg_string(env, argv[0]);
+    const char *r = gateNOT(a, "");
+    free(a);
+    return ret_string(env, r);
+}
+static napi_value n_gateMUX(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    char *a = arg_string(env, argv[0]), *b = arg_string(env, argv[1]), *c = arg_string(env, argv[2]);
+    const char *r = gateMUX(a, b, c, "");
+    free(a); free(b); free(c);
+    return ret_string(env, r);
+}
+static napi_value n_exportSecretKey(napi_env env, napi_callback_info info) { (void)info; return ret_string(env, exportSecretKey()); }
+static napi_value n_importSecretKey(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    char *k = arg_string(env, argv[0]);
+    int v = importSecretKey(k);
+    free(k);
+    return ret_int(env, v);
+}
+
+/* ---- raw-buffer batch calls on the global key: Buffers of bytes / int32 LWE samples ---- */
+static napi_value n_sampleInts(napi_env env, napi_callback_info info)
+{ /* n + 1: int32 per LWE sample of the global key, or -1 */
+    (void)info;
+    eoc_params p;
+    return ret_int(env, eoc_global_params(&p) == EOC_OK ? p.n + 1 : -1);
+}
+static napi_value n_encryptBits(napi_env env, napi_callback_info info)
+{ /* (Buffer bits[count]) -> Buffer int32[count][n+1] */
+    ARGS(1);
+    void *bits; size_t count;
+    NAPI_OK(napi_get_buffer_info(env, argv[0], &bits, &count));
+    eoc_params p;
+    napi_value out;
+    if (eoc_global_params(&p) != EOC_OK) { napi_get_null(env, &out); return out; }
+    void *cts;
+    NAPI_OK(napi_create_buffer(env, count * (size_t)(p.n + 1) * 4, &cts, &out));
+    if (eoc_global_encrypt_bits((const uint8_t *)bits, count, (int32_t *)cts) != EOC_OK) napi_get_null(env, &out);
+    return out;
+}
+static napi_value n_decryptBits(napi_env env, napi_callback_info info)
+{ /* (Buffer int32[count][n+1]) -> Buffer bits[count] */
+    ARGS(1);
+    void *cts; size_t bytes;
+    NAPI_OK(napi_get_buffer_info(env, argv[0], &cts, &bytes));
+    eoc_params p;
+    napi_value out;
+    if (eoc_global_params(&p) != EOC_OK) { napi_get_null(env, &out); return out; }
+    size_t count = bytes / ((size_t)(p.n + 1) * 4);
+    void *bits;
+    NAPI_OK(napi_create_buffer(env, count, &bits, &out));
+    if (eoc_global_decrypt_bits((const int32_t *)cts, count, (uint8_t *)bits) != EOC_OK) napi_get_null(env, &out);
+    return out;
+}
+static napi_value n_gateBatch(napi_env env, napi_callback_info info)
+{ /* (op, Buffer in0, Buffer in1 | null, Buffer in2 | null) -> Buffer out, or null on error (no GPU, ...) */
+    ARGS(4);
+    int op = arg_int(env, argv[0]);
+    void *in[3] = {NULL, NULL, NULL};
+    size_t bytes[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        bool isbuf = false;
+        if (argv[1 + k] && napi_is_buffer(env, argv[1 + k], &isbuf) == napi_ok && isbuf)
+            NAPI_OK(napi_get_buffer_info(env, argv[1 + k], &in[k], &bytes[k]));
+    }
+    eoc_params p;
+    napi_value out;
+    if (!in[0] || eoc_global_params(&p) != EOC_OK) { napi_get_null(env, &out); return out; }
+    size_t count = bytes[0] / ((size_t)(p.n + 1) * 4);
+    void *o;
+    NAPI_OK(napi_create_buffer(env, bytes[0], &o, &out));
+    if (eoc_global_gate_batch(op, NULL, (const int32_t *)in[0], (const int32_t *)in[1], (const int32_t *)in[2],
+                              (int32_t *)o, count) != EOC_OK)
+        napi_get_null(env, &out);
+    return out;
+}
+static napi_value n_deviceCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_device_count()); }
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    static const struct { const char *name; napi_callback fn; } tab[] = {
+        {"info", n_info}, {"testJWT", n_testJWT}, {"generateSecretKey", n_generateSecretKey},
+        {"generatePublicKey", n_generatePublicKey}, {"encryptInteger", n_encryptInteger},
+        {"encryptInteger_dummy", n_encryptInteger_dummy}, {"decryptInteger", n_decryptInteger},
+        {"addCiphertexts", n_addCiphertexts}, {"subtractCiphertexts", n_subtractCiphertexts},
+        {"encryptASCIIString", n_encryptASCIIString}, {"decryptASCIIString", n_decryptASCIIString},
+        {"generateGateKey", n_generateGateKey}, {"resetGateKey", n_resetGateKey}, {"encryptBit", n_encryptBit},
+        {"decryptBit", n_decryptBit}, {"gateNAND", n_gateNAND}, {"gateAND", n_gateAND}, {"gateOR", n_gateOR},
+        {"gateNOR", n_gateNOR}, {"gateXOR", n_gateXOR}, {"gateXNOR", n_gateXNOR}, {"gateNOT", n_gateNOT},
+        {"gateMUX", n_gateMUX}, {"exportSecretKey", n_exportSecretKey}, {"importSecretKey", n_importSecretKey},
+        {"sampleInts", n_sampleInts}, {"encryptBits", n_encryptBits}, {"decryptBits", n_decryptBits},
+        {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount},
+    };
+    for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++) {
+        napi_value fn;
+        if (napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &fn) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, tab[i].name, fn) != napi_ok) return NULL;
+    }
+    return exports;
+}
+NAPI_MODULE(eoc_tfhe, init)

@@ -1,0 +1,62 @@
+// tfhe.js -- the JS twin of ao-tfhe/tfhe.lua: `Tfhe.*` pass-throughs to `Tfhe.backend.*` (tfhe.lua:1-53),
+// plus the Boolean gate operations and small circuits this repo adds behind the same surface.
+'use strict';
+const path = require('path');
+const Tfhe = {};
+Tfhe.backend = require(path.join(__dirname, 'eoc_tfhe.node'));
+const B = Tfhe.backend;
+
+// ---- the reference's 11 functions, same names and argument order (ao-tfhe/tfhe.lua:4-53) ----
+Tfhe.info = () => B.info();
+Tfhe.testJWT = () => B.testJWT();
+Tfhe.generateSecretKey = (jwtToken, jwksBase64) => B.generateSecretKey(jwtToken, jwksBase64);
+Tfhe.generatePublicKey = () => B.generatePublicKey();
+Tfhe.encryptInteger = (value, key) => B.encryptInteger(value, key);
+Tfhe.encryptInteger_dummy = (value, key) => B.encryptInteger_dummy(value, key);
+Tfhe.decryptInteger = (value, key, jwtToken, jwksBase64) => B.decryptInteger(value, key, jwtToken, jwksBase64);
+Tfhe.addCiphertexts = (c1, c2, pk) => B.addCiphertexts(c1, c2, pk);
+// tfhe.lua:41-43 forwards subtract to backend.addCiphertexts (tests/tfhe.test.js:185 pins 50 "-" 8 = 58)
+Tfhe.subtractCiphertexts = (c1, c2, pk) => B.addCiphertexts(c1, c2, pk);
+Tfhe.encryptASCIIString = (value, length, key) => B.encryptASCIIString(value, length, key);
+Tfhe.decryptASCIIString = (value, length, key, jwtToken, jwksBase64) =>
+  B.decryptASCIIString(value, length, key, jwtToken, jwksBase64);
+
+// ---- Boolean path (bootstrapped gates on the GPU engine) ----
+Tfhe.generateGateKey = (lambda, seed) => B.generateGateKey(lambda, seed);
+Tfhe.encryptBit = (bit, key) => B.encryptBit(bit, key);
+Tfhe.decryptBit = (ct, key) => B.decryptBit(ct, key);
+Tfhe.nand = (a, b, pk) => B.gateNAND(a, b, pk);
+Tfhe.and = (a, b, pk) => B.gateAND(a, b, pk);
+Tfhe.or = (a, b, pk) => B.gateOR(a, b, pk);
+Tfhe.nor = (a, b, pk) => B.gateNOR(a, b, pk);
+Tfhe.xor = (a, b, pk) => B.gateXOR(a, b, pk);
+Tfhe.xnor = (a, b, pk) => B.gateXNOR(a, b, pk);
+Tfhe.not = (a, pk) => B.gateNOT(a, pk);
+Tfhe.mux = (a, b, c, pk) => B.gateMUX(a, b, c, pk);
+
+// ripple-carry adder over bit-sliced ciphertext arrays (LSB first): 2 XOR + 2 AND + 1 OR per bit
+Tfhe.addBits = (A, Bs, pk) => {
+  const S = [];
+  let c = null;
+  for (let i = 0; i < A.length; i++) {
+    const p = Tfhe.xor(A[i], Bs[i], pk), g = Tfhe.and(A[i], Bs[i], pk);
+    if (c === null) { S.push(p); c = g; } else { S.push(Tfhe.xor(p, c, pk)); c = Tfhe.or(g, Tfhe.and(p, c, pk), pk); }
+  }
+  S.push(c);
+  return S;
+};
+// ASCII string equality: XOR per bit, OR tree, NOT -- batched over the bits with the raw-buffer API
+Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1]
+  const w = B.sampleInts() * 4;
+  let level = B.gateBatch(4 /* XOR */, X, Y, null);
+  let n = level.length / w;
+  while (n > 1) {
+    const half = n >> 1;
+    const a = level.slice(0, half * w), b = level.slice(half * w, 2 * half * w);
+    const next = B.gateBatch(2 /* OR */, Buffer.from(a), Buffer.from(b), null);
+    level = (n & 1) ? Buffer.concat([next, level.slice(2 * half * w)]) : next;
+    n = level.length / w;
+  }
+  return B.gateBatch(11 /* NOT */, level, null, null);
+};
+module.exports = Tfhe;
