@@ -205,7 +205,7 @@ __device__ __forceinline__ void t01_read(d2 (&x)[8], const d2 *scr, int lane)
 }
 __device__ __forceinline__ void t12_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(hi * 64 + r * 8 + lo)] = x[r];
@@ -214,7 +214,7 @@ __device__ __forceinline__ void t12_write(const d2 (&x)[8], d2 *scr, int lane)
 }
 __device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(lane * 8 + r)];
     wave_lds_fence();
@@ -279,7 +279,7 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
         ct_ic(x[2], x[6]);
         ct_wc(x[3], x[7], wd);
     }
-#ifndef EOC_ABL_NOTRANSPOSE
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
     wave_lds_fence();
