@@ -184,6 +184,8 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     *out = e;
     return EOC_OK;
 }
@@ -396,13 +398,18 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     a.stamps = e->d_stamps;
     dim3 grid((njobs + 1) / 2), block(256);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
-    switch (e->p.l) {
-    case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-    case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-    case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-    case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-    default: return EOC_ERR_ARG;
-    }
+    if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
+        hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+    else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
+        hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+    else
+        switch (e->p.l) {
+        case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+        case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+        case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+        case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+        default: return EOC_ERR_ARG;
+        }
     HIP_TRY(hipGetLastError());
     return EOC_OK;
 }

@@ -517,7 +517,8 @@ struct BRArgs {
 
 constexpr int kBRLds = (kTwEntries + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
 
-template <int L>
+// BGBIT > 0: gadget base known at compile time (digit extraction becomes one bit-field extract); 0: run time
+template <int L, int BGBIT = 0>
 __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__restrict__ g_tw,
                                                          const d2 *__restrict__ g_twist)
 {
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     }
     __syncthreads();
 
-    const int Bgbit = A.Bgbit;
+    const int Bgbit = BGBIT > 0 ? BGBIT : A.Bgbit;
     const uint32_t maskBg = (1u << Bgbit) - 1, halfBg = 1u << (Bgbit - 1);
     uint32_t offset = 0;
 #pragma unroll
