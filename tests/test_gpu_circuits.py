@@ -189,3 +189,37 @@ def test_legacy_key_then_gates(eoc):
         assert T.decryptBit(T.mux(c1, c0, c1)) == 0
     finally:
         T.resetGateKey()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_netlists_bit_exact(eoc, seed):
+    """random netlists with every opcode, wire re-use (WAR/WAW hazards) and fan-out: the levelised, batched GPU
+    evaluation equals the oracle's gate-by-gate evaluation bit for bit"""
+    p, sk, eng, orc = _setup(eoc, seed % 2, 20 + seed, 12 + seed)
+    rng = np.random.default_rng(seed)
+    n_in, n_wires, n_gates, S = 5, 11, 40, 3
+    names = ["NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NOT", "COPY"]
+    gates = []
+    for _ in range(n_gates):
+        op = eoc.OPS[names[rng.integers(0, len(names))]]
+        a, b, c = (int(x) for x in rng.integers(0, n_wires, 3))
+        out = int(rng.integers(n_in, n_wires))     # may overwrite a wire that earlier gates read or wrote
+        if op in (eoc.OPS["NOT"], eoc.OPS["COPY"]):
+            gates.append(eoc.Gate(op, a, -1, -1, out))
+        elif op == eoc.OPS["MUX"]:
+            gates.append(eoc.Gate(op, a, b, c, out))
+        else:
+            gates.append(eoc.Gate(op, a, b, -1, out))
+    wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+    for w in range(n_wires):                        # every wire starts as a valid ciphertext
+        wires[w] = sk.encrypt_bits(rng.integers(0, 2, S), 700 + w, 0)
+    got = eoc_run(eoc, eng, gates, wires, n_wires, S)
+    want = _oracle_run(orc, gates, wires)
+    assert np.array_equal(got, want)
+    # and the host-buffer entry point gives the same
+    eoc.gpu_init(p)
+    try:
+        eoc.upload_cloud_key(sk)
+        assert np.array_equal(eoc.circuit_run(gates, wires.copy(), S), want)
+    finally:
+        eoc.gpu_shutdown()
