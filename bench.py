@@ -95,23 +95,10 @@ def main():
     eng = eoc.Engine(p, device=local_rank)
 
     # ---- cloud key: built on rank 0, broadcast over RCCL ------------------------------------
+    from eoc_tfhe_amd import distributed as D
     key_seed = 1
-    t_bcast = 0.0
-    bkfft = torch.empty(eng.bkfft_bytes // 8, dtype=torch.float64, device=dev)
-    ksk = torch.empty(eng.ksk_dev_bytes // 4, dtype=torch.int32, device=dev)
     sk = eoc.SecretKey(p, key_seed, with_cloud_key=(rank == 0))
-    if rank == 0:
-        eng.build_cloud_key_device(sk, bkfft.data_ptr(), ksk.data_ptr())
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        dist.broadcast(bkfft, src=0)
-        dist.broadcast(ksk, src=0)
-        torch.cuda.synchronize()
-        t_bcast = time.perf_counter() - t0
-        if rank != 0:
-            eng.set_cloud_key_device(bkfft.data_ptr(), ksk.data_ptr())
+    bkfft, ksk, t_bcast = D.replicate_cloud_key(eng, sk, dist, rank, dev)
 
     # ---- synthetic inputs: fresh encryptions of uniform bits, one stream per rank -----------
     rng = np.random.default_rng(1000 + rank)

@@ -69,3 +69,19 @@ def gather_blocks(dist, local, total, rank, world):
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return torch.cat([outs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def replicate_cloud_key(eng, sk, dist, rank, device):
+    """Multi-GPU key set-up: rank 0 builds the two device images (BK transformed on its GPU,
+    KSK padded) into torch tensors, one RCCL broadcast per image sends them over xGMI, every other rank's
+    engine adopts its copy.  Keys are replicated, never sharded: every gate needs all of both.
+    Returns (bkfft_tensor, ksk_tensor, broadcast_seconds); the tensors own the memory and must stay alive."""
+    import torch
+    bkfft = torch.empty(eng.bkfft_bytes // 8, dtype=torch.float64, device=device)
+    ksk = torch.empty(eng.ksk_dev_bytes // 4, dtype=torch.int32, device=device)
+    if rank == 0:
+        eng.build_cloud_key_device(sk, bkfft.data_ptr(), ksk.data_ptr())
+    secs = broadcast_key_images(dist, [bkfft, ksk], src=0)
+    if rank != 0:
+        eng.set_cloud_key_device(bkfft.data_ptr(), ksk.data_ptr())
+    return bkfft, ksk, secs
