@@ -298,3 +298,48 @@ def test_truth_tables_16k_random_encryptions_per_gate(eoc, rig_a):
             assert np.abs(err).max() < 1 / 16 and err.std() < 0.012467, (name, err.std())
     got = r.gate(eoc.OPS["MUX"], c0, c1, c2)
     assert np.array_equal(r.sk.decrypt_bits(got), np.where(b0 == 1, b1, b2))
+
+
+@pytest.mark.parametrize("n,l,bgbit", [(1, 2, 10), (5, 1, 12), (6, 4, 6), (9, 4, 8), (300, 2, 10), (1023, 3, 7)])
+def test_custom_parameter_shapes_bit_exact(eoc, n, l, bgbit):
+    """every kernel instantiation (gadget lengths 1..4, run-time gadget base, key-switch widths for n up to the
+    maximum 1023, the degenerate n = 1): GPU == oracle bit for bit.  Parity does not depend on the noise level,
+    so exotic shapes are compared as ciphertexts, not by decryption."""
+    torch = torch_cuda()
+    p = eoc.default_params(0)
+    p.n, p.l, p.Bgbit = n, l, bgbit
+    sk = eoc.SecretKey(p, 77)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    orc = ol.Oracle(0, 77, n_override=n, with_bk=False)
+    orc.p.l, orc.p.Bgbit = l, bgbit
+    orc.l, orc.kpl = l, 2 * l
+    orc.gen_cloud()
+    assert np.array_equal(sk.bk, orc.bk) and np.array_equal(sk.ksk, orc.ksk)
+    cnt = 5
+    rng = np.random.default_rng(n)
+    c = [sk.encrypt_bits(rng.integers(0, 2, cnt), 90 + k, 0) for k in range(3)]
+    d = [to_dev(x) for x in c]
+    out = torch.empty_like(d[0])
+    for name in ("NAND", "XOR", "MUX"):
+        eng.gate_batch_device(eoc.OPS[name], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), cnt)
+        sync()
+        want = orc.gate_batch(ol.OPS[name], c[0], c[1], c[2] if name == "MUX" else None)
+        assert np.array_equal(out.cpu().numpy(), want), (name, n, l, bgbit)
+    eng.close()
+
+
+def test_unsupported_keyswitch_shape_fails_loudly(eoc):
+    """key-switch kernels exist for basebit = 2, t = 8 (both reference sets); anything else is an error, not a
+    wrong answer"""
+    torch = torch_cuda()
+    p = eoc.default_params(0)
+    p.n, p.ks_t, p.ks_basebit = 8, 4, 3
+    sk = eoc.SecretKey(p, 3)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    c = to_dev(sk.encrypt_bits([0, 1], 1, 0))
+    out = torch.empty_like(c)
+    with pytest.raises(eoc.EocError, match="key switch: unsupported"):
+        eng.gate_batch_device(0, c.data_ptr(), c.data_ptr(), None, out.data_ptr(), 2)
+    eng.close()
