@@ -222,6 +222,15 @@ def main():
         jobs_per_launch = boots_per_step * args.steps / max(1, br["launches"])
         br_bytes = int((bk_b + (n + 1) * 2 + 1025 * 4) * jobs_per_launch)
         achieved = br_bytes / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
+        # secondary, and the meaningful one for this kernel: FP64 vector issue.  flop per blind-rotate job from the
+        # rocprofv3 instruction mix of profiles/r01_final_pmc_summary.txt (fma = 2 flop): (2*643 + 188 + 82)e6 * 64 / 1024
+        fp64_flop_per_job = {"A": 97.25e6}.get(args.pset)
+        fp64 = None
+        if fp64_flop_per_job and br_ms > 0:
+            tf = fp64_flop_per_job * jobs_per_launch / (br_ms * 1e-3) / 1e12
+            fp64 = {"achieved": round(tf, 2), "peak_measured": 57.0, "peak_spec": 78.6, "unit": "TFLOP/s",
+                    "frac_of_measured_peak": round(tf / 57.0, 3),
+                    "note": "peak_measured = pure v_fma_f64 loop, tools/fp64_issue_bench.hip (clock drops under FP64 load)"}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -253,7 +262,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic,
-                         "bytes_per_launch": br_bytes, "avg_launch_ms": round(br_ms, 4),
+                         "bytes_per_launch": br_bytes, "avg_launch_ms": round(br_ms, 4), "fp64_valu": fp64,
                          "note": "algorithmic bytes = every gate streams the whole BK-FFT once; the batch "
                                  "re-uses BK slices from L2/Infinity Cache so measured HBM traffic is far lower "
                                  "and the kernel is FP64-VALU/LDS bound (DESIGN.md)"},
