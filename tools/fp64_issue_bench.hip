@@ -52,5 +52,13 @@ int main()
     for (int w = 1; w <= 4; w++) run<16>(w, 20000);
     for (int w = 1; w <= 4; w++) run<4>(w, 80000);
     for (int w = 1; w <= 2; w++) run<1>(w, 200000);
+    // ILP sweep at the occupancy the blind-rotate kernel runs at (2 waves per SIMD)
+    run<2>(2, 160000);
+    run<3>(2, 100000);
+    run<6>(2, 50000);
+    run<8>(2, 40000);
+    run<12>(2, 26000);
+    run<24>(2, 13000);
+    run<32>(2, 10000);
     return 0;
 }
