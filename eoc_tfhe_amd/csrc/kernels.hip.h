@@ -259,6 +259,31 @@ __device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const 
     fft_fwd_wave_x2_head(xa, xb, tw, scr, lane);
     fft_fwd_wave_x2_tail(xa, xb, tw, scr, lane);
 }
+// three transforms on one scratch, same skew (gadget length 3: Set B)
+__device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&xc)[8], const d2 *tw, d2 *scr, int lane)
+{
+    fwd_pass0(xa);
+    t01_write(xa, scr, lane);
+    t01_read(xa, scr, lane);
+    fwd_pass0(xb);
+    t01_write(xb, scr, lane);
+    t01_read(xb, scr, lane);
+    fwd_pass0(xc);
+    t01_write(xc, scr, lane);
+    t01_read(xc, scr, lane);
+    fwd_pass1(xa, tw, lane);
+    t12_write(xa, scr, lane);
+    t12_read(xa, scr, lane);
+    fwd_pass1(xb, tw, lane);
+    t12_write(xb, scr, lane);
+    t12_read(xb, scr, lane);
+    fwd_pass1(xc, tw, lane);
+    t12_write(xc, scr, lane);
+    t12_read(xc, scr, lane);
+    fwd_pass2(xa, tw, lane);
+    fwd_pass2(xb, tw, lane);
+    fwd_pass2(xc, tw, lane);
+}
 
 // inverse: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time, conjugate twiddles
 __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
@@ -481,6 +506,8 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 //   EOC_LATE_BK   load all key rows after the transforms: 178 VGPRs but +12 % time                  (off)
 //   EOC_BK_PREFETCH 1/2  partner rows issued mid-transform / at the start: no gain, spills          (0)
 #define EOC_ACC_REGS 1
+//   EOC_L3_TRIPLE gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 %    (on)
+#define EOC_L3_TRIPLE 1
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -715,9 +742,37 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             mac(p == 1, x, bt, theirs);
             EOC_STAMP(3);
         };
+        auto triple_pass = [&]() __attribute__((always_inline)) { // L == 3: all three digits skewed on one scratch
+            d2 ba[8], bb[8], xa[8], xb[8], xc[8];
+            make_x(1, xa);
+            make_x(2, xb);
+            make_x(3, xc);
+            load_row(1, h, ba);
+            load_row(2, h, bb);
+            EOC_STAMP(1);
+            fft_fwd_wave_x3(xa, xb, xc, s_tw, scr, lane);
+            EOC_STAMP(2);
+            mac(true, xa, ba, mine);
+            mac(false, xb, bb, mine);
+            load_row(3, h, ba);
+            load_row(1, 1 - h, bb);
+            mac(false, xc, ba, mine);
+            mac(true, xa, bb, theirs);
+            load_row(2, 1 - h, ba);
+            load_row(3, 1 - h, bb);
+            mac(false, xb, ba, theirs);
+            mac(false, xc, bb, theirs);
+            EOC_STAMP(3);
+        };
         if constexpr (L == 1) single_pass(std::integral_constant<int, 1>{});
+#ifdef EOC_L3_TRIPLE
+        if constexpr (L == 3) triple_pass();
+        if constexpr (L == 2 || L == 4) pair_pass(std::integral_constant<int, 1>{});
+#else
+        (void)triple_pass;
         if constexpr (L >= 2) pair_pass(std::integral_constant<int, 1>{});
         if constexpr (L == 3) single_pass(std::integral_constant<int, 3>{});
+#endif
         if constexpr (L == 4) pair_pass(std::integral_constant<int, 3>{});
         // hand the other polynomial's partial spectrum to the partner wave
 #pragma unroll
