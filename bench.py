@@ -153,9 +153,9 @@ def main():
             else:
                 def circuit_check():
                     return bool(np.array_equal(sk.decrypt_bits(wires[outw].cpu().numpy()), (X == Y).all(axis=1)))
-        else:  # mixed: NAND / XOR / MUX, opcodes grouped by the host so that every run is one batch
+        else:  # mixed: NAND / XOR / MUX in arbitrary order (the engine groups equal opcodes on the device)
             S = args.instances or (1 << 20) // 8
-            mops = np.sort(wrng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), S))
+            mops = wrng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), S)
             mb = [wrng.integers(0, 2, S).astype(np.uint8) for _ in range(3)]
             mc = [torch.from_numpy(sk.encrypt_bits(mb[k], 9500 + k, 0)).to(dev) for k in range(3)]
             mout = torch.empty_like(mc[0])

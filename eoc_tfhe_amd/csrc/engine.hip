@@ -45,6 +45,8 @@ struct eoc_engine {
     int32_t *d_u = nullptr;
     uint32_t *d_ubarT = nullptr; // [N][ws_jobs] key-switch operand, transposed
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
+    int32_t *d_mixed = nullptr;             // gather/scatter space of mixed batches: 4 row arrays + perm
+    size_t ws_mixed = 0;
     size_t ws_jobs = 0;
     GateDesc *d_descs = nullptr;
     size_t ws_descs = 0;
@@ -205,6 +207,7 @@ extern "C" void eoc_engine_destroy(eoc_engine *e)
     hipFree(e->d_u);
     hipFree(e->d_ubarT);
     hipFree(e->d_descs);
+    hipFree(e->d_mixed);
     delete e;
 }
 
@@ -530,45 +533,90 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
         if (rc) return rc;
         return run_level(e, boot, freeg, count, e->d_descs, st);
     }
-    // mixed batch: maximal runs of equal opcode become one descriptor each (S differs per run, so
-    // runs are grouped by opcode class and launched run by run when lengths differ).  To keep the
-    // launch count at three per batch, gates are bucketed per opcode with S = 1 descriptors only
-    // when a run is short; long runs dominate in practice (bench config 4 sorts by opcode).
-    size_t i = 0;
-    int rc = EOC_OK;
-    size_t max_jobs = 0;
+    // mixed batch.  Every maximal run of equal opcodes is one batch; when the caller's order has many
+    // runs the rows are first gathered into opcode-sorted order on the device (stable, so equal opcodes keep
+    // their relative order), evaluated run by run, and scattered back.
     for (size_t k = 0; k < count; k++) {
         if (!op_valid(ops[k])) {
             eoc_set_error("eoc_gate_batch_device: bad opcode %d at %zu", (int)ops[k], k);
             return EOC_ERR_ARG;
         }
+        if ((!op_free(ops[k]) && !d_in1) || (ops[k] == OP_MUX && !d_in2)) {
+            eoc_set_error("eoc_gate_batch_device: missing operand for opcode %d", (int)ops[k]);
+            return EOC_ERR_ARG;
+        }
     }
-    // worst case jobs for one run
+    size_t runs = 1;
+    for (size_t k = 1; k < count; k++) runs += ops[k] != ops[k - 1];
+    std::vector<uint8_t> sorted_ops;
+    const uint8_t *run_ops = ops;
+    const int32_t *in0 = d_in0, *in1 = d_in1, *in2 = d_in2;
+    int32_t *out = d_out;
+    const bool gather = runs > 13; // more runs than opcodes: sorting pays
+    if (gather) {
+        std::vector<uint32_t> perm(count);
+        size_t bucket[14] = {0};
+        for (size_t k = 0; k < count; k++) bucket[ops[k] + 1]++;
+        for (int o = 1; o < 14; o++) bucket[o] += bucket[o - 1];
+        sorted_ops.resize(count);
+        for (size_t k = 0; k < count; k++) {
+            size_t pos = bucket[ops[k]]++;
+            perm[pos] = (uint32_t)k;
+            sorted_ops[pos] = ops[k];
+        }
+        const size_t rows_bytes = count * stride * 4;
+        if (count > e->ws_mixed) {
+            hipDeviceSynchronize();
+            hipFree(e->d_mixed);
+            e->d_mixed = nullptr;
+            e->ws_mixed = 0;
+            HIP_TRY(hipMalloc(&e->d_mixed, 4 * rows_bytes + count * 4));
+            e->ws_mixed = count;
+        }
+        int32_t *g0 = e->d_mixed, *g1 = g0 + count * stride, *g2 = g1 + count * stride, *go = g2 + count * stride;
+        uint32_t *d_perm = reinterpret_cast<uint32_t *>(go + count * stride);
+        HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), count * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st)); // perm is a local vector: the copy must finish before it dies
+        dim3 grid((unsigned)((stride + 255) / 256), (unsigned)count);
+        hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in0, g0, d_perm, (int)stride, 0);
+        if (d_in1) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in1, g1, d_perm, (int)stride, 0);
+        if (d_in2) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in2, g2, d_perm, (int)stride, 0);
+        HIP_TRY(hipGetLastError());
+        in0 = g0;
+        in1 = d_in1 ? g1 : nullptr;
+        in2 = d_in2 ? g2 : nullptr;
+        out = go;
+        run_ops = sorted_ops.data();
+    }
+    size_t max_jobs = 0;
     {
         size_t run = 0;
         for (size_t k = 0; k < count; k++) {
-            run = (k && ops[k] == ops[k - 1]) ? run + 1 : 1;
-            max_jobs = std::max(max_jobs, run * (ops[k] == OP_MUX ? 2 : 1));
+            run = (k && run_ops[k] == run_ops[k - 1]) ? run + 1 : 1;
+            max_jobs = std::max(max_jobs, run * (run_ops[k] == OP_MUX ? 2 : 1));
         }
     }
-    rc = ensure_ws(e, max_jobs, 2);
+    int rc = ensure_ws(e, max_jobs, 2);
     if (rc) return rc;
+    size_t i = 0;
     while (i < count) {
         size_t j = i;
-        while (j < count && ops[j] == ops[i]) j++;
-        int o = ops[i];
-        if ((!op_free(o) && !d_in1) || (o == OP_MUX && !d_in2)) {
-            eoc_set_error("eoc_gate_batch_device: missing operand for opcode %d", o);
-            return EOC_ERR_ARG;
-        }
-        GateDesc d{o, 0, d_in0 + i * stride, d_in1 ? d_in1 + i * stride : nullptr,
-                   d_in2 ? d_in2 + i * stride : nullptr, d_out + i * stride};
+        while (j < count && run_ops[j] == run_ops[i]) j++;
+        int o = run_ops[i];
+        GateDesc d{o, 0, in0 + i * stride, in1 ? in1 + i * stride : nullptr, in2 ? in2 + i * stride : nullptr,
+                   out + i * stride};
         boot.clear();
         freeg.clear();
         (op_free(o) ? freeg : boot).push_back(d);
         rc = run_level(e, boot, freeg, j - i, e->d_descs, st);
         if (rc) return rc;
         i = j;
+    }
+    if (gather) {
+        const uint32_t *d_perm = reinterpret_cast<const uint32_t *>(e->d_mixed + 4 * count * stride);
+        dim3 grid((unsigned)((stride + 255) / 256), (unsigned)count);
+        hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, out, d_out, d_perm, (int)stride, 1);
+        HIP_TRY(hipGetLastError());
     }
     return EOC_OK;
 }

@@ -525,6 +525,19 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #define EOC_STAMP(k) do { } while (0)
 #endif
 
+// mixed batches in arbitrary opcode order: rows are gathered into opcode-sorted order, evaluated run by
+// run, and scattered back.  perm[i] = original index of the i-th gate in sorted order.
+// grid: x = ceil(rowlen / 256), y = rows
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                                                     const uint32_t *__restrict__ perm, int rowlen, int scatter)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= rowlen) return;
+    const size_t i = blockIdx.y, j = perm[i];
+    if (scatter) dst[j * rowlen + m] = src[i * rowlen + m];
+    else dst[i * rowlen + m] = src[j * rowlen + m];
+}
+
 // =================================================================================================
 // K2: blind rotate + sample extract.  One workgroup = 4 waves = 2 ciphertexts; wave pair (h = 0,1)
 // of a ciphertext: wave h owns accumulator polynomial h, decomposes it, runs the l forward

@@ -143,7 +143,8 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  *
  * one homogeneous or mixed batch of independent gates, all operands resident on the device.
  *   op      : opcode when ops == NULL
- *   ops     : HOST array [count] of opcodes, or NULL
+ *   ops     : HOST array [count] of opcodes in any order, or NULL (equal opcodes are grouped on the device:
+ *             gather into opcode-sorted order, one batch per opcode, scatter back)
  *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX)
  *   d_out   : DEVICE array  [count][n+1] int32
  * bootsNAND ... bootsMUX over a batch.  Asynchronous on hip_stream (NULL = default stream). */

@@ -343,3 +343,18 @@ def test_unsupported_keyswitch_shape_fails_loudly(eoc):
     with pytest.raises(eoc.EocError, match="key switch: unsupported"):
         eng.gate_batch_device(0, c.data_ptr(), c.data_ptr(), None, out.data_ptr(), 2)
     eng.close()
+
+
+def test_mixed_ops_arbitrary_order_large(eoc, rig_small):
+    """BASELINE config 4's op stream is uniform over {NAND, XOR, MUX} in ARBITRARY order: the engine sorts by
+    opcode on the device (gather, per-opcode runs, scatter); results equal the oracle gate by gate"""
+    r = rig_small
+    cnt = 300
+    rng = np.random.default_rng(44)
+    ops = rng.choice(np.array([eoc.OPS[k] for k in ("NAND", "XOR", "MUX", "NOT", "ORYN", "COPY")], np.uint8), cnt)
+    _, a = _rand_cts(r, cnt, 45)
+    _, b = _rand_cts(r, cnt, 46)
+    _, c = _rand_cts(r, cnt, 47)
+    got = r.gate(0, a, b, c, ops=ops)
+    want = r.orc.gate_batch(0, a, b, c, ops=ops)
+    assert np.array_equal(got, want)
