@@ -508,6 +508,8 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #define EOC_ACC_REGS 1
 //   EOC_L3_TRIPLE gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 %    (on)
 #define EOC_L3_TRIPLE 1
+//   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)
+#define EOC_THEIRS_FIRST 1
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -702,7 +704,10 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #define EOC_BK_PREFETCH 0
 #endif
             d2 ba[8], bb[8], xa[8], xb[8];
-#ifndef EOC_LATE_BK
+#if defined(EOC_THEIRS_FIRST)
+            load_row(p, L == 2 ? 1 - h : h, ba);
+            load_row(p + 1, L == 2 ? 1 - h : h, bb);
+#elif !defined(EOC_LATE_BK)
             load_row(p, h, ba);
             load_row(p + 1, h, bb);
 #endif
@@ -727,6 +732,22 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #ifdef EOC_LATE_BK
             load_row(p, h, ba);
             load_row(p + 1, h, bb);
+#endif
+#if defined(EOC_THEIRS_FIRST)
+            if constexpr (L == 2) {
+                // early-loaded rows are the PARTNER's: its partial spectrum is stored before the own
+                // accumulation, which then runs while that store lands and the partner catches up
+                mac(true, xa, ba, theirs);
+                mac(false, xb, bb, theirs);
+                load_row(p, h, ba);
+                load_row(p + 1, h, bb);
+#pragma unroll
+                for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+                mac(true, xa, ba, mine);
+                mac(false, xb, bb, mine);
+                EOC_STAMP(3);
+                return;
+            }
 #endif
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
@@ -788,8 +809,13 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #endif
         if constexpr (L == 4) pair_pass(std::integral_constant<int, 3>{});
         // hand the other polynomial's partial spectrum to the partner wave
+#if defined(EOC_THEIRS_FIRST)
+        if constexpr (L != 2)
+#endif
+        {
 #pragma unroll
-        for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+            for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+        }
         EOC_STAMP(4);
         EOC_SYNC();
         EOC_STAMP(5);
