@@ -289,6 +289,12 @@ __device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&x
 __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
+#ifdef EOC_INV_TW_PREFETCH
+    // the middle pass's twiddles are requested before the first transposition so that they are not queued
+    // behind it (one wave's LDS operations return in issue order)
+    const d2 *t1 = tw + kTwI1 + lo;
+    const d2 m6 = t1[6 * 8], m4 = t1[4 * 8], m5 = t1[5 * 8], m0 = t1[0 * 8], m1 = t1[1 * 8], m2 = t1[2 * 8], m3 = t1[3 * 8];
+#endif
     { // stages 8,7,6 (bits 0,1,2): register constants
         const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
         ct_1(x[0], x[1]);
@@ -312,23 +318,29 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
 #endif
+#ifdef EOC_INV_TW_PREFETCH
+    // likewise the last pass's twiddles, requested before the middle pass computes
+    const d2 *t0 = tw + kTwI0 + lane;
+    const d2 n6 = t0[6 * 64], n4 = t0[4 * 64], n5 = t0[5 * 64], n0 = t0[0 * 64], n1 = t0[1 * 64], n2 = t0[2 * 64],
+             n3 = t0[3 * 64];
+#endif
     { // stages 5,4,3 (bits 3,4,5): W[(i mod h) << s] depends on lane & 7 (and the lower register bits)
+#ifndef EOC_INV_TW_PREFETCH
         const d2 *t = tw + kTwI1 + lo;
-        d2 w6 = t[6 * 8];
-        ct_wc(x[0], x[1], w6);
-        ct_wc(x[2], x[3], w6);
-        ct_wc(x[4], x[5], w6);
-        ct_wc(x[6], x[7], w6);
-        d2 w4 = t[4 * 8], w5 = t[5 * 8];
-        ct_wc(x[0], x[2], w4);
-        ct_wc(x[1], x[3], w5);
-        ct_wc(x[4], x[6], w4);
-        ct_wc(x[5], x[7], w5);
-        d2 w0 = t[0 * 8], w1 = t[1 * 8], w2 = t[2 * 8], w3 = t[3 * 8];
-        ct_wc(x[0], x[4], w0);
-        ct_wc(x[1], x[5], w1);
-        ct_wc(x[2], x[6], w2);
-        ct_wc(x[3], x[7], w3);
+        const d2 m6 = t[6 * 8], m4 = t[4 * 8], m5 = t[5 * 8], m0 = t[0 * 8], m1 = t[1 * 8], m2 = t[2 * 8], m3 = t[3 * 8];
+#endif
+        ct_wc(x[0], x[1], m6);
+        ct_wc(x[2], x[3], m6);
+        ct_wc(x[4], x[5], m6);
+        ct_wc(x[6], x[7], m6);
+        ct_wc(x[0], x[2], m4);
+        ct_wc(x[1], x[3], m5);
+        ct_wc(x[4], x[6], m4);
+        ct_wc(x[5], x[7], m5);
+        ct_wc(x[0], x[4], m0);
+        ct_wc(x[1], x[5], m1);
+        ct_wc(x[2], x[6], m2);
+        ct_wc(x[3], x[7], m3);
     }
 #ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
@@ -339,22 +351,23 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
     wave_lds_fence();
 #endif
     { // stages 2,1,0 (bits 6,7,8): depends on the lane (and the lower register bits)
+#ifndef EOC_INV_TW_PREFETCH
         const d2 *t = tw + kTwI0 + lane;
-        d2 w6 = t[6 * 64];
-        ct_wc(x[0], x[1], w6);
-        ct_wc(x[2], x[3], w6);
-        ct_wc(x[4], x[5], w6);
-        ct_wc(x[6], x[7], w6);
-        d2 w4 = t[4 * 64], w5 = t[5 * 64];
-        ct_wc(x[0], x[2], w4);
-        ct_wc(x[1], x[3], w5);
-        ct_wc(x[4], x[6], w4);
-        ct_wc(x[5], x[7], w5);
-        d2 w0 = t[0 * 64], w1 = t[1 * 64], w2 = t[2 * 64], w3 = t[3 * 64];
-        ct_wc(x[0], x[4], w0);
-        ct_wc(x[1], x[5], w1);
-        ct_wc(x[2], x[6], w2);
-        ct_wc(x[3], x[7], w3);
+        const d2 n6 = t[6 * 64], n4 = t[4 * 64], n5 = t[5 * 64], n0 = t[0 * 64], n1 = t[1 * 64], n2 = t[2 * 64],
+                 n3 = t[3 * 64];
+#endif
+        ct_wc(x[0], x[1], n6);
+        ct_wc(x[2], x[3], n6);
+        ct_wc(x[4], x[5], n6);
+        ct_wc(x[6], x[7], n6);
+        ct_wc(x[0], x[2], n4);
+        ct_wc(x[1], x[3], n5);
+        ct_wc(x[4], x[6], n4);
+        ct_wc(x[5], x[7], n5);
+        ct_wc(x[0], x[4], n0);
+        ct_wc(x[1], x[5], n1);
+        ct_wc(x[2], x[6], n2);
+        ct_wc(x[3], x[7], n3);
     }
 }
 
@@ -510,6 +523,8 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #define EOC_L3_TRIPLE 1
 //   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)
 #define EOC_THEIRS_FIRST 1
+//   EOC_INV_TW_PREFETCH  inverse-transform twiddles / un-twist factors requested one pass early: 0 %   (off)
+//   EOC_STAGGER_MODE     de-phasing the workgroups that share a CU: 0 %                                (off)
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -826,12 +841,21 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(6);
         EOC_SYNC();
         EOC_STAMP(7);
+#ifdef EOC_INV_TW_PREFETCH
+        d2 ut[8]; // un-twist factors, requested before the transform instead of after it
+#pragma unroll
+        for (int r = 0; r < 8; r++) ut[r] = s_twist[lane + 64 * r];
+#endif
         fft_inv_wave(x, s_tw, scr, lane);
         EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
+#ifdef EOC_INV_TW_PREFETCH
+            d2 y = cmulc(x[r], ut[r]); // the 1/512 is in the key image
+#else
             d2 y = cmulc(x[r], s_twist[j]); // the 1/512 is in the key image
+#endif
 #ifdef EOC_ACC_REGS
             racc[r] += wrap_round(y.x);
             racc[8 + r] += wrap_round(y.y);
