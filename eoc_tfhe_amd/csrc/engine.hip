@@ -488,7 +488,7 @@ static int run_level(eoc_engine *e, std::vector<GateDesc> &boot, std::vector<Gat
     GateDesc *dd = d_descs_slot + ofs;
     HIP_TRY(hipMemcpyAsync(dd, boot.data(), boot.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
     {
-        dim3 grid((unsigned)((n + 1 + 255) / 256), (unsigned)(S * (any_mux ? 2 : 1)), (unsigned)boot.size());
+        dim3 grid((unsigned)(S * (any_mux ? 2 : 1)), (unsigned)((n + 1 + 255) / 256), (unsigned)boot.size());
         SpanGuard span(e, st, KIND_PREPARE);
         hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, e->d_bara, e->bara_stride);
         HIP_TRY(hipGetLastError());
@@ -577,7 +577,7 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
         uint32_t *d_perm = reinterpret_cast<uint32_t *>(go + count * stride);
         HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), count * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st)); // perm is a local vector: the copy must finish before it dies
-        dim3 grid((unsigned)((stride + 255) / 256), (unsigned)count);
+        dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
         hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in0, g0, d_perm, (int)stride, 0);
         if (d_in1) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in1, g1, d_perm, (int)stride, 0);
         if (d_in2) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in2, g2, d_perm, (int)stride, 0);
@@ -614,7 +614,7 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
     }
     if (gather) {
         const uint32_t *d_perm = reinterpret_cast<const uint32_t *>(e->d_mixed + 4 * count * stride);
-        dim3 grid((unsigned)((stride + 255) / 256), (unsigned)count);
+        dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
         hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, out, d_out, d_perm, (int)stride, 1);
         HIP_TRY(hipGetLastError());
     }
@@ -710,7 +710,7 @@ extern "C" int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_
     if (rc) return rc;
     GateDesc d{OP_RAW, 0, d_t, nullptr, nullptr, nullptr};
     HIP_TRY(hipMemcpyAsync(e->d_descs, &d, sizeof d, hipMemcpyHostToDevice, st));
-    dim3 grid((unsigned)((e->p.n + 1 + 255) / 256), (unsigned)count, 1);
+    dim3 grid((unsigned)count, (unsigned)((e->p.n + 1 + 255) / 256), 1);
     hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, e->d_descs, e->p.n, (uint32_t)count, e->d_bara,
                        e->bara_stride);
     HIP_TRY(hipGetLastError());

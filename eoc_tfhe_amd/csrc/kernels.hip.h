@@ -478,15 +478,16 @@ __device__ __forceinline__ void gate_lin(int op, int &cst8, int &s0, int &s1)
     }
 }
 
-// grid: x = ceil((n+1)/256), y = jobs of the widest gate (S or 2S), z = gates of this level
+// grid: x = jobs of the widest gate (S or 2S; the large dimension goes on x), y = ceil((n+1)/256),
+//       z = gates of this level
 __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ descs, int n, uint32_t S,
                                                  uint16_t *__restrict__ bara, int bara_stride)
 {
     const GateDesc d = descs[blockIdx.z];
-    const uint32_t y = blockIdx.y;
+    const uint32_t y = blockIdx.x;
     const uint32_t variant = y / S, s = y - variant * S;
     if (variant >= (d.op == OP_MUX ? 2u : 1u)) return;
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y * 256 + threadIdx.x;
     if (m > n) return;
     int op = d.op;
     const int32_t *a = d.in0, *b = d.in1;
@@ -544,13 +545,13 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 
 // mixed batches in arbitrary opcode order: rows are gathered into opcode-sorted order, evaluated run by
 // run, and scattered back.  perm[i] = original index of the i-th gate in sorted order.
-// grid: x = ceil(rowlen / 256), y = rows
+// grid: x = rows, y = ceil(rowlen / 256)
 __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
                                                      const uint32_t *__restrict__ perm, int rowlen, int scatter)
 {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y * 256 + threadIdx.x;
     if (m >= rowlen) return;
-    const size_t i = blockIdx.y, j = perm[i];
+    const size_t i = blockIdx.x, j = perm[i];
     if (scatter) dst[j * rowlen + m] = src[i * rowlen + m];
     else dst[i * rowlen + m] = src[j * rowlen + m];
 }

@@ -108,3 +108,18 @@ def test_config4_mixed_gates_one_shard(eoc, rig):
     idx = np.concatenate([np.flatnonzero(ops == o)[:6] for o in np.unique(ops)])
     h = [x.cpu().numpy()[idx] for x in c]
     assert np.array_equal(got[idx], orc.gate_batch(0, h[0], h[1], h[2], ops=ops[idx]))
+
+
+def test_single_launch_262144_gates(eoc, rig):
+    """one launch far beyond the headline batch (2^18 gates: 131072 workgroups, grid dimensions > 65535):
+    every gate decrypts correctly"""
+    p, sk, eng = rig
+    torch = torch_cuda()
+    cnt = 1 << 18
+    rng = np.random.default_rng(18)
+    b0, b1 = rng.integers(0, 2, cnt).astype(np.uint8), rng.integers(0, 2, cnt).astype(np.uint8)
+    c0, c1 = to_dev(sk.encrypt_bits(b0, 6000, 0)), to_dev(sk.encrypt_bits(b1, 6001, 0))
+    out = torch.empty_like(c0)
+    eng.gate_batch_device(eoc.OPS["XNOR"], c0.data_ptr(), c1.data_ptr(), None, out.data_ptr(), cnt)
+    sync()
+    assert np.array_equal(sk.decrypt_bits(out.cpu().numpy()), 1 - (b0 ^ b1))
