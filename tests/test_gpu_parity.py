@@ -358,3 +358,24 @@ def test_mixed_ops_arbitrary_order_large(eoc, rig_small):
     got = r.gate(0, a, b, c, ops=ops)
     want = r.orc.gate_batch(0, a, b, c, ops=ops)
     assert np.array_equal(got, want)
+
+
+def test_deep_chain_bit_exact_set_a(eoc, rig_a):
+    """24 dependent levels x 96 gates on Set A (outputs of one level feed the next, alternating opcodes): GPU and
+    oracle stay bit-identical through the whole depth (2304 bootstraps, ~1.1 M CMux steps, so the rare
+    abar = 0 steps -- one in 2048 -- occur hundreds of times) and every level decrypts correctly."""
+    r = rig_a
+    width, depth = 96, 24
+    bits, cur = _rand_cts(r, width, 91)
+    ref = cur.copy()
+    names = ["NAND", "XOR", "ORNY", "XNOR", "AND", "NOR"]
+    for lv in range(depth):
+        op = names[lv % len(names)]
+        a, b = cur, np.roll(cur, lv + 1, axis=0)
+        cur = r.gate(eoc.OPS[op], a, b)
+        ref = r.orc.gate_batch(ol.OPS[op], ref, np.roll(ref, lv + 1, axis=0))
+        assert np.array_equal(cur, ref), f"diverged at level {lv} ({op})"
+        x, y = bits, np.roll(bits, lv + 1)
+        bits = {"NAND": 1 - (x & y), "XOR": x ^ y, "ORNY": (1 - x) | y, "XNOR": 1 - (x ^ y), "AND": x & y,
+                "NOR": 1 - (x | y)}[op]
+        assert np.array_equal(r.sk.decrypt_bits(cur), bits), f"wrong plaintext at level {lv}"
