@@ -323,8 +323,9 @@ static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_
         eoc_set_error("cloud key upload failed");
         return EOC_ERR_HIP;
     }
-    // the key image carries the inverse transform's 1/512 (exact power-of-two scaling)
-    int rc = launch_fft_fwd(e, d_bk, d_bkfft, npoly, 0x1p-9, nullptr);
+    // the key image carries the inverse transform's 1/512 and the 2^-32 of the wrap-around rounding
+    // (exact power-of-two scaling; products stay around 2^11, far from underflow)
+    int rc = launch_fft_fwd(e, d_bk, d_bkfft, npoly, 0x1p-41, nullptr);
     hipError_t se = hipDeviceSynchronize();
     hipFree(d_bk);
     if (rc) return rc;

@@ -381,6 +381,15 @@ __device__ __forceinline__ uint32_t wrap_round(double v)
     double m = lo + 6755399441055744.0;
     return (uint32_t)__double2loint(m);
 }
+// the same for a value that arrives pre-scaled, w = v * 2^-32 (exactly: power of two):
+//   q = rint(w);  w - q is exact (|w - q| <= 1/2, a multiple of ulp(w));  fma((w - q), 2^32, 1.5 * 2^52) rounds
+//   v - q * 2^32 to the nearest-even integer in the low mantissa bits.  3 operations instead of 4.
+__device__ __forceinline__ uint32_t wrap_round_scaled(double w)
+{
+    double q = __builtin_rint(w);
+    double m = EOC_FMA(w - q, 4294967296.0, 6755399441055744.0);
+    return (uint32_t)__double2loint(m);
+}
 
 // copy the two constant tables into LDS (called by all 256 threads, followed by __syncthreads)
 __device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_tw, const d2 *g_twist, int tid)
@@ -392,8 +401,9 @@ __device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_t
 // =================================================================================================
 // K4 / debug: forward transform of `count` integer polynomials, one wave each
 // =================================================================================================
-// `scale` must be a power of two (exact): 1 for the plain transform, 2^-9 for the key image so that
-// the inverse transform's 1/512 is already in the products (bit-identical to scaling at the end)
+// `scale` must be a power of two (exact): 1 for the plain transform, 2^-41 for the key image so that the
+// inverse transform's 1/512 and the 2^-32 of the wrap-around rounding are already in the products
+// (bit-identical to scaling at the end)
 __global__ __launch_bounds__(256) void k_fft_fwd_polys(const int32_t *__restrict__ polys,
                                                         double *__restrict__ specs, size_t count,
                                                         const d2 *__restrict__ g_tw,
@@ -853,18 +863,18 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
 #ifdef EOC_INV_TW_PREFETCH
-            d2 y = cmulc(x[r], ut[r]); // the 1/512 is in the key image
+            d2 y = cmulc(x[r], ut[r]); // (1/512) * 2^-32 is in the key image
 #else
-            d2 y = cmulc(x[r], s_twist[j]); // the 1/512 is in the key image
+            d2 y = cmulc(x[r], s_twist[j]); // (1/512) * 2^-32 is in the key image
 #endif
 #ifdef EOC_ACC_REGS
-            racc[r] += wrap_round(y.x);
-            racc[8 + r] += wrap_round(y.y);
+            racc[r] += wrap_round_scaled(y.x); // the key image carries 2^-41 = (1/512) * 2^-32
+            racc[8 + r] += wrap_round_scaled(y.y);
             acc[j] = (int32_t)racc[r];
             acc[j + kNH] = (int32_t)racc[8 + r];
 #else
-            acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round(y.x));
-            acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round(y.y));
+            acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round_scaled(y.x));
+            acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round_scaled(y.y));
 #endif
         }
         wave_lds_fence();

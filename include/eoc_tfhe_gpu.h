@@ -117,7 +117,8 @@ int eoc_device_to_host(eoc_engine *e, void *dst, const void *d_src, size_t bytes
 int eoc_engine_synchronize(eoc_engine *e);
 
 /* device-side key image sizes in bytes: BK-FFT [n][2l][2][512] complex f64 (bin order sigma, values
- * scaled by 2^-9: the image carries the inverse transform's 1/512, an exact power-of-two scaling),
+ * scaled by 2^-41: the image carries the inverse transform's 1/512 and the 2^-32 of the final wrap-around
+ * rounding, an exact power-of-two scaling),
  * KSK [N*t][base-1][n1p] int32 (rows d = 1..base-1, zero-padded to n1p = eoc_ksk_row_stride) */
 size_t eoc_bkfft_bytes(const eoc_params *p);
 size_t eoc_ksk_dev_bytes(const eoc_params *p);
