@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -45,6 +46,8 @@ struct eoc_engine {
     int32_t *d_u = nullptr;
     uint32_t *d_ubarT = nullptr; // [N][ws_jobs] key-switch operand, transposed
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
+    int br_mode = 0;                        // 0 auto, 1 pair form always, 2 throughput form always
+    uint32_t br_t_threshold = 0xFFFFFFFFu;  // jobs from which the throughput form is used (set after measuring)
     int32_t *d_mixed = nullptr;             // gather/scatter space of mixed batches: 4 row arrays + perm
     size_t ws_mixed = 0;
     size_t ws_jobs = 0;
@@ -188,6 +191,14 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
+    if (const char *m = getenv("EOC_TFHE_BR_MODE")) e->br_mode = atoi(m); // 1 = pair form, 2 = throughput form
+    if (const char *t = getenv("EOC_TFHE_BR_T_THRESHOLD")) e->br_t_threshold = (uint32_t)atol(t);
     *out = e;
     return EOC_OK;
 }
@@ -402,6 +413,27 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     a.stamps = e->d_stamps;
     dim3 grid((njobs + 1) / 2), block(256);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
+    // large launches take the one-wave-per-ciphertext form (no pair exchange, skewed inverse pair); the
+    // 1024-gate headline needs two waves per ciphertext to put two waves on every SIMD
+    const int mode = e->br_mode; // 0 auto, 1 pair form, 2 throughput form
+    const bool tform = mode == 2 || (mode == 0 && njobs >= e->br_t_threshold);
+    if (tform) {
+        dim3 gt((njobs + 7) / 8), bt(512);
+        if (e->p.l == 2 && e->p.Bgbit == 10)
+            hipLaunchKernelGGL((k_blind_rotate_t<2, 10>), gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist);
+        else if (e->p.l == 3 && e->p.Bgbit == 7)
+            hipLaunchKernelGGL((k_blind_rotate_t<3, 7>), gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist);
+        else
+            switch (e->p.l) {
+            case 1: hipLaunchKernelGGL(k_blind_rotate_t<1>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
+            case 2: hipLaunchKernelGGL(k_blind_rotate_t<2>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
+            case 3: hipLaunchKernelGGL(k_blind_rotate_t<3>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
+            case 4: hipLaunchKernelGGL(k_blind_rotate_t<4>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
+            default: return EOC_ERR_ARG;
+            }
+        HIP_TRY(hipGetLastError());
+        return EOC_OK;
+    }
     if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
         hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
     else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B

@@ -285,90 +285,123 @@ __device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&x
     fwd_pass2(xc, tw, lane);
 }
 
-// inverse: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time, conjugate twiddles
-__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+// ---- inverse transform, in pieces: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time,
+// conjugate twiddles ---------------------------------------------------------------------------------
+__device__ __forceinline__ void inv_pass2(d2 (&x)[8])
+{ // stages 8,7,6 (bits 0,1,2): register constants
+    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
+    ct_1(x[0], x[1]);
+    ct_1(x[2], x[3]);
+    ct_1(x[4], x[5]);
+    ct_1(x[6], x[7]);
+    ct_1(x[0], x[2]);
+    ct_ic(x[1], x[3]);
+    ct_1(x[4], x[6]);
+    ct_ic(x[5], x[7]);
+    ct_1(x[0], x[4]);
+    ct_wc(x[1], x[5], wc);
+    ct_ic(x[2], x[6]);
+    ct_wc(x[3], x[7], wd);
+}
+__device__ __forceinline__ void inv_pass1(d2 (&x)[8], const d2 *tw, int lane)
+{ // stages 5,4,3 (bits 3,4,5): W[(i mod h) << s] depends on lane & 7 (and the lower register bits)
+    const d2 *t = tw + kTwI1 + (lane & 7);
+    const d2 m6 = t[6 * 8];
+    ct_wc(x[0], x[1], m6);
+    ct_wc(x[2], x[3], m6);
+    ct_wc(x[4], x[5], m6);
+    ct_wc(x[6], x[7], m6);
+    const d2 m4 = t[4 * 8], m5 = t[5 * 8];
+    ct_wc(x[0], x[2], m4);
+    ct_wc(x[1], x[3], m5);
+    ct_wc(x[4], x[6], m4);
+    ct_wc(x[5], x[7], m5);
+    const d2 m0 = t[0 * 8], m1 = t[1 * 8], m2 = t[2 * 8], m3 = t[3 * 8];
+    ct_wc(x[0], x[4], m0);
+    ct_wc(x[1], x[5], m1);
+    ct_wc(x[2], x[6], m2);
+    ct_wc(x[3], x[7], m3);
+}
+__device__ __forceinline__ void inv_pass0(d2 (&x)[8], const d2 *tw, int lane)
+{ // stages 2,1,0 (bits 6,7,8): depends on the lane (and the lower register bits)
+    const d2 *t = tw + kTwI0 + lane;
+    const d2 n6 = t[6 * 64];
+    ct_wc(x[0], x[1], n6);
+    ct_wc(x[2], x[3], n6);
+    ct_wc(x[4], x[5], n6);
+    ct_wc(x[6], x[7], n6);
+    const d2 n4 = t[4 * 64], n5 = t[5 * 64];
+    ct_wc(x[0], x[2], n4);
+    ct_wc(x[1], x[3], n5);
+    ct_wc(x[4], x[6], n4);
+    ct_wc(x[5], x[7], n5);
+    const d2 n0 = t[0 * 64], n1 = t[1 * 64], n2 = t[2 * 64], n3 = t[3 * 64];
+    ct_wc(x[0], x[4], n0);
+    ct_wc(x[1], x[5], n1);
+    ct_wc(x[2], x[6], n2);
+    ct_wc(x[3], x[7], n3);
+}
+__device__ __forceinline__ void t21_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-    const int hi = lane >> 3, lo = lane & 7;
-#ifdef EOC_INV_TW_PREFETCH
-    // the middle pass's twiddles are requested before the first transposition so that they are not queued
-    // behind it (one wave's LDS operations return in issue order)
-    const d2 *t1 = tw + kTwI1 + lo;
-    const d2 m6 = t1[6 * 8], m4 = t1[4 * 8], m5 = t1[5 * 8], m0 = t1[0 * 8], m1 = t1[1 * 8], m2 = t1[2 * 8], m3 = t1[3 * 8];
-#endif
-    { // stages 8,7,6 (bits 0,1,2): register constants
-        const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
-        ct_1(x[0], x[1]);
-        ct_1(x[2], x[3]);
-        ct_1(x[4], x[5]);
-        ct_1(x[6], x[7]);
-        ct_1(x[0], x[2]);
-        ct_ic(x[1], x[3]);
-        ct_1(x[4], x[6]);
-        ct_ic(x[5], x[7]);
-        ct_1(x[0], x[4]);
-        ct_wc(x[1], x[5], wc);
-        ct_ic(x[2], x[6]);
-        ct_wc(x[3], x[7], wd);
-    }
 #if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
     wave_lds_fence();
+#endif
+}
+__device__ __forceinline__ void t21_read(d2 (&x)[8], const d2 *scr, int lane)
+{
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
+    const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
 #endif
-#ifdef EOC_INV_TW_PREFETCH
-    // likewise the last pass's twiddles, requested before the middle pass computes
-    const d2 *t0 = tw + kTwI0 + lane;
-    const d2 n6 = t0[6 * 64], n4 = t0[4 * 64], n5 = t0[5 * 64], n0 = t0[0 * 64], n1 = t0[1 * 64], n2 = t0[2 * 64],
-             n3 = t0[3 * 64];
-#endif
-    { // stages 5,4,3 (bits 3,4,5): W[(i mod h) << s] depends on lane & 7 (and the lower register bits)
-#ifndef EOC_INV_TW_PREFETCH
-        const d2 *t = tw + kTwI1 + lo;
-        const d2 m6 = t[6 * 8], m4 = t[4 * 8], m5 = t[5 * 8], m0 = t[0 * 8], m1 = t[1 * 8], m2 = t[2 * 8], m3 = t[3 * 8];
-#endif
-        ct_wc(x[0], x[1], m6);
-        ct_wc(x[2], x[3], m6);
-        ct_wc(x[4], x[5], m6);
-        ct_wc(x[6], x[7], m6);
-        ct_wc(x[0], x[2], m4);
-        ct_wc(x[1], x[3], m5);
-        ct_wc(x[4], x[6], m4);
-        ct_wc(x[5], x[7], m5);
-        ct_wc(x[0], x[4], m0);
-        ct_wc(x[1], x[5], m1);
-        ct_wc(x[2], x[6], m2);
-        ct_wc(x[3], x[7], m3);
-    }
+}
+__device__ __forceinline__ void t10_write(const d2 (&x)[8], d2 *scr, int lane)
+{
 #ifndef EOC_ABL_NOTRANSPOSE
+    const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = x[r];
     wave_lds_fence();
+#endif
+}
+__device__ __forceinline__ void t10_read(d2 (&x)[8], const d2 *scr, int lane)
+{
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
     wave_lds_fence();
 #endif
-    { // stages 2,1,0 (bits 6,7,8): depends on the lane (and the lower register bits)
-#ifndef EOC_INV_TW_PREFETCH
-        const d2 *t = tw + kTwI0 + lane;
-        const d2 n6 = t[6 * 64], n4 = t[4 * 64], n5 = t[5 * 64], n0 = t[0 * 64], n1 = t[1 * 64], n2 = t[2 * 64],
-                 n3 = t[3 * 64];
-#endif
-        ct_wc(x[0], x[1], n6);
-        ct_wc(x[2], x[3], n6);
-        ct_wc(x[4], x[5], n6);
-        ct_wc(x[6], x[7], n6);
-        ct_wc(x[0], x[2], n4);
-        ct_wc(x[1], x[3], n5);
-        ct_wc(x[4], x[6], n4);
-        ct_wc(x[5], x[7], n5);
-        ct_wc(x[0], x[4], n0);
-        ct_wc(x[1], x[5], n1);
-        ct_wc(x[2], x[6], n2);
-        ct_wc(x[3], x[7], n3);
-    }
+}
+__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+{
+    inv_pass2(x);
+    t21_write(x, scr, lane);
+    t21_read(x, scr, lane);
+    inv_pass1(x, tw, lane);
+    t10_write(x, scr, lane);
+    t10_read(x, scr, lane);
+    inv_pass0(x, tw, lane);
+}
+// two inverse transforms of one wave on one scratch, skewed like fft_fwd_wave_x2
+__device__ __forceinline__ void fft_inv_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+{
+    inv_pass2(xa);
+    t21_write(xa, scr, lane);
+    t21_read(xa, scr, lane);
+    inv_pass2(xb);
+    t21_write(xb, scr, lane);
+    t21_read(xb, scr, lane);
+    inv_pass1(xa, tw, lane);
+    t10_write(xa, scr, lane);
+    t10_read(xa, scr, lane);
+    inv_pass1(xb, tw, lane);
+    t10_write(xb, scr, lane);
+    t10_read(xb, scr, lane);
+    inv_pass0(xa, tw, lane);
+    inv_pass0(xb, tw, lane);
 }
 
 // rint + wrap to 32 bits, exact for |v| < 2^83:  q = rint(v / 2^32);  lo = v - q * 2^32 (exact, |lo| <= 2^31);
@@ -534,7 +567,7 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #define EOC_L3_TRIPLE 1
 //   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)
 #define EOC_THEIRS_FIRST 1
-//   EOC_INV_TW_PREFETCH  inverse-transform twiddles / un-twist factors requested one pass early: 0 %   (off)
+//   (requesting the inverse transform's twiddles / un-twist factors one pass early was measured too: 0 %, removed)
 //   EOC_STAGGER_MODE     de-phasing the workgroups that share a CU: 0 %                                (off)
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
@@ -852,21 +885,12 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(6);
         EOC_SYNC();
         EOC_STAMP(7);
-#ifdef EOC_INV_TW_PREFETCH
-        d2 ut[8]; // un-twist factors, requested before the transform instead of after it
-#pragma unroll
-        for (int r = 0; r < 8; r++) ut[r] = s_twist[lane + 64 * r];
-#endif
         fft_inv_wave(x, s_tw, scr, lane);
         EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
-#ifdef EOC_INV_TW_PREFETCH
-            d2 y = cmulc(x[r], ut[r]); // (1/512) * 2^-32 is in the key image
-#else
             d2 y = cmulc(x[r], s_twist[j]); // (1/512) * 2^-32 is in the key image
-#endif
 #ifdef EOC_ACC_REGS
             racc[r] += wrap_round_scaled(y.x); // the key image carries 2^-41 = (1/512) * 2^-32
             racc[8 + r] += wrap_round_scaled(y.y);
@@ -898,6 +922,201 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             u[kN] = acc[0];
         }
     }
+}
+
+// =================================================================================================
+// K2t: blind rotate, throughput form for LARGE launches (circuits, mixed batches: >= 2 waves per SIMD are
+// available from the job count alone).  One ciphertext = ONE wave: no partner exchange, no barriers in the
+// loop; the wave transforms the digits of polynomial 0, then of polynomial 1 (each pair skewed on the one
+// scratch), and runs the two inverse transforms as a skewed pair as well.  Same arithmetic, same
+// accumulation order (S_c = chain(q_in = 0) + chain(q_in = 1)) as k_blind_rotate: bit-identical results.
+// Workgroup = 512 threads = 8 ciphertexts; LDS = tables + 8 x (2 accumulator polynomials + scratch).
+// MEASURED SLOWER than the pair form at every size tried (255 k vs 296 k bootstraps/s on 131 072 mixed gates),
+// so the engine never selects it by itself (EOC_TFHE_BR_MODE=2 forces it); kept as a tested alternative.
+// =================================================================================================
+constexpr int kBRTLds = (kTwEntries + kNH + 8 * kScr) * 16 + 8 * 2 * kN * 4; // 162 560 bytes
+
+template <int L, int BGBIT = 0>
+__global__ __launch_bounds__(512, 2) void k_blind_rotate_t(BRArgs A, const d2 *__restrict__ g_tw,
+                                                           const d2 *__restrict__ g_twist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    d2 *s_tw = reinterpret_cast<d2 *>(smem);
+    d2 *s_twist = s_tw + kTwEntries;
+    d2 *s_scr_all = s_twist + kNH;
+    int32_t *s_acc_all = reinterpret_cast<int32_t *>(s_scr_all + 8 * kScr);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    d2 *scr = s_scr_all + w * kScr;
+    int32_t *acc = s_acc_all + w * 2 * kN; // [2][N]
+
+    for (int i = tid; i < kTwEntries; i += 512) s_tw[i] = g_tw[i];
+    for (int i = tid; i < kNH; i += 512) s_twist[i] = g_twist[i];
+    __syncthreads();
+    const uint32_t job = blockIdx.x * 8 + w;
+    if (job >= A.njobs) return; // no barrier below: idle waves simply leave
+    const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
+    {
+        const int barb = bara[A.n];
+        const int rot = (2 * kN - barb) & (2 * kN - 1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int j = lane + 64 * r;
+            int idx = (j - rot) & (2 * kN - 1);
+            acc[j] = 0;
+            acc[kN + j] = (idx & kN) ? -A.mu : A.mu;
+        }
+    }
+    wave_lds_fence();
+
+    const int Bgbit = BGBIT > 0 ? BGBIT : A.Bgbit;
+    const uint32_t maskBg = (1u << Bgbit) - 1, halfBg = 1u << (Bgbit - 1);
+    uint32_t offset = 0;
+#pragma unroll
+    for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
+    constexpr int KPL = 2 * L;
+    const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
+    const double digit_bias = 4503599627370496.0 + (double)halfBg;
+
+    for (int i = 0; i < A.n; i++) {
+        const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
+        d2 S0[8], S1[8]; // output spectra, accumulated as chain(q_in = 0) + chain(q_in = 1)
+        auto poly_pass = [&](auto hc) __attribute__((always_inline)) {
+            constexpr int hp = decltype(hc)::value; // input polynomial q_in
+            const int32_t *a = acc + hp * kN;
+            uint32_t dlo[8], dhi[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int j = lane + 64 * r;
+                int i0 = (j - abar) & (2 * kN - 1);
+                int i1 = (j + kNH - abar) & (2 * kN - 1);
+                uint32_t v0 = (uint32_t)a[i0 & (kN - 1)];
+                uint32_t v1 = (uint32_t)a[i1 & (kN - 1)];
+                v0 = (i0 & kN) ? 0u - v0 : v0;
+                v1 = (i1 & kN) ? 0u - v1 : v1;
+                dlo[r] = v0 - (uint32_t)a[j] + offset;
+                dhi[r] = v1 - (uint32_t)a[j + kNH] + offset;
+            }
+            const d2 *rows = bk + ((size_t)i * KPL + hp * L) * 2 * kNH; // rows (hp, p), p = 1..L
+            auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
+                const d2 *src = rows + ((size_t)(p - 1) * 2 + c) * kNH;
+#pragma unroll
+                for (int r = 0; r < 8; r++) b[r] = src[r * 64 + lane];
+            };
+            auto make_x = [&](int p, d2 (&x)[8]) __attribute__((always_inline)) {
+                const int shift = 32 - p * Bgbit;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    uint32_t ul = (dlo[r] >> shift) & maskBg, uh = (dhi[r] >> shift) & maskBg;
+                    d2 v = {__hiloint2double(0x43300000, (int)ul) - digit_bias,
+                            __hiloint2double(0x43300000, (int)uh) - digit_bias};
+                    x[r] = cmul(v, s_twist[lane + 64 * r]);
+                }
+            };
+            auto mac = [&](bool first, const d2 (&x)[8], const d2 (&b)[8], d2 (&acc_)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (first) {
+                        acc_[r].x = EOC_FMA(-x[r].y, b[r].y, x[r].x * b[r].x);
+                        acc_[r].y = EOC_FMA(x[r].y, b[r].x, x[r].x * b[r].y);
+                    } else {
+                        acc_[r].x = EOC_FMA(-x[r].y, b[r].y, EOC_FMA(x[r].x, b[r].x, acc_[r].x));
+                        acc_[r].y = EOC_FMA(x[r].y, b[r].x, EOC_FMA(x[r].x, b[r].y, acc_[r].y));
+                    }
+                }
+            };
+            // chain over the digits of this polynomial for output c, then folded into S_c
+            auto fold = [&](d2 (&S)[8], const d2 (&Q)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    if (hp == 0) S[r] = Q[r];
+                    else S[r] = S[r] + Q[r];
+                }
+            };
+            d2 ba[8], bb[8], Q[8];
+            if constexpr (L == 1) {
+                d2 x[8];
+                load_row(1, 0, ba);
+                make_x(1, x);
+                fft_fwd_wave(x, s_tw, scr, lane);
+                mac(true, x, ba, Q);
+                fold(S0, Q);
+                load_row(1, 1, ba);
+                mac(true, x, ba, Q);
+                fold(S1, Q);
+            } else {
+                d2 xa[8], xb[8];
+                load_row(1, 0, ba);
+                load_row(2, 0, bb);
+                make_x(1, xa);
+                make_x(2, xb);
+                fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
+                if constexpr (L == 2) {
+                    mac(true, xa, ba, Q);
+                    mac(false, xb, bb, Q);
+                    fold(S0, Q);
+                    load_row(1, 1, ba);
+                    load_row(2, 1, bb);
+                    mac(true, xa, ba, Q);
+                    mac(false, xb, bb, Q);
+                    fold(S1, Q);
+                } else { // L = 3 or 4: the remaining digit(s) after the first pair
+                    d2 Q1[8];
+                    mac(true, xa, ba, Q);
+                    mac(false, xb, bb, Q);
+                    load_row(1, 1, ba);
+                    load_row(2, 1, bb);
+                    mac(true, xa, ba, Q1);
+                    mac(false, xb, bb, Q1);
+                    if constexpr (L == 3) {
+                        load_row(3, 0, ba);
+                        load_row(3, 1, bb);
+                        make_x(3, xa);
+                        fft_fwd_wave(xa, s_tw, scr, lane);
+                        mac(false, xa, ba, Q);
+                        mac(false, xa, bb, Q1);
+                    } else {
+                        load_row(3, 0, ba);
+                        load_row(4, 0, bb);
+                        make_x(3, xa);
+                        make_x(4, xb);
+                        fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
+                        mac(false, xa, ba, Q);
+                        mac(false, xb, bb, Q);
+                        load_row(3, 1, ba);
+                        load_row(4, 1, bb);
+                        mac(false, xa, ba, Q1);
+                        mac(false, xb, bb, Q1);
+                    }
+                    fold(S0, Q);
+                    fold(S1, Q1);
+                }
+            }
+        };
+        poly_pass(std::integral_constant<int, 0>{});
+        poly_pass(std::integral_constant<int, 1>{});
+        fft_inv_wave_x2(S0, S1, s_tw, scr, lane);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int j = lane + 64 * r;
+            d2 tw_ = s_twist[j];
+            d2 y0 = cmulc(S0[r], tw_), y1 = cmulc(S1[r], tw_); // (1/512) * 2^-32 is in the key image
+            acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round_scaled(y0.x));
+            acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round_scaled(y0.y));
+            acc[kN + j] = (int32_t)((uint32_t)acc[kN + j] + wrap_round_scaled(y1.x));
+            acc[kN + j + kNH] = (int32_t)((uint32_t)acc[kN + j + kNH] + wrap_round_scaled(y1.y));
+        }
+        wave_lds_fence();
+    }
+    // tLweExtractLweSample, index 0
+    int32_t *u = A.u + (size_t)job * (kN + 1);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        int j = lane + 64 * r;
+        u[j] = j == 0 ? acc[0] : (int32_t)(0u - (uint32_t)acc[kN - j]);
+    }
+    if (lane == 0) u[kN] = acc[kN];
 }
 
 // =================================================================================================
