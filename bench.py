@@ -62,6 +62,12 @@ def main():
                     help="gloo = rehearsal of the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything else that libraries print there (RCCL's
+    # version banner, for one) is sent to stderr by pointing fd 1 at fd 2 until the result is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import eoc_tfhe_amd as eoc
 
@@ -80,7 +86,8 @@ def main():
     elif local_rank >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # EOC_BENCH_FORCE_DIST=1 runs the collective code path with a single rank too (RCCL smoke on a 1-GPU box)
+    if world > 1 or (os.environ.get("EOC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -278,7 +285,8 @@ def main():
                 eoc.gate_batch(op, c0, c1)
             res["pcie_inclusive_gates_per_s"] = round(3 * G / (time.perf_counter() - t0), 1)
             eoc.gpu_shutdown()
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist:
         dist.barrier()
         dist.destroy_process_group()
