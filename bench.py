@@ -178,6 +178,11 @@ def main():
                                 np.where(mops == eoc.OPS["XOR"], mb[0] ^ mb[1], np.where(mb[0] == 1, mb[1], mb[2])))
                 return bool(np.array_equal(sk.decrypt_bits(mout.cpu().numpy()), want))
 
+    # pre-flight (set-up, untimed, not one of the W warm-up steps): the key images just built/received are
+    # exercised twice so that a bad broadcast or key load fails here, before anything is measured
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
