@@ -66,3 +66,181 @@ def string_equal(nbytes=32):
     out = nxt
     gates.append(Gate(OPS["NOT"], level[0], -1, -1, out))
     return gates, nxt + 1, x, y, out
+
+
+# ---- more word-level circuits (comparison / min / max) ------------------------------
+
+def less_than(nbits=8):
+    """unsigned a < b, LSB first: lt_0 = (not a_0) and b_0; lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i).
+    1 + 3 (nbits - 1) bootstraps (XNOR = 1, MUX = 2).  Returns (gates, n_wires, a_wires, b_wires, out_wire)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    nxt = 2 * nbits
+    gates = [Gate(OPS["ANDNY"], a[0], b[0], -1, nxt)]
+    lt = nxt
+    nxt += 1
+    for i in range(1, nbits):
+        eq, new = nxt, nxt + 1
+        nxt += 2
+        gates.append(Gate(OPS["XNOR"], a[i], b[i], -1, eq))
+        gates.append(Gate(OPS["MUX"], eq, lt, b[i], new))
+        lt = new
+    return gates, nxt, a, b, lt
+
+
+def min_max(nbits=8):
+    """(min(a, b), max(a, b)) of two unsigned words: one comparator, then a MUX per output bit.
+    Returns (gates, n_wires, a_wires, b_wires, min_wires, max_wires)."""
+    gates, nxt, a, b, lt = less_than(nbits)
+    mn = list(range(nxt, nxt + nbits))
+    mx = list(range(nxt + nbits, nxt + 2 * nbits))
+    for i in range(nbits):
+        gates.append(Gate(OPS["MUX"], lt, a[i], b[i], mn[i]))
+        gates.append(Gate(OPS["MUX"], lt, b[i], a[i], mx[i]))
+    return gates, nxt + 2 * nbits, a, b, mn, mx
+
+
+# ---- plaintext semantics and netlist rewriting -----------------------------------------------------
+
+_NAMES = {v: k for k, v in OPS.items()}
+_SEM2 = {
+    "NAND": lambda a, b: 1 - (a & b), "AND": lambda a, b: a & b, "OR": lambda a, b: a | b,
+    "NOR": lambda a, b: 1 - (a | b), "XOR": lambda a, b: a ^ b, "XNOR": lambda a, b: 1 - (a ^ b),
+    "ANDNY": lambda a, b: (1 - a) & b, "ANDYN": lambda a, b: a & (1 - b),
+    "ORNY": lambda a, b: (1 - a) | b, "ORYN": lambda a, b: a | (1 - b),
+}
+
+
+def evaluate_plain(gates, wires):
+    """Run a netlist on plaintext bits: wires is an integer array [n_wires][instances] (modified copy is
+    returned).  The truth tables are those of the boots* gates."""
+    import numpy as np
+    w = np.array(wires, dtype=np.uint8, copy=True)
+    for g in gates:
+        name = _NAMES[g.op]
+        if name == "NOT":
+            w[g.out] = 1 - w[g.in0]
+        elif name == "COPY":
+            w[g.out] = w[g.in0]
+        elif name == "MUX":
+            w[g.out] = np.where(w[g.in0] == 1, w[g.in1], w[g.in2])
+        else:
+            w[g.out] = _SEM2[name](w[g.in0], w[g.in1])
+    return w
+
+
+def _table(name, n0=0, n1=0):
+    f = _SEM2[name]
+    return tuple(f(a ^ n0, b ^ n1) for a in (0, 1) for b in (0, 1))
+
+
+_BY_TABLE = {_table(k): k for k in _SEM2}
+
+
+def _check_ssa(gates):
+    written = set()
+    for g in gates:
+        if g.out in written:
+            raise ValueError("netlist rewriting needs single-assignment wires (wire %d is written twice)" % g.out)
+        for i in (g.in0, g.in1, g.in2):
+            if i >= 0 and i == g.out:
+                raise ValueError("gate reads its own output wire %d" % g.out)
+        written.add(g.out)
+    for k, g in enumerate(gates):
+        for i in (g.in0, g.in1, g.in2):
+            if i >= 0 and i in written and not any(h.out == i for h in gates[:k]):
+                raise ValueError("wire %d is read before it is written" % i)
+
+
+def _uses(gates):
+    u = {}
+    for g in gates:
+        for i in (g.in0, g.in1, g.in2):
+            if i >= 0:
+                u[i] = u.get(i, 0) + 1
+    return u
+
+
+def _drop_dead(gates, keep):
+    keep = set(keep)
+    while True:
+        u = _uses(gates)
+        live = [g for g in gates if g.out in keep or u.get(g.out, 0) > 0]
+        if len(live) == len(gates):
+            return live
+        gates = live
+
+
+def fold_nots(gates, outputs):
+    """NOT is free, but a NOT in front of a bootstrapped gate is unnecessary altogether: the ten two-input
+    boots* gates are closed under input negation (AND with a negated first input IS bootsANDNY, ...), a negated
+    MUX selector swaps the branches, NOT(NOT x) is a COPY.  `outputs` are the wires the caller reads; NOT gates
+    nobody reads afterwards are dropped.  Single-assignment netlists only."""
+    _check_ssa(gates)
+    src = {g.out: g for g in gates}
+
+    def strip(wire):
+        neg = 0
+        while wire in src and _NAMES[src[wire].op] == "NOT":
+            wire, neg = src[wire].in0, neg ^ 1
+        return wire, neg
+
+    out = []
+    for g in gates:
+        name = _NAMES[g.op]
+        if name in _SEM2:
+            (i0, n0), (i1, n1) = strip(g.in0), strip(g.in1)
+            out.append(Gate(OPS[_BY_TABLE[_table(name, n0, n1)]], i0, i1, -1, g.out))
+        elif name == "MUX":
+            (s, ns) = strip(g.in0)
+            b, c = (g.in2, g.in1) if ns else (g.in1, g.in2)
+            out.append(Gate(g.op, s, b, c, g.out))
+        elif name == "NOT":
+            i0, n0 = strip(g.in0)
+            out.append(Gate(OPS["COPY"] if n0 else OPS["NOT"], i0, -1, -1, g.out))
+        else:
+            out.append(Gate(g.op, g.in0, g.in1, g.in2, g.out))
+    return _drop_dead(out, outputs)
+
+
+def fuse_mux(gates, outputs):
+    """OR(AND(s, b), ANDNY(s, c)) with single-use inner wires is bootsMUX(s, b, c): 2 blind rotations and
+    one key switch instead of 3 + 3.  Run fold_nots first so that AND(NOT s, c) has become
+    ANDNY(s, c).  Single-assignment netlists only."""
+    _check_ssa(gates)
+    src = {g.out: g for g in gates}
+    uses = _uses(gates)
+    keep = set(outputs)
+
+    def as_sel(g):
+        """(selector, data, polarity) for a gate computing sel&data (polarity 1) or (not sel)&data (0)"""
+        name = _NAMES[g.op]
+        if name == "AND":
+            return [(g.in0, g.in1, 1), (g.in1, g.in0, 1)]
+        if name == "ANDNY":
+            return [(g.in0, g.in1, 0)]
+        if name == "ANDYN":
+            return [(g.in1, g.in0, 0)]
+        return []
+
+    out = []
+    for g in gates:
+        done = False
+        if _NAMES[g.op] == "OR" and g.in0 in src and g.in1 in src:
+            x, y = src[g.in0], src[g.in1]
+            inner_ok = all(uses.get(t.out, 0) == 1 and t.out not in keep for t in (x, y))
+            if inner_ok:
+                for (s0, d0, p0) in as_sel(x):
+                    for (s1, d1, p1) in as_sel(y):
+                        if not done and s0 == s1 and p0 != p1:
+                            b, c = (d0, d1) if p0 else (d1, d0)
+                            out.append(Gate(OPS["MUX"], s0, b, c, g.out))
+                            done = True
+        if not done:
+            out.append(Gate(g.op, g.in0, g.in1, g.in2, g.out))
+    return _drop_dead(out, outputs)
+
+
+def optimize(gates, outputs):
+    """fold_nots, then fuse_mux; returns the rewritten netlist (same wire numbering, fewer gates)."""
+    return fuse_mux(fold_nots(gates, outputs), outputs)

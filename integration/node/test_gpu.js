@@ -15,6 +15,14 @@ assert.strictEqual(tfhe.decryptBit(tfhe.not(e[1], ''), ''), 0);
 const enc = (v, n) => [...Array(n).keys()].map(i => tfhe.encryptBit((v >> i) & 1, ''));
 const S = tfhe.addBits(enc(9, 4), enc(5, 4), '');
 assert.strictEqual(S.reduce((acc, c, i) => acc | (tfhe.decryptBit(c, '') << i), 0), 14);
+// 3-bit comparison / min / max with the string API
+const val = cs => cs.reduce((acc, c, i) => acc | (tfhe.decryptBit(c, '') << i), 0);
+for (const [x, y] of [[5, 3], [2, 6], [4, 4]]) {
+  assert.strictEqual(tfhe.decryptBit(tfhe.lessThanBits(enc(x, 3), enc(y, 3), ''), ''), x < y ? 1 : 0);
+}
+const mm = tfhe.minMaxBits(enc(5, 3), enc(3, 3), '');
+assert.strictEqual(val(mm.min), 3);
+assert.strictEqual(val(mm.max), 5);
 // batched: 2048 NANDs and a 16-byte string equality through raw buffers
 const N = 2048, bits0 = Buffer.alloc(N), bits1 = Buffer.alloc(N);
 for (let i = 0; i < N; i++) { bits0[i] = (i * 7 + 3) & 1; bits1[i] = (i >> 3) & 1; }

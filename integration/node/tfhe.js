@@ -59,4 +59,16 @@ Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1]
   }
   return B.gateBatch(11 /* NOT */, level, null, null);
 };
+// unsigned comparison and min/max over bit-sliced ciphertext arrays (LSB first), string API:
+// lt_0 = (not a_0) and b_0 -- written NOT + AND here; the batch/circuit layer uses bootsANDNY directly --
+// lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i)
+Tfhe.lessThanBits = (A, Bs, pk) => {
+  let lt = Tfhe.and(Tfhe.not(A[0], pk), Bs[0], pk);
+  for (let i = 1; i < A.length; i++) lt = Tfhe.mux(Tfhe.xnor(A[i], Bs[i], pk), lt, Bs[i], pk);
+  return lt;
+};
+Tfhe.minMaxBits = (A, Bs, pk) => {
+  const lt = Tfhe.lessThanBits(A, Bs, pk);
+  return { min: A.map((a, i) => Tfhe.mux(lt, a, Bs[i], pk)), max: A.map((a, i) => Tfhe.mux(lt, Bs[i], a, pk)) };
+};
 module.exports = Tfhe;

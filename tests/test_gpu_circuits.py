@@ -223,3 +223,47 @@ def test_random_netlists_bit_exact(eoc, seed):
         assert np.array_equal(eoc.circuit_run(gates, wires.copy(), S), want)
     finally:
         eoc.gpu_shutdown()
+
+
+def test_min_max_4bit_bit_exact_and_optimised_select(eoc):
+    """8f3: comparator + word select.  min_max (XNOR/MUX chain) equals the oracle bit for bit; the same select
+    written the long way (NOT, AND, AND, OR per bit) and rewritten by circuits.optimize (-> one MUX per bit)
+    decrypts to the same words with a third fewer bootstraps."""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng, orc = _setup(eoc, 0, 9, 18)
+    nb, S = 4, 8
+    rng = np.random.default_rng(8)
+    A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+    A[0], B[0] = 7, 7                                         # a tie
+    gates, n_wires, aw, bw, mn, mx = circuits.min_max(nb)
+    wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+    for i in range(nb):
+        wires[aw[i]] = sk.encrypt_bits((A >> i) & 1, 500 + i, 0)
+        wires[bw[i]] = sk.encrypt_bits((B >> i) & 1, 520 + i, 0)
+    got = eoc_run(eoc, eng, gates, wires, n_wires, S)
+    want = _oracle_run(orc, gates, wires)
+    for w in mn + mx:
+        assert np.array_equal(got[w], want[w]), w
+    val = lambda ws: sum(sk.decrypt_bits(got[w]).astype(np.int64) << i for i, w in enumerate(ws))
+    assert np.array_equal(val(mn), np.minimum(A, B)) and np.array_equal(val(mx), np.maximum(A, B))
+
+    # long-form select on the comparator's output, before and after rewriting
+    lt_gates, nxt, a2, b2, lt = circuits.less_than(nb)
+    ns = nxt; nxt += 1
+    long_form, outs = list(lt_gates) + [eoc.Gate(eoc.OPS["NOT"], lt, -1, -1, ns)], []
+    for i in range(nb):
+        t0, t1, o = nxt, nxt + 1, nxt + 2
+        nxt += 3
+        long_form += [eoc.Gate(eoc.OPS["AND"], lt, a2[i], -1, t0), eoc.Gate(eoc.OPS["AND"], ns, b2[i], -1, t1),
+                      eoc.Gate(eoc.OPS["OR"], t0, t1, -1, o)]
+        outs.append(o)
+    opt = circuits.optimize(long_form, outs)
+    assert eoc.circuit_bootstraps(opt) == eoc.circuit_bootstraps(lt_gates) + 2 * nb
+    assert eoc.circuit_bootstraps(long_form) == eoc.circuit_bootstraps(lt_gates) + 3 * nb
+    wires2 = np.zeros((nxt, S, p.n + 1), np.int32)
+    wires2[: 2 * nb] = wires[: 2 * nb]
+    g1 = eoc_run(eoc, eng, long_form, wires2, nxt, S)
+    g2 = eoc_run(eoc, eng, opt, wires2, nxt, S)
+    for g in (g1, g2):
+        v = sum(sk.decrypt_bits(g[w]).astype(np.int64) << i for i, w in enumerate(outs))
+        assert np.array_equal(v, np.minimum(A, B))
