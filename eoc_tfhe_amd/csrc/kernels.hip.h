@@ -146,43 +146,47 @@ __device__ __forceinline__ void fwd_pass0(d2 (&x)[8])
     ct_w(x[4], x[5], wc); // W[64]
     ct_w(x[6], x[7], wd); // W[192]
 }
-__device__ __forceinline__ void fwd_pass1(d2 (&x)[8], const d2 *tw, int lane)
+// twiddle sets of the two table-driven passes: 7 per lane each.  Loading them is separate from using them so that
+// the skewed multi-transform schedules can issue the loads EARLY: one wave's LDS operations complete in issue
+// order, so a twiddle read issued after another transform's transpose would wait for that whole round trip.
+__device__ __forceinline__ void fwd_tw1_load(d2 (&t)[7], const d2 *tw, int lane)
 { // stages 3,4,5 (bits 5,4,3): twiddles depend on lane >> 3 (and the upper register bits)
-    const d2 *t = tw + kTwF1 + (lane >> 3);
-    d2 w0 = t[0 * 8];
-    ct_w(x[0], x[4], w0);
-    ct_w(x[1], x[5], w0);
-    ct_w(x[2], x[6], w0);
-    ct_w(x[3], x[7], w0);
-    d2 w1 = t[1 * 8], w2 = t[2 * 8];
-    ct_w(x[0], x[2], w1);
-    ct_w(x[1], x[3], w1);
-    ct_w(x[4], x[6], w2);
-    ct_w(x[5], x[7], w2);
-    d2 w3 = t[3 * 8], w4 = t[4 * 8], w5 = t[5 * 8], w6 = t[6 * 8];
-    ct_w(x[0], x[1], w3);
-    ct_w(x[2], x[3], w4);
-    ct_w(x[4], x[5], w5);
-    ct_w(x[6], x[7], w6);
+    const d2 *q = tw + kTwF1 + (lane >> 3);
+#pragma unroll
+    for (int k = 0; k < 7; k++) t[k] = q[k * 8];
+}
+__device__ __forceinline__ void fwd_tw2_load(d2 (&t)[7], const d2 *tw, int lane)
+{ // stages 6,7,8 (bits 2,1,0): twiddles depend on the lane (and the upper register bits)
+    const d2 *q = tw + kTwF2 + lane;
+#pragma unroll
+    for (int k = 0; k < 7; k++) t[k] = q[k * 64];
+}
+__device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[7])
+{ // three radix-2 stages on the 8 register points with the 1 + 2 + 4 twiddles of t[]
+    ct_w(x[0], x[4], t[0]);
+    ct_w(x[1], x[5], t[0]);
+    ct_w(x[2], x[6], t[0]);
+    ct_w(x[3], x[7], t[0]);
+    ct_w(x[0], x[2], t[1]);
+    ct_w(x[1], x[3], t[1]);
+    ct_w(x[4], x[6], t[2]);
+    ct_w(x[5], x[7], t[2]);
+    ct_w(x[0], x[1], t[3]);
+    ct_w(x[2], x[3], t[4]);
+    ct_w(x[4], x[5], t[5]);
+    ct_w(x[6], x[7], t[6]);
+}
+__device__ __forceinline__ void fwd_pass1(d2 (&x)[8], const d2 *tw, int lane)
+{
+    d2 t[7];
+    fwd_tw1_load(t, tw, lane);
+    fwd_pass12(x, t);
 }
 __device__ __forceinline__ void fwd_pass2(d2 (&x)[8], const d2 *tw, int lane)
-{ // stages 6,7,8 (bits 2,1,0): twiddles depend on the lane (and the upper register bits)
-    const d2 *t = tw + kTwF2 + lane;
-    d2 w0 = t[0 * 64];
-    ct_w(x[0], x[4], w0);
-    ct_w(x[1], x[5], w0);
-    ct_w(x[2], x[6], w0);
-    ct_w(x[3], x[7], w0);
-    d2 w1 = t[1 * 64], w2 = t[2 * 64];
-    ct_w(x[0], x[2], w1);
-    ct_w(x[1], x[3], w1);
-    ct_w(x[4], x[6], w2);
-    ct_w(x[5], x[7], w2);
-    d2 w3 = t[3 * 64], w4 = t[4 * 64], w5 = t[5 * 64], w6 = t[6 * 64];
-    ct_w(x[0], x[1], w3);
-    ct_w(x[2], x[3], w4);
-    ct_w(x[4], x[5], w5);
-    ct_w(x[6], x[7], w6);
+{
+    d2 t[7];
+    fwd_tw2_load(t, tw, lane);
+    fwd_pass12(x, t);
 }
 // transposes: write in the source layout, read in the destination layout.  One wave's LDS operations
 // execute in issue order, so a later write to the same scratch cannot overtake an earlier read.
@@ -234,34 +238,115 @@ __device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
 
 // Two independent forward transforms of one wave on ONE scratch, skewed so that each transform's
 // LDS round trip runs under the other's register pass (same arithmetic as two fft_fwd_wave calls).
-__device__ __forceinline__ void fft_fwd_wave_x2_head(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+#ifndef EOC_TW_HOIST
+#define EOC_TW_HOIST 0
+#endif
+// EOC_SCHED_PIN: scheduling barriers at the phase boundaries of the skewed schedule (the compiler otherwise
+// interleaves neighbouring phases and places its LDS waits inside register passes)
+#ifdef EOC_SCHED_PIN
+#define EOC_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define EOC_SB() do { } while (0)
+#endif
+template <class F>
+__device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane, F before_last)
 {
+#if EOC_TW_HOIST
+    d2 t1[7], t2[7];
     fwd_pass0(xa);
+    EOC_SB();
     t01_write(xa, scr, lane);
     t01_read(xa, scr, lane);
+    EOC_SB();
+    fwd_tw1_load(t1, tw, lane); // behind a's transpose only; shared by both transforms
+    wave_lds_fence();
+    EOC_SB();
     fwd_pass0(xb); // under a's round trip
+    EOC_SB();
     t01_write(xb, scr, lane);
     t01_read(xb, scr, lane);
-    fwd_pass1(xa, tw, lane); // under b's round trip
+    EOC_SB();
+    fwd_pass12(xa, t1); // under b's round trip: everything it needs was issued before b's transpose
+    EOC_SB();
     t12_write(xa, scr, lane);
     t12_read(xa, scr, lane);
-}
-__device__ __forceinline__ void fft_fwd_wave_x2_tail(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
-{
-    fwd_pass1(xb, tw, lane);
+    EOC_SB();
+    fwd_tw2_load(t2, tw, lane);
+    wave_lds_fence();
+    EOC_SB();
+    fwd_pass12(xb, t1);
+    EOC_SB();
     t12_write(xb, scr, lane);
     t12_read(xb, scr, lane);
+    EOC_SB();
+    before_last();
+    fwd_pass12(xa, t2); // under b's second round trip
+    EOC_SB();
+    fwd_pass12(xb, t2);
+    EOC_SB();
+#else
+    fwd_pass0(xa);
+    EOC_SB();
+    t01_write(xa, scr, lane);
+    t01_read(xa, scr, lane);
+    EOC_SB();
+    fwd_pass0(xb); // under a's round trip
+    EOC_SB();
+    t01_write(xb, scr, lane);
+    t01_read(xb, scr, lane);
+    EOC_SB();
+    fwd_pass1(xa, tw, lane); // under b's round trip
+    EOC_SB();
+    t12_write(xa, scr, lane);
+    t12_read(xa, scr, lane);
+    EOC_SB();
+    fwd_pass1(xb, tw, lane);
+    EOC_SB();
+    t12_write(xb, scr, lane);
+    t12_read(xb, scr, lane);
+    EOC_SB();
+    before_last();
     fwd_pass2(xa, tw, lane);
+    EOC_SB();
     fwd_pass2(xb, tw, lane);
+    EOC_SB();
+#endif
 }
 __device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
 {
-    fft_fwd_wave_x2_head(xa, xb, tw, scr, lane);
-    fft_fwd_wave_x2_tail(xa, xb, tw, scr, lane);
+    fft_fwd_wave_x2(xa, xb, tw, scr, lane, []() {});
 }
 // three transforms on one scratch, same skew (gadget length 3: Set B)
 __device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&xc)[8], const d2 *tw, d2 *scr, int lane)
 {
+#if EOC_TW_HOIST
+    d2 t1[7], t2[7];
+    fwd_pass0(xa);
+    t01_write(xa, scr, lane);
+    t01_read(xa, scr, lane);
+    fwd_tw1_load(t1, tw, lane);
+    wave_lds_fence();
+    fwd_pass0(xb);
+    t01_write(xb, scr, lane);
+    t01_read(xb, scr, lane);
+    fwd_pass0(xc);
+    t01_write(xc, scr, lane);
+    t01_read(xc, scr, lane);
+    fwd_pass12(xa, t1);
+    t12_write(xa, scr, lane);
+    t12_read(xa, scr, lane);
+    fwd_tw2_load(t2, tw, lane);
+    wave_lds_fence();
+    fwd_pass12(xb, t1);
+    t12_write(xb, scr, lane);
+    t12_read(xb, scr, lane);
+    fwd_pass12(xc, t1);
+    t12_write(xc, scr, lane);
+    t12_read(xc, scr, lane);
+    fwd_pass12(xa, t2);
+    fwd_pass12(xb, t2);
+    fwd_pass12(xc, t2);
+#else
     fwd_pass0(xa);
     t01_write(xa, scr, lane);
     t01_read(xa, scr, lane);
@@ -283,6 +368,7 @@ __device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&x
     fwd_pass2(xa, tw, lane);
     fwd_pass2(xb, tw, lane);
     fwd_pass2(xc, tw, lane);
+#endif
 }
 
 // ---- inverse transform, in pieces: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time,
@@ -558,17 +644,28 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
     d.out[i] = (int32_t)(d.op == OP_NOT ? 0u - v : v);
 }
 
-// Tuning switches kept from measured experiments (tools/ablate.sh, 1024 gates, Set A):
+// Tuning switches kept from measured experiments (tools/ablate.sh, tools/variants.sh; 1024 gates, Set A):
 //   EOC_ACC_REGS  register copy of the accumulator next to the LDS copy the rotation reads: -1.7 %  (on)
 //   EOC_LATE_BK   load all key rows after the transforms: 178 VGPRs but +12 % time                  (off)
-//   EOC_BK_PREFETCH 1/2  partner rows issued mid-transform / at the start: no gain, spills          (0)
+//   EOC_BK_PREFETCH 2    partner rows issued at the start (1, mid-transform, was removed): no gain, spills (0)
+#ifndef EOC_ACC_REGS
 #define EOC_ACC_REGS 1
+#endif
 //   EOC_L3_TRIPLE gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 %    (on)
 #define EOC_L3_TRIPLE 1
 //   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)
 #define EOC_THEIRS_FIRST 1
 //   (requesting the inverse transform's twiddles / un-twist factors one pass early was measured too: 0 %, removed)
 //   EOC_STAGGER_MODE     de-phasing the workgroups that share a CU: 0 %                                (off)
+//   EOC_BK_PREFETCH 3    one own row issued before the forward transforms' last pass: 0 % (3.756 vs 3.766 ms)  (0)
+//   EOC_TW_HOIST  forward twiddle sets loaded once per skewed pair/triple, ahead of the other transform's
+//                 transpose (7-14 fewer ds_read_b128 per step): +1.5 % (l = 2) / +9.7 % (l = 3) -- the 28 extra
+//                 live registers spill, and every scratch reload is an s_waitcnt vmcnt(0) that also waits for
+//                 the key rows in flight                                                                  (off)
+//   EOC_SCHED_PIN sched_barriers that force the hand-written skew order: +12 %.  The compiler's own order
+//                 (both register passes of a pair back to back = 16 independent FMA chains, then both
+//                 transposes) is faster than strict skew: FP64 dependent-issue latency (about 11 cycles)
+//                 matters more than the LDS round trip, which the second wave on the SIMD covers         (off)
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -686,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef EOC_ACC_REGS
+#if EOC_ACC_REGS
     uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8: low half)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -709,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             uint32_t v1 = (uint32_t)acc[i1 & (kN - 1)];
             v0 = (i0 & kN) ? 0u - v0 : v0;
             v1 = (i1 & kN) ? 0u - v1 : v1;
-#ifdef EOC_ACC_REGS
+#if EOC_ACC_REGS
             dlo[r] = v0 - racc[r] + offset;
             dhi[r] = v1 - racc[8 + r] + offset;
 #else
@@ -778,14 +875,11 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             make_x(p, xa);
             make_x(p + 1, xb);
             EOC_STAMP(1);
-#if EOC_BK_PREFETCH == 1
-            d2 ca[8], cb[8];
-            fft_fwd_wave_x2_head(xa, xb, s_tw, scr, lane);
-            load_row(p, 1 - h, ca);
-            load_row(p + 1, 1 - h, cb);
-            fft_fwd_wave_x2_tail(xa, xb, s_tw, scr, lane);
+#if EOC_BK_PREFETCH == 3
+            d2 ca[8];
+            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane, [&]() __attribute__((always_inline)) { load_row(p, h, ca); });
 #else
-            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
+            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane, []() {});
 #endif
             EOC_STAMP(2);
 #ifdef EOC_LATE_BK
@@ -798,11 +892,17 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 // accumulation, which then runs while that store lands and the partner catches up
                 mac(true, xa, ba, theirs);
                 mac(false, xb, bb, theirs);
+#if EOC_BK_PREFETCH != 3
                 load_row(p, h, ba);
+#endif
                 load_row(p + 1, h, bb);
 #pragma unroll
                 for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+#if EOC_BK_PREFETCH == 3
+                mac(true, xa, ca, mine);
+#else
                 mac(true, xa, ba, mine);
+#endif
                 mac(false, xb, bb, mine);
                 EOC_STAMP(3);
                 return;
@@ -810,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #endif
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
-#if EOC_BK_PREFETCH == 0
+#if EOC_BK_PREFETCH != 2
             // the partner polynomial's rows re-use the same registers
             load_row(p, 1 - h, ba);
             load_row(p + 1, 1 - h, bb);
@@ -891,7 +991,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
             d2 y = cmulc(x[r], s_twist[j]); // (1/512) * 2^-32 is in the key image
-#ifdef EOC_ACC_REGS
+#if EOC_ACC_REGS
             racc[r] += wrap_round_scaled(y.x); // the key image carries 2^-41 = (1/512) * 2^-32
             racc[8 + r] += wrap_round_scaled(y.y);
             acc[j] = (int32_t)racc[r];
