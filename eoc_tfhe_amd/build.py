@@ -45,7 +45,8 @@ def build_stamps(verbose=False):
     eng_obj = os.path.join(OBJ, "engine_stamps.o")
     host_obj = os.path.join(OBJ, "host.o")
     leg_obj = os.path.join(OBJ, "legacy.o")
-    _run([HIPCC, *HIP_FLAGS, "-DEOC_STAMPS", "-c", os.path.join(CSRC, "engine.hip"), "-o", eng_obj], verbose)
+    extra = os.environ.get("EOC_EXTRA_HIP_FLAGS", "").split()
+    _run([HIPCC, *HIP_FLAGS, "-DEOC_STAMPS", *extra, "-c", os.path.join(CSRC, "engine.hip"), "-o", eng_obj], verbose)
     if not os.path.exists(host_obj):
         _run([GXX, *CXX_FLAGS, "-c", os.path.join(CSRC, "host.cpp"), "-o", host_obj], verbose)
     if not os.path.exists(leg_obj):

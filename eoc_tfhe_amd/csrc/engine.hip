@@ -46,6 +46,8 @@ struct eoc_engine {
     int32_t *d_u = nullptr;
     uint32_t *d_ubarT = nullptr; // [N][ws_jobs] key-switch operand, transposed
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
+    int num_cus = 256;
+    int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
     int br_mode = 0;                        // 0 auto, 1 pair form always, 2 throughput form always
     uint32_t br_t_threshold = 0xFFFFFFFFu;  // jobs from which the throughput form is used (set after measuring)
     int32_t *d_mixed = nullptr;             // gather/scatter space of mixed batches: 4 row arrays + perm
@@ -183,6 +185,11 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
     if (rc) {
         delete e;
         return rc;
+    }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->num_cus = cus;
+        if (const char *s = getenv("EOC_TFHE_PRIO_DUTY")) e->prio_duty_override = atoi(s);
     }
     // blind-rotate kernels use > 64 KiB of dynamic LDS
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
@@ -411,6 +418,9 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     a.bara_stride = e->bara_stride;
     a.mu = (int32_t)(1u << 29);
     a.stamps = e->d_stamps;
+    // priority alternation pays only when every workgroup is resident from the start (two per CU)
+    a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
+                  : ((njobs + 1) / 2 <= 2u * (uint32_t)e->num_cus ? EOC_PRIO_DUTY : -1);
     dim3 grid((njobs + 1) / 2), block(256);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
     // large launches take the one-wave-per-ciphertext form (no pair exchange, skewed inverse pair); the

@@ -238,115 +238,26 @@ __device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, 
 
 // Two independent forward transforms of one wave on ONE scratch, skewed so that each transform's
 // LDS round trip runs under the other's register pass (same arithmetic as two fft_fwd_wave calls).
-#ifndef EOC_TW_HOIST
-#define EOC_TW_HOIST 0
-#endif
-// EOC_SCHED_PIN: scheduling barriers at the phase boundaries of the skewed schedule (the compiler otherwise
-// interleaves neighbouring phases and places its LDS waits inside register passes)
-#ifdef EOC_SCHED_PIN
-#define EOC_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define EOC_SB() do { } while (0)
-#endif
-template <class F>
-__device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane, F before_last)
-{
-#if EOC_TW_HOIST
-    d2 t1[7], t2[7];
-    fwd_pass0(xa);
-    EOC_SB();
-    t01_write(xa, scr, lane);
-    t01_read(xa, scr, lane);
-    EOC_SB();
-    fwd_tw1_load(t1, tw, lane); // behind a's transpose only; shared by both transforms
-    wave_lds_fence();
-    EOC_SB();
-    fwd_pass0(xb); // under a's round trip
-    EOC_SB();
-    t01_write(xb, scr, lane);
-    t01_read(xb, scr, lane);
-    EOC_SB();
-    fwd_pass12(xa, t1); // under b's round trip: everything it needs was issued before b's transpose
-    EOC_SB();
-    t12_write(xa, scr, lane);
-    t12_read(xa, scr, lane);
-    EOC_SB();
-    fwd_tw2_load(t2, tw, lane);
-    wave_lds_fence();
-    EOC_SB();
-    fwd_pass12(xb, t1);
-    EOC_SB();
-    t12_write(xb, scr, lane);
-    t12_read(xb, scr, lane);
-    EOC_SB();
-    before_last();
-    fwd_pass12(xa, t2); // under b's second round trip
-    EOC_SB();
-    fwd_pass12(xb, t2);
-    EOC_SB();
-#else
-    fwd_pass0(xa);
-    EOC_SB();
-    t01_write(xa, scr, lane);
-    t01_read(xa, scr, lane);
-    EOC_SB();
-    fwd_pass0(xb); // under a's round trip
-    EOC_SB();
-    t01_write(xb, scr, lane);
-    t01_read(xb, scr, lane);
-    EOC_SB();
-    fwd_pass1(xa, tw, lane); // under b's round trip
-    EOC_SB();
-    t12_write(xa, scr, lane);
-    t12_read(xa, scr, lane);
-    EOC_SB();
-    fwd_pass1(xb, tw, lane);
-    EOC_SB();
-    t12_write(xb, scr, lane);
-    t12_read(xb, scr, lane);
-    EOC_SB();
-    before_last();
-    fwd_pass2(xa, tw, lane);
-    EOC_SB();
-    fwd_pass2(xb, tw, lane);
-    EOC_SB();
-#endif
-}
 __device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
 {
-    fft_fwd_wave_x2(xa, xb, tw, scr, lane, []() {});
+    fwd_pass0(xa);
+    t01_write(xa, scr, lane);
+    t01_read(xa, scr, lane);
+    fwd_pass0(xb); // under a's round trip
+    t01_write(xb, scr, lane);
+    t01_read(xb, scr, lane);
+    fwd_pass1(xa, tw, lane); // under b's round trip
+    t12_write(xa, scr, lane);
+    t12_read(xa, scr, lane);
+    fwd_pass1(xb, tw, lane);
+    t12_write(xb, scr, lane);
+    t12_read(xb, scr, lane);
+    fwd_pass2(xa, tw, lane);
+    fwd_pass2(xb, tw, lane);
 }
 // three transforms on one scratch, same skew (gadget length 3: Set B)
 __device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&xc)[8], const d2 *tw, d2 *scr, int lane)
 {
-#if EOC_TW_HOIST
-    d2 t1[7], t2[7];
-    fwd_pass0(xa);
-    t01_write(xa, scr, lane);
-    t01_read(xa, scr, lane);
-    fwd_tw1_load(t1, tw, lane);
-    wave_lds_fence();
-    fwd_pass0(xb);
-    t01_write(xb, scr, lane);
-    t01_read(xb, scr, lane);
-    fwd_pass0(xc);
-    t01_write(xc, scr, lane);
-    t01_read(xc, scr, lane);
-    fwd_pass12(xa, t1);
-    t12_write(xa, scr, lane);
-    t12_read(xa, scr, lane);
-    fwd_tw2_load(t2, tw, lane);
-    wave_lds_fence();
-    fwd_pass12(xb, t1);
-    t12_write(xb, scr, lane);
-    t12_read(xb, scr, lane);
-    fwd_pass12(xc, t1);
-    t12_write(xc, scr, lane);
-    t12_read(xc, scr, lane);
-    fwd_pass12(xa, t2);
-    fwd_pass12(xb, t2);
-    fwd_pass12(xc, t2);
-#else
     fwd_pass0(xa);
     t01_write(xa, scr, lane);
     t01_read(xa, scr, lane);
@@ -368,7 +279,6 @@ __device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&x
     fwd_pass2(xa, tw, lane);
     fwd_pass2(xb, tw, lane);
     fwd_pass2(xc, tw, lane);
-#endif
 }
 
 // ---- inverse transform, in pieces: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time,
@@ -651,21 +561,38 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #ifndef EOC_ACC_REGS
 #define EOC_ACC_REGS 1
 #endif
+//   (touching a slice of the NEXT step's key rows one step ahead, to pre-load each XCD's L2: 0 %, removed -- the
+//    lockstep penalty of a chip-filling launch is the arbiter's unfairness below, not L2 misses)
+//   EOC_PRIO_ALT  wave-priority alternation between the two waves sharing a SIMD (see the loop): steps per phase
+//                 (power of two; 0 compiles it out).  Single-round launches: -10 % (l = 2) / -13 % (l = 3) at
+//                 EOC_PRIO_DUTY = 11..12 sixteenths and 1 step per phase (8 steps: -8 %, 16: -6 %); level 1, 2, 3 alike.
+//                 The host enables it per launch (BRArgs::prio_duty); launches of several rounds lose 4 % with it.
+#ifndef EOC_PRIO_ALT
+#define EOC_PRIO_ALT 1
+#endif
+#ifndef EOC_PRIO_DUTY
+#define EOC_PRIO_DUTY 12
+#endif
+#ifndef EOC_PRIO_HI
+#define EOC_PRIO_HI 1
+#endif
+//   (a feedback form -- waves publish their step counters by physical slot, the one behind takes the priority --
+//    gave -7 %, less than the fixed duty; a phase-dependent priority inside the step cost +6..20 %; both removed)
 //   EOC_L3_TRIPLE gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 %    (on)
 #define EOC_L3_TRIPLE 1
 //   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)
 #define EOC_THEIRS_FIRST 1
 //   (requesting the inverse transform's twiddles / un-twist factors one pass early was measured too: 0 %, removed)
 //   EOC_STAGGER_MODE     de-phasing the workgroups that share a CU: 0 %                                (off)
-//   EOC_BK_PREFETCH 3    one own row issued before the forward transforms' last pass: 0 % (3.756 vs 3.766 ms)  (0)
-//   EOC_TW_HOIST  forward twiddle sets loaded once per skewed pair/triple, ahead of the other transform's
+//   (one own key row issued before the forward transforms' last pass: 0 %, 3.756 vs 3.766 ms, removed)
+//   (removed) forward twiddle sets loaded once per skewed pair/triple, ahead of the other transform's
 //                 transpose (7-14 fewer ds_read_b128 per step): +1.5 % (l = 2) / +9.7 % (l = 3) -- the 28 extra
 //                 live registers spill, and every scratch reload is an s_waitcnt vmcnt(0) that also waits for
-//                 the key rows in flight                                                                  (off)
-//   EOC_SCHED_PIN sched_barriers that force the hand-written skew order: +12 %.  The compiler's own order
+//                 the key rows in flight
+//   (removed) sched_barriers that force the hand-written skew order: +12 %.  The compiler's own order
 //                 (both register passes of a pair back to back = 16 independent FMA chains, then both
 //                 transposes) is faster than strict skew: FP64 dependent-issue latency (about 11 cycles)
-//                 matters more than the LDS round trip, which the second wave on the SIMD covers         (off)
+//                 matters more than the LDS round trip, which the second wave on the SIMD covers
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -711,6 +638,7 @@ struct BRArgs {
     int n, Bgbit, bara_stride;
     int32_t mu;
     unsigned long long *stamps; // diagnostic build only: [waves][16] cycle sums per segment
+    int prio_duty;              // < 0: leave wave priorities alone; else see the loop (single-round launches)
 };
 
 constexpr int kBRLds = (kTwEntries + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
@@ -782,6 +710,9 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #ifdef EOC_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+    st_acc[12] = st_prev;                                          // loop entry time
+    st_acc[14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: CU / SE / SIMD / wave slot
+    st_acc[13] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
 #endif
 #if EOC_ACC_REGS
     uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8: low half)
@@ -791,8 +722,28 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         racc[8 + r] = (uint32_t)acc[lane + 64 * r + kNH];
     }
 #endif
+#if EOC_PRIO_ALT
+    const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
+#endif
     for (int i = 0; i < A.n; i++) {
         EOC_STAMP(15);
+#if EOC_PRIO_ALT
+        // The two waves that share a SIMD belong to different workgroups, and the issue arbiter favours the older
+        // one: in a launch that exactly fills the chip (1024 gates = 512 workgroups) the first half of the grid
+        // finishes at 0.82x and the second half at 1.19x of the mean, and the launch lasts as long as its slowest
+        // workgroup.  The two waves occupy different wave slots, so the slot parity tells them apart: the
+        // later-placed (odd) one holds the high priority A.prio_duty sixteenths of the steps, the other one the
+        // rest.  12/16 makes both halves finish together (-10 % on the launch).  Launches of several rounds are
+        // faster WITHOUT it (the arbiter's run-to-completion bias suits them: +4 %), so the host passes a
+        // negative duty there.
+        if (A.prio_duty >= 0 && (i & (EOC_PRIO_ALT - 1)) == 0) {
+            const bool first_part = ((i / EOC_PRIO_ALT) & 15) < A.prio_duty;
+            if (first_part == ((prio_slot & 1) != 0))
+                __builtin_amdgcn_s_setprio(EOC_PRIO_HI);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
         // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
         // zero update, which is what skipping the step (as libtfhe does) amounts to.
@@ -875,12 +826,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             make_x(p, xa);
             make_x(p + 1, xb);
             EOC_STAMP(1);
-#if EOC_BK_PREFETCH == 3
-            d2 ca[8];
-            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane, [&]() __attribute__((always_inline)) { load_row(p, h, ca); });
-#else
-            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane, []() {});
-#endif
+            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
             EOC_STAMP(2);
 #ifdef EOC_LATE_BK
             load_row(p, h, ba);
@@ -892,17 +838,11 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 // accumulation, which then runs while that store lands and the partner catches up
                 mac(true, xa, ba, theirs);
                 mac(false, xb, bb, theirs);
-#if EOC_BK_PREFETCH != 3
                 load_row(p, h, ba);
-#endif
                 load_row(p + 1, h, bb);
 #pragma unroll
                 for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
-#if EOC_BK_PREFETCH == 3
-                mac(true, xa, ca, mine);
-#else
                 mac(true, xa, ba, mine);
-#endif
                 mac(false, xb, bb, mine);
                 EOC_STAMP(3);
                 return;
@@ -910,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #endif
             mac(p == 1, xa, ba, mine);
             mac(false, xb, bb, mine);
-#if EOC_BK_PREFETCH != 2
+#if EOC_BK_PREFETCH == 0
             // the partner polynomial's rows re-use the same registers
             load_row(p, 1 - h, ba);
             load_row(p + 1, 1 - h, bb);
@@ -1005,6 +945,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(9);
     }
 #ifdef EOC_STAMPS
+    st_acc[11] = __builtin_amdgcn_s_memtime(); // loop exit time
     if (A.stamps && lane == 0)
         for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * 4 + w) * 16 + k] = st_acc[k];
 #endif

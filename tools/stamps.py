@@ -35,8 +35,41 @@ assert L.eoc_dbg_stamps(eng.h, waves, buf.ctypes.data) == 0
 names = {0: "rotate-diff (acc reads)", 1: "BK loads issue + digits + twist", 2: "forward FFT", 3: "MAC (waits BK)",
          4: "xchg write", 5: "barrier A", 6: "xchg read + add", 7: "barrier B", 8: "inverse FFT",
          9: "untwist + round + acc update", 15: "loop top (bara load)"}
+meta = buf[:, 11:15].copy()
+buf[:, 11:15] = 0
 tot = buf.sum(axis=1).astype(np.float64)
 print(f"waves={waves} steps={p.n}  mean cycles/step/wave = {tot.mean() / p.n:.0f}")
 for k in sorted(names):
     v = buf[:, k].astype(np.float64)
     print(f"  [{k:2d}] {names[k]:34s} {v.mean() / p.n:9.1f} cyc/step  {100 * v.sum() / tot.sum():5.1f} %")
+
+# per-workgroup loop durations: a launch ends with its slowest workgroup
+dur = (meta[:, 0].astype(np.int64) - meta[:, 1].astype(np.int64)).astype(np.float64)   # exit - entry
+t0 = meta[:, 1].astype(np.int64)
+wg = dur.reshape(-1, 4).max(axis=1)
+start = (t0.reshape(-1, 4).min(axis=1) - t0.min()).astype(np.float64)
+end = start + wg
+print(f"workgroup loop duration [cycles]: min {wg.min():.0f}  mean {wg.mean():.0f}  max {wg.max():.0f}  (max/mean = {wg.max() / wg.mean():.3f})")
+print(f"loop entry spread: {start.max():.0f} cycles;  last exit at {end.max():.0f};  mean exit at {end.mean():.0f}")
+xcc = (meta[:, 2] & 0xF).reshape(-1, 4)[:, 0]
+hw = meta[:, 3].reshape(-1, 4)[:, 0]
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print(f"  XCC {x}: {m.sum():4d} workgroups  mean {wg[m].mean():.0f}  max {wg[m].max():.0f}  distinct (se,sh,cu) = {len(set(zip(se[m].tolist(), sh[m].tolist(), cu[m].tolist())))}")
+key = list(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+from collections import Counter
+cnt = Counter(key)
+print("workgroups per CU histogram:", sorted(Counter(cnt.values()).items()))
+pairs = {}
+for k, d in zip(key, wg.tolist()):
+    pairs.setdefault(k, []).append(d)
+two = np.array([sorted(v) for v in pairs.values() if len(v) == 2])
+if len(two):
+    print(f"per CU with two workgroups: faster mean {two[:, 0].mean():.0f}  slower mean {two[:, 1].mean():.0f}  "
+          f"ratio {(two[:, 1] / two[:, 0]).mean():.3f}")
+idx = np.arange(len(wg))
+print(f"first half of the grid mean {wg[idx < len(wg) // 2].mean():.0f}   second half mean {wg[idx >= len(wg) // 2].mean():.0f}")
+print("deciles:", " ".join(f"{q:.0f}" for q in np.percentile(wg, [0, 10, 25, 50, 75, 90, 100])))
