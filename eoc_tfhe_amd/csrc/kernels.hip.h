@@ -577,7 +577,8 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #define EOC_PRIO_HI 1
 #endif
 //   (a feedback form -- waves publish their step counters by physical slot, the one behind takes the priority --
-//    gave -7 %, less than the fixed duty; a phase-dependent priority inside the step cost +6..20 %; both removed)
+//    gave -7 % on a single round, less than the fixed duty, and as a tail balancer for launches of a few rounds
+//    -5 % at exactly 2 rounds, 0 % beyond 4 and on the circuit workloads, +5 % at 1.5 rounds; a phase-dependent priority inside the step cost +6..20 %; both removed)
 //   EOC_L3_TRIPLE gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 %    (on)
 #define EOC_L3_TRIPLE 1
 //   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU-box call that regenerates the evidence under profiles/: bench lines (A with cpu_baseline and the
+# PCIe-inclusive rate, B), rocprofv3 kernel-trace stats of the same command, and the PMC passes.
+# Usage (GPU box): bash tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>/...
+set -e
+TAG=${1:-final}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$TAG
+mkdir -p "$O"
+python3 bench.py --pcie > "$O/bench_A.json" 2> "$O/bench_A.err"
+echo "bench A done"
+python3 bench.py --pset B --no-cpu-baseline > "$O/bench_B.json" 2> "$O/bench_B.err"
+echo "bench B done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
+echo "trace done"
+cp "$O"/trace/*/*kernel_stats.csv "$O/kernel_stats.csv"
+bash tools/pmc_passes.sh "$O/pmc" > "$O/pmc_passes.log" 2>&1
+cp "$O/pmc/summary.txt" "$O/pmc_summary.txt"
+echo "pmc done"
+head -5 "$O/kernel_stats.csv"
+cat "$O/bench_A.json"
