@@ -118,6 +118,7 @@ def lib():
         "eoc_gate_batch_device": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, sz, vp]),
         "eoc_circuit_run_device": (C.c_int, [vp, vp, sz, vp, sz, sz, vp]),
         "eoc_circuit_bootstraps": (sz, [vp, sz]),
+        "eoc_netlist_optimize": (C.c_int64, [vp, sz, vp, sz, vp]),
         "eoc_dbg_fft_fwd_device": (C.c_int, [vp, vp, vp, sz, vp]),
         "eoc_dbg_fft_inv_device": (C.c_int, [vp, vp, vp, sz, vp]),
         "eoc_blind_rotate_device": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -419,6 +420,18 @@ class Engine:
 def circuit_bootstraps(gates):
     arr = (Gate * len(gates))(*gates)
     return lib().eoc_circuit_bootstraps(C.addressof(arr), len(gates))
+
+
+def netlist_optimize(gates, outputs):
+    """eoc_netlist_optimize: NOT folding, MUX fusion and dead-gate removal in the native library (the same
+    rewriting as circuits.optimize).  Raises EocError for netlists that are not single-assignment."""
+    arr = (Gate * max(1, len(gates)))(*gates)
+    out = (Gate * max(1, len(gates)))()
+    outs = (C.c_int32 * max(1, len(outputs)))(*outputs)
+    n = lib().eoc_netlist_optimize(C.addressof(arr), len(gates), C.addressof(outs), len(outputs), C.addressof(out))
+    if n < 0:
+        raise EocError(f"eoc_netlist_optimize failed ({n}): not a single-assignment netlist?")
+    return [Gate(out[k].op, out[k].in0, out[k].in1, out[k].in2, out[k].out) for k in range(n)]
 
 
 # ---- host-buffer batch API (global engine), numpy in / numpy out ----------------------------------

@@ -536,3 +536,160 @@ extern "C" int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int
     if (rc) return rc;
     return eoc_circuit_run(gates, n_gates, wires, n_wires, instances);
 }
+
+// ---- netlist rewriting (host side, no GPU): the native twin of eoc_tfhe_amd/circuits.py -------------------
+// NOT is free, but a NOT in front of a bootstrapped gate is unnecessary altogether: the ten two-input boots*
+// gates are closed under input negation (AND with a negated first input IS bootsANDNY, ...), a negated MUX
+// selector swaps the branches, NOT(NOT x) is a COPY; and OR(AND(s, b), ANDNY(s, c)) with single-use inner
+// wires is bootsMUX(s, b, c): 2 blind rotations + 1 key switch instead of 3 + 3.
+namespace {
+inline int sem2(int op, int a, int b)
+{
+    switch (op) {
+    case EOC_NAND: return 1 - (a & b);
+    case EOC_AND: return a & b;
+    case EOC_OR: return a | b;
+    case EOC_NOR: return 1 - (a | b);
+    case EOC_XOR: return a ^ b;
+    case EOC_XNOR: return 1 - (a ^ b);
+    case EOC_ANDNY: return (1 - a) & b;
+    case EOC_ANDYN: return a & (1 - b);
+    case EOC_ORNY: return (1 - a) | b;
+    default: return a | (1 - b); // EOC_ORYN
+    }
+}
+inline int table_of(int op, int n0, int n1)
+{
+    int t = 0;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) t = (t << 1) | sem2(op, a ^ n0, b ^ n1);
+    return t;
+}
+inline int op_with_negated_inputs(int op, int n0, int n1)
+{
+    const int want = table_of(op, n0, n1);
+    for (int o = EOC_NAND; o <= EOC_ORYN; o++)
+        if (table_of(o, 0, 0) == want) return o;
+    return -1; // unreachable: the family is closed under input negation
+}
+void drop_dead(std::vector<eoc_gate> &g, const std::vector<char> &keep, size_t n_wires)
+{
+    for (;;) {
+        std::vector<int> uses(n_wires, 0);
+        for (const eoc_gate &x : g)
+            for (int32_t i : {x.in0, x.in1, x.in2})
+                if (i >= 0) uses[i]++;
+        std::vector<eoc_gate> live;
+        for (const eoc_gate &x : g)
+            if (keep[x.out] || uses[x.out] > 0) live.push_back(x);
+        if (live.size() == g.size()) return;
+        g.swap(live);
+    }
+}
+} // namespace
+
+extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs,
+                                        size_t n_outputs, eoc_gate *gates_out)
+{
+    if ((!gates && n_gates) || (!outputs && n_outputs) || (!gates_out && n_gates)) return EOC_ERR_ARG;
+    size_t n_wires = 0;
+    for (size_t k = 0; k < n_gates; k++) {
+        const eoc_gate &g = gates[k];
+        if (g.op < EOC_NAND || g.op > EOC_COPY || g.out < 0 || g.in0 < 0) return EOC_ERR_ARG;
+        if (g.op <= EOC_MUX && g.in1 < 0) return EOC_ERR_ARG;
+        if (g.op == EOC_MUX && g.in2 < 0) return EOC_ERR_ARG;
+        for (int32_t i : {g.in0, g.in1, g.in2, g.out}) n_wires = std::max(n_wires, (size_t)(i + 1));
+    }
+    for (size_t k = 0; k < n_outputs; k++) {
+        if (outputs[k] < 0) return EOC_ERR_ARG;
+        n_wires = std::max(n_wires, (size_t)outputs[k] + 1);
+    }
+    // single assignment: every wire written at most once, never read before its write, no gate reads its own output
+    std::vector<int64_t> src(n_wires, -1);
+    for (size_t k = 0; k < n_gates; k++) {
+        const eoc_gate &g = gates[k];
+        if (src[g.out] >= 0) return EOC_ERR_ARG;
+        for (int32_t i : {g.in0, g.in1, g.in2})
+            if (i >= 0 && i == g.out) return EOC_ERR_ARG;
+        src[g.out] = (int64_t)k;
+    }
+    for (size_t k = 0; k < n_gates; k++)
+        for (int32_t i : {gates[k].in0, gates[k].in1, gates[k].in2})
+            if (i >= 0 && src[i] >= (int64_t)k) return EOC_ERR_ARG;
+    std::vector<char> keep(n_wires, 0);
+    for (size_t k = 0; k < n_outputs; k++) keep[outputs[k]] = 1;
+
+    // pass 1: fold NOTs into their readers
+    auto strip = [&](int32_t wire, int &neg) {
+        neg = 0;
+        while (src[wire] >= 0 && gates[src[wire]].op == EOC_NOT) {
+            wire = gates[src[wire]].in0;
+            neg ^= 1;
+        }
+        return wire;
+    };
+    std::vector<eoc_gate> cur;
+    cur.reserve(n_gates);
+    for (size_t k = 0; k < n_gates; k++) {
+        eoc_gate g = gates[k];
+        int n0, n1;
+        if (g.op <= EOC_ORYN) {
+            g.in0 = strip(g.in0, n0);
+            g.in1 = strip(g.in1, n1);
+            g.op = op_with_negated_inputs(g.op, n0, n1);
+            g.in2 = -1;
+        } else if (g.op == EOC_MUX) {
+            g.in0 = strip(g.in0, n0);
+            if (n0) std::swap(g.in1, g.in2);
+        } else if (g.op == EOC_NOT) {
+            g.in0 = strip(g.in0, n0);
+            g.op = n0 ? EOC_COPY : EOC_NOT;
+            g.in1 = g.in2 = -1;
+        }
+        cur.push_back(g);
+    }
+    drop_dead(cur, keep, n_wires);
+
+    // pass 2: OR(sel & b, ~sel & c) -> MUX
+    std::vector<int64_t> src2(n_wires, -1);
+    std::vector<int> uses(n_wires, 0);
+    for (size_t k = 0; k < cur.size(); k++) {
+        src2[cur[k].out] = (int64_t)k;
+        for (int32_t i : {cur[k].in0, cur[k].in1, cur[k].in2})
+            if (i >= 0) uses[i]++;
+    }
+    struct Sel { int32_t sel, data; int pol; };
+    auto as_sel = [](const eoc_gate &g, Sel (&o)[2]) {
+        if (g.op == EOC_AND) { o[0] = {g.in0, g.in1, 1}; o[1] = {g.in1, g.in0, 1}; return 2; }
+        if (g.op == EOC_ANDNY) { o[0] = {g.in0, g.in1, 0}; return 1; }
+        if (g.op == EOC_ANDYN) { o[0] = {g.in1, g.in0, 0}; return 1; }
+        return 0;
+    };
+    std::vector<eoc_gate> fused;
+    fused.reserve(cur.size());
+    for (const eoc_gate &g : cur) {
+        bool done = false;
+        if (g.op == EOC_OR && src2[g.in0] >= 0 && src2[g.in1] >= 0) {
+            const eoc_gate &x = cur[src2[g.in0]], &y = cur[src2[g.in1]];
+            const bool inner_ok = uses[x.out] == 1 && uses[y.out] == 1 && !keep[x.out] && !keep[y.out];
+            Sel sx[2], sy[2];
+            const int nx = as_sel(x, sx), ny = as_sel(y, sy);
+            for (int a = 0; inner_ok && a < nx && !done; a++)
+                for (int b = 0; b < ny && !done; b++)
+                    if (sx[a].sel == sy[b].sel && sx[a].pol != sy[b].pol) {
+                        eoc_gate m;
+                        m.op = EOC_MUX;
+                        m.in0 = sx[a].sel;
+                        m.in1 = sx[a].pol ? sx[a].data : sy[b].data;
+                        m.in2 = sx[a].pol ? sy[b].data : sx[a].data;
+                        m.out = g.out;
+                        fused.push_back(m);
+                        done = true;
+                    }
+        }
+        if (!done) fused.push_back(g);
+    }
+    drop_dead(fused, keep, n_wires);
+    std::copy(fused.begin(), fused.end(), gates_out);
+    return (int64_t)fused.size();
+}

@@ -165,6 +165,14 @@ int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size_t n_gates,
                            size_t n_wires, size_t instances, void *hip_stream);
 /* number of bootstraps (blind rotations) a netlist costs per instance: MUX = 2, NOT/COPY = 0 */
 size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
+/* Netlist rewriting on the host (no GPU): folds NOT gates into their readers (the ten two-input gates are closed
+ * under input negation; a negated MUX selector swaps the branches; NOT(NOT x) = COPY), turns
+ * OR(AND(s, b), ANDNY(s, c)) with single-use inner wires into MUX(s, b, c), and drops gates nobody reads.
+ * `outputs` are the wires the caller reads afterwards.  Single-assignment netlists only (every wire written at most
+ * once, after its readers' inputs): otherwise EOC_ERR_ARG.  gates_out has room for n_gates entries (may alias
+ * nothing); returns the number of gates written.  Same wire numbering, never more bootstraps. */
+int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
+                             eoc_gate *gates_out);
 
 /* building blocks exposed for parity tests and profiling (device pointers, async) */
 int eoc_dbg_fft_fwd_device(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count,

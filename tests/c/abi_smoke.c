@@ -32,6 +32,17 @@ int main(int argc, char **argv)
     CHECK(eoc_secret_key_import(blob, need, 0, &sk2) == EOC_OK);
     CHECK(memcmp(eoc_sk_lwe_key(sk), eoc_sk_lwe_key(sk2), (size_t)p.n * 4) == 0);
     eoc_secret_key_free(sk2);
+    {   /* host-side netlist rewriting: NOT s; (s & x) | (~s & y)  ->  one MUX */
+        const eoc_gate nl[4] = {{EOC_NOT, 0, -1, -1, 3}, {EOC_AND, 0, 1, -1, 4}, {EOC_AND, 3, 2, -1, 5},
+                                {EOC_OR, 4, 5, -1, 6}};
+        const int32_t outs[1] = {6};
+        eoc_gate opt[4];
+        CHECK(eoc_circuit_bootstraps(nl, 4) == 3);
+        CHECK(eoc_netlist_optimize(nl, 4, outs, 1, opt) == 1);
+        CHECK(opt[0].op == EOC_MUX && opt[0].in0 == 0 && opt[0].in1 == 1 && opt[0].in2 == 2 && opt[0].out == 6);
+        const eoc_gate bad[2] = {{EOC_AND, 0, 1, -1, 2}, {EOC_OR, 0, 1, -1, 2}};
+        CHECK(eoc_netlist_optimize(bad, 2, outs, 0, opt) == EOC_ERR_ARG);
+    }
     if (!gpu) {
         if (eoc_device_count() == 0) {
             CHECK(eoc_gate_batch(EOC_NAND, NULL, c0, c1, NULL, out, 4) == EOC_ERR_NO_DEVICE);

@@ -160,3 +160,41 @@ def test_rewrites_refuse_non_ssa():
     g = [Gate(OPS["AND"], 0, 1, -1, 2), Gate(OPS["OR"], 0, 1, -1, 2)]
     with pytest.raises(ValueError):
         c.fold_nots(g, [2])
+
+
+def test_native_optimizer_matches_python(built_lib):
+    """eoc_netlist_optimize (C ABI, host.cpp) rewrites exactly like circuits.optimize"""
+    import eoc_tfhe_amd as eoc
+    rng = np.random.default_rng(23)
+    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "COPY"]
+    as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
+    for trial in range(80):
+        n_in, n_g = 4, int(rng.integers(1, 50))
+        gates, avail = [], list(range(n_in))
+        for k in range(n_g):
+            name = names[int(rng.integers(0, len(names)))]
+            pick = lambda: int(avail[int(rng.integers(0, len(avail)))])
+            out = n_in + k
+            if name in ("NOT", "COPY"):
+                gates.append(Gate(OPS[name], pick(), -1, -1, out))
+            elif name == "MUX":
+                gates.append(Gate(OPS[name], pick(), pick(), pick(), out))
+            else:
+                gates.append(Gate(OPS[name], pick(), pick(), -1, out))
+            avail.append(out)
+        outs = [int(v) for v in rng.choice(avail[n_in:], size=min(3, n_g), replace=False)]
+        assert as_t(eoc.netlist_optimize(gates, outs)) == as_t(c.optimize(gates, outs)), trial
+    # the word-select example: 1 NOT + 3 gates per bit -> 1 MUX per bit
+    gates = [Gate(OPS["NOT"], 0, -1, -1, 9)]
+    outs = []
+    for i in range(4):
+        gates += [Gate(OPS["AND"], 0, 1 + i, -1, 10 + 3 * i), Gate(OPS["AND"], 9, 5 + i, -1, 11 + 3 * i),
+                  Gate(OPS["OR"], 10 + 3 * i, 11 + 3 * i, -1, 12 + 3 * i)]
+        outs.append(12 + 3 * i)
+    assert [g.op for g in eoc.netlist_optimize(gates, outs)] == [OPS["MUX"]] * 4
+    # not single-assignment / malformed -> error
+    with pytest.raises(eoc.EocError):
+        eoc.netlist_optimize([Gate(OPS["AND"], 0, 1, -1, 2), Gate(OPS["OR"], 0, 1, -1, 2)], [2])
+    with pytest.raises(eoc.EocError):
+        eoc.netlist_optimize([Gate(OPS["AND"], 3, 1, -1, 2), Gate(OPS["OR"], 0, 1, -1, 3)], [2])
+    assert eoc.netlist_optimize([], []) == []
