@@ -146,9 +146,9 @@ __device__ __forceinline__ void fwd_pass0(d2 (&x)[8])
     ct_w(x[4], x[5], wc); // W[64]
     ct_w(x[6], x[7], wd); // W[192]
 }
-// twiddle sets of the two table-driven passes: 7 per lane each.  Loading them is separate from using them so that
-// the skewed multi-transform schedules can issue the loads EARLY: one wave's LDS operations complete in issue
-// order, so a twiddle read issued after another transform's transpose would wait for that whole round trip.
+// twiddle sets of the two table-driven passes: 7 per lane each (1 + 2 + 4 for the three stages).  Load and use are
+// separate functions; sharing one loaded set between the transforms of a skewed pair was measured and costs more
+// in spills than it saves in LDS reads (tuning notes further down).
 __device__ __forceinline__ void fwd_tw1_load(d2 (&t)[7], const d2 *tw, int lane)
 { // stages 3,4,5 (bits 5,4,3): twiddles depend on lane >> 3 (and the upper register bits)
     const d2 *q = tw + kTwF1 + (lane >> 3);
