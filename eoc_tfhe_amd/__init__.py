@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("EOC_TFHE_LIB") or os.path.join(_HERE, "libeoc_tfhe_gp
 N = 1024
 
 OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9,
-           MUX=10, NOT=11, COPY=12)
+           MUX=10, NOT=11, COPY=12, CONST0=13, CONST1=14)
 
 
 class EocError(RuntimeError):
@@ -134,6 +134,7 @@ def lib():
         "resetGateKey": (None, []),
         "encryptBit": (vp, [C.c_int, C.c_char_p]),
         "decryptBit": (C.c_int, [C.c_char_p, C.c_char_p]),
+        "constantBit": (vp, [C.c_int]),
         "gateNAND": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
         "gateAND": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
         "gateOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
@@ -544,6 +545,11 @@ class Tfhe:
     @staticmethod
     def encryptBit(bit, key=""):
         return _take_str(lib().encryptBit(int(bit), key.encode()))
+
+    @staticmethod
+    def constantBit(bit):
+        """bootsCONSTANT: the noiseless trivial sample of `bit` as a ciphertext string"""
+        return _take_str(lib().constantBit(int(bit)))
 
     @staticmethod
     def decryptBit(ct, key=""):

@@ -122,6 +122,8 @@ def evaluate_plain(gates, wires):
             w[g.out] = 1 - w[g.in0]
         elif name == "COPY":
             w[g.out] = w[g.in0]
+        elif name in ("CONST0", "CONST1"):
+            w[g.out] = 1 if name == "CONST1" else 0
         elif name == "MUX":
             w[g.out] = np.where(w[g.in0] == 1, w[g.in1], w[g.in2])
         else:

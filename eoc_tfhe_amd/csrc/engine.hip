@@ -501,8 +501,10 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
     return EOC_OK;
 }
 
-static inline bool op_free(int op) { return op == OP_NOT || op == OP_COPY; }
-static inline bool op_valid(int op) { return (op >= 0 && op <= 12); }
+static inline bool op_const(int op) { return op == OP_CONST0 || op == OP_CONST1; }
+static inline bool op_free(int op) { return op == OP_NOT || op == OP_COPY || op_const(op); }
+static inline bool op_valid(int op) { return (op >= 0 && op <= OP_CONST1); }
+static inline int op_inputs(int op) { return op_const(op) ? 0 : (op_free(op) ? 1 : (op == OP_MUX ? 3 : 2)); }
 
 // One "level": a set of gates that all run over the same S instances.  descs are host-side and
 // carry device pointers; free gates and bootstrapped gates are separated here.
@@ -515,7 +517,7 @@ static int run_level(eoc_engine *e, std::vector<GateDesc> &boot, std::vector<Gat
         HIP_TRY(hipMemcpyAsync(d_descs_slot, freeg.data(), freeg.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
         size_t total = S * (size_t)(n + 1);
         dim3 grid((unsigned)((total + 255) / 256), (unsigned)freeg.size());
-        hipLaunchKernelGGL(k_free_gates, grid, dim3(256), 0, st, d_descs_slot, total);
+        hipLaunchKernelGGL(k_free_gates, grid, dim3(256), 0, st, d_descs_slot, total, n + 1, (int32_t)(1u << 29));
         HIP_TRY(hipGetLastError());
         ofs = freeg.size();
     }
@@ -551,7 +553,7 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
                                      const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
                                      void *hip_stream)
 {
-    if (!e || !d_in0 || !d_out) {
+    if (!e || !d_out || (!d_in0 && !(ops == nullptr && op_const(op)))) {
         eoc_set_error("eoc_gate_batch_device: null argument");
         return EOC_ERR_ARG;
     }
@@ -595,12 +597,12 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
     const uint8_t *run_ops = ops;
     const int32_t *in0 = d_in0, *in1 = d_in1, *in2 = d_in2;
     int32_t *out = d_out;
-    const bool gather = runs > 13; // more runs than opcodes: sorting pays
+    const bool gather = runs > 15; // more runs than opcodes: sorting pays
     if (gather) {
         std::vector<uint32_t> perm(count);
-        size_t bucket[14] = {0};
+        size_t bucket[OP_CONST1 + 2] = {0};
         for (size_t k = 0; k < count; k++) bucket[ops[k] + 1]++;
-        for (int o = 1; o < 14; o++) bucket[o] += bucket[o - 1];
+        for (int o = 1; o < OP_CONST1 + 2; o++) bucket[o] += bucket[o - 1];
         sorted_ops.resize(count);
         for (size_t k = 0; k < count; k++) {
             size_t pos = bucket[ops[k]]++;
@@ -692,7 +694,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     int nlev = 0;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &q = gates[k];
-        int nin = op_free(q.op) ? 1 : (q.op == OP_MUX ? 3 : 2);
+        const int nin = op_valid(q.op) ? op_inputs(q.op) : 0;
         const int32_t ins[3] = {q.in0, q.in1, q.in2};
         if (!op_valid(q.op) || q.out < 0 || (size_t)q.out >= n_wires) {
             eoc_set_error("eoc_circuit_run_device: bad gate %zu", k);
@@ -717,7 +719,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     size_t max_jobs = 0, total_descs = 0;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &q = gates[k];
-        GateDesc d{q.op, 0, d_wires + (size_t)q.in0 * wstride,
+        GateDesc d{q.op, 0, q.in0 >= 0 ? d_wires + (size_t)q.in0 * wstride : nullptr,
                    q.in1 >= 0 ? d_wires + (size_t)q.in1 * wstride : nullptr,
                    q.in2 >= 0 ? d_wires + (size_t)q.in2 * wstride : nullptr, d_wires + (size_t)q.out * wstride};
         (op_free(q.op) ? freeg : boot)[level[k]].push_back(d);

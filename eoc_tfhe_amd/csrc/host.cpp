@@ -434,6 +434,19 @@ extern "C" const char *encryptBit(int bit, const char *)
     return sample_to_b64(ct.data(), c.sk->p.n, c.sk->p.ks_stdev * c.sk->p.ks_stdev);
 }
 
+extern "C" const char *constantBit(int bit)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) { // the sample length comes from the key's parameter set
+        fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
+        return nullptr;
+    }
+    std::vector<int32_t> ct(c.sk->p.n + 1, 0); // lweNoiselessTrivial(+-1/8)
+    ct[c.sk->p.n] = bit ? (int32_t)(1u << 29) : (int32_t)(0u - (1u << 29));
+    return sample_to_b64(ct.data(), c.sk->p.n, 0.0);
+}
+
 extern "C" int decryptBit(const char *b64ct, const char *)
 {
     GlobalCtx &c = ctx();
@@ -595,7 +608,8 @@ extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, c
     size_t n_wires = 0;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &g = gates[k];
-        if (g.op < EOC_NAND || g.op > EOC_COPY || g.out < 0 || g.in0 < 0) return EOC_ERR_ARG;
+        const bool is_const = g.op == EOC_CONST0 || g.op == EOC_CONST1;
+        if (g.op < EOC_NAND || g.op > EOC_CONST1 || g.out < 0 || (g.in0 < 0 && !is_const)) return EOC_ERR_ARG;
         if (g.op <= EOC_MUX && g.in1 < 0) return EOC_ERR_ARG;
         if (g.op == EOC_MUX && g.in2 < 0) return EOC_ERR_ARG;
         for (int32_t i : {g.in0, g.in1, g.in2, g.out}) n_wires = std::max(n_wires, (size_t)(i + 1));

@@ -497,7 +497,7 @@ struct GateDesc {
     const int32_t *in0, *in1, *in2;
     int32_t *out;
 };
-constexpr int OP_MUX = 10, OP_NOT = 11, OP_COPY = 12, OP_RAW = 100;
+constexpr int OP_MUX = 10, OP_NOT = 11, OP_COPY = 12, OP_CONST0 = 13, OP_CONST1 = 14, OP_RAW = 100;
 
 __device__ __forceinline__ void gate_lin(int op, int &cst8, int &s0, int &s1)
 {
@@ -545,11 +545,16 @@ __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ de
 }
 
 // NOT / COPY: no bootstrap.  grid: x = ceil(S*(n+1)/256), y = gates
-__global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__ descs, size_t total)
+__global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__ descs, size_t total, int rowlen, int32_t mu)
 {
     const GateDesc d = descs[blockIdx.y];
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    if (d.op >= OP_CONST0) { // bootsCONSTANT: (0, ..., 0, +-mu), no input
+        const bool is_b = (int)(i % (size_t)rowlen) == rowlen - 1;
+        d.out[i] = is_b ? (d.op == OP_CONST1 ? mu : (int32_t)(0u - (uint32_t)mu)) : 0;
+        return;
+    }
     uint32_t v = (uint32_t)d.in0[i];
     d.out[i] = (int32_t)(d.op == OP_NOT ? 0u - v : v);
 }

@@ -52,7 +52,8 @@ typedef struct eoc_params {
 enum eoc_op {
     EOC_NAND = 0, EOC_AND = 1, EOC_OR = 2, EOC_NOR = 3, EOC_XOR = 4, EOC_XNOR = 5,
     EOC_ANDNY = 6, EOC_ANDYN = 7, EOC_ORNY = 8, EOC_ORYN = 9, EOC_MUX = 10,
-    EOC_NOT = 11, EOC_COPY = 12
+    EOC_NOT = 11, EOC_COPY = 12,
+    EOC_CONST0 = 13, EOC_CONST1 = 14 /* bootsCONSTANT(result, 0 / 1): noiseless trivial sample, no inputs (in0 = -1 / NULL) */
 };
 
 /* error codes (all negative) */
@@ -218,6 +219,8 @@ void resetGateKey(void);
 /* bootsSymEncrypt / bootsSymDecrypt on base64(export_lweSample_toStream bytes):
  * little-endian a[n] | b | f64 current_variance  (eoc-tfhe-run.cpp:293-295) */
 const char *encryptBit(int bit, const char *base64SecretKey);
+/* bootsCONSTANT as a string: the noiseless trivial sample of `bit` (no key material involved, variance 0) */
+const char *constantBit(int bit);
 int decryptBit(const char *base64Ciphertext, const char *base64SecretKey);
 /* boots* gates, signature style of addCiphertexts (eoc-tfhe-run.cpp:427) */
 const char *gateNAND(const char *ct1, const char *ct2, const char *base64PublicKey);

@@ -173,6 +173,13 @@ static napi_value n_sampleInts(napi_env env, napi_callback_info info)
     eoc_params p;
     return ret_int(env, eoc_global_params(&p) == EOC_OK ? p.n + 1 : -1);
 }
+static napi_value n_constantBit(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    return ret_string(env, constantBit(arg_int(env, argv[0])));
+}
 static napi_value n_encryptBits(napi_env env, napi_callback_info info)
 { /* (Buffer bits[count]) -> Buffer int32[count][n+1] */
     ARGS(1);
@@ -232,7 +239,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"encryptInteger_dummy", n_encryptInteger_dummy}, {"decryptInteger", n_decryptInteger},
         {"addCiphertexts", n_addCiphertexts}, {"subtractCiphertexts", n_subtractCiphertexts},
         {"encryptASCIIString", n_encryptASCIIString}, {"decryptASCIIString", n_decryptASCIIString},
-        {"generateGateKey", n_generateGateKey}, {"resetGateKey", n_resetGateKey}, {"encryptBit", n_encryptBit},
+        {"generateGateKey", n_generateGateKey}, {"resetGateKey", n_resetGateKey}, {"encryptBit", n_encryptBit}, {"constantBit", n_constantBit},
         {"decryptBit", n_decryptBit}, {"gateNAND", n_gateNAND}, {"gateAND", n_gateAND}, {"gateOR", n_gateOR},
         {"gateNOR", n_gateNOR}, {"gateXOR", n_gateXOR}, {"gateXNOR", n_gateXNOR}, {"gateNOT", n_gateNOT},
         {"gateMUX", n_gateMUX}, {"exportSecretKey", n_exportSecretKey}, {"importSecretKey", n_importSecretKey},

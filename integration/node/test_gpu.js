@@ -11,6 +11,8 @@ for (const x of [0, 1]) for (const y of [0, 1]) {
   assert.strictEqual(tfhe.decryptBit(tfhe.mux(e[x], e[y], e[1 - y], ''), ''), x ? y : 1 - y);
 }
 assert.strictEqual(tfhe.decryptBit(tfhe.not(e[1], ''), ''), 0);
+assert.strictEqual(tfhe.decryptBit(tfhe.and(tfhe.constantBit(1), e[1], ''), ''), 1);
+assert.strictEqual(tfhe.decryptBit(tfhe.constantBit(0), ''), 0);
 // 4-bit adder with the string API: 9 + 5 = 14
 const enc = (v, n) => [...Array(n).keys()].map(i => tfhe.encryptBit((v >> i) & 1, ''));
 const S = tfhe.addBits(enc(9, 4), enc(5, 4), '');

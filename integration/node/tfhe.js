@@ -24,6 +24,7 @@ Tfhe.decryptASCIIString = (value, length, key, jwtToken, jwksBase64) =>
 // ---- Boolean path (bootstrapped gates on the GPU engine) ----
 Tfhe.generateGateKey = (lambda, seed) => B.generateGateKey(lambda, seed);
 Tfhe.encryptBit = (bit, key) => B.encryptBit(bit, key);
+Tfhe.constantBit = bit => B.constantBit(bit);  // bootsCONSTANT: noiseless trivial sample
 Tfhe.decryptBit = (ct, key) => B.decryptBit(ct, key);
 Tfhe.nand = (a, b, pk) => B.gateNAND(a, b, pk);
 Tfhe.and = (a, b, pk) => B.gateAND(a, b, pk);

@@ -543,6 +543,12 @@ int orc_gate(const orc_params *p, const double *bkfft, const int32_t *ksk, int o
         memcpy(out, ca, sizeof(int32_t) * (size_t)(n + 1));
         return 0;
     }
+    if (op == ORC_CONST0 || op == ORC_CONST1) {
+        /* bootsCONSTANT: lweNoiselessTrivial(result, value ? +1/8 : -1/8)   */
+        memset(out, 0, sizeof(int32_t) * (size_t)n);
+        out[n] = op == ORC_CONST1 ? mu : (int32_t)(0u - (uint32_t)mu);
+        return 0;
+    }
     int32_t *t = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
     int rc = 0;
     if (op == ORC_MUX) {

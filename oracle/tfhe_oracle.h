@@ -46,7 +46,7 @@ int orc_default_params(int set, orc_params *out);
 enum {
     ORC_NAND = 0, ORC_AND = 1, ORC_OR = 2, ORC_NOR = 3, ORC_XOR = 4, ORC_XNOR = 5,
     ORC_ANDNY = 6, ORC_ANDYN = 7, ORC_ORNY = 8, ORC_ORYN = 9, ORC_MUX = 10,
-    ORC_NOT = 11, ORC_COPY = 12
+    ORC_NOT = 11, ORC_COPY = 12, ORC_CONST0 = 13, ORC_CONST1 = 14 /* bootsCONSTANT(result, 0 / 1) */
 };
 
 /* ---- deterministic counter-based generator (DESIGN.md "PRNG") ---- */

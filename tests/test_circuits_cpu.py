@@ -166,7 +166,7 @@ def test_native_optimizer_matches_python(built_lib):
     """eoc_netlist_optimize (C ABI, host.cpp) rewrites exactly like circuits.optimize"""
     import eoc_tfhe_amd as eoc
     rng = np.random.default_rng(23)
-    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "COPY"]
+    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "COPY", "CONST0", "CONST1"]
     as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
     for trial in range(80):
         n_in, n_g = 4, int(rng.integers(1, 50))
@@ -175,7 +175,9 @@ def test_native_optimizer_matches_python(built_lib):
             name = names[int(rng.integers(0, len(names)))]
             pick = lambda: int(avail[int(rng.integers(0, len(avail)))])
             out = n_in + k
-            if name in ("NOT", "COPY"):
+            if name in ("CONST0", "CONST1"):
+                gates.append(Gate(OPS[name], -1, -1, -1, out))
+            elif name in ("NOT", "COPY"):
                 gates.append(Gate(OPS[name], pick(), -1, -1, out))
             elif name == "MUX":
                 gates.append(Gate(OPS[name], pick(), pick(), pick(), out))
@@ -183,6 +185,12 @@ def test_native_optimizer_matches_python(built_lib):
                 gates.append(Gate(OPS[name], pick(), pick(), -1, out))
             avail.append(out)
         outs = [int(v) for v in rng.choice(avail[n_in:], size=min(3, n_g), replace=False)]
+        w = np.zeros((n_in + n_g, 16), np.uint8)
+        for k in range(16):
+            for i in range(n_in):
+                w[i, k] = (k >> i) & 1
+        ref, opt = c.evaluate_plain(gates, w), c.evaluate_plain(c.optimize(gates, outs), w)
+        assert all(np.array_equal(ref[o], opt[o]) for o in outs), trial
         assert as_t(eoc.netlist_optimize(gates, outs)) == as_t(c.optimize(gates, outs)), trial
     # the word-select example: 1 NOT + 3 gates per bit -> 1 MUX per bit
     gates = [Gate(OPS["NOT"], 0, -1, -1, 9)]

@@ -21,7 +21,8 @@ def _oracle_run(orc, gates, wires):
     for g in gates:
         i1 = None if g.in1 < 0 else w[g.in1]
         i2 = None if g.in2 < 0 else w[g.in2]
-        w[g.out] = orc.gate_batch(g.op, w[g.in0], i1, i2)
+        i0 = w[g.in0] if g.in0 >= 0 else np.zeros_like(w[g.out])   # bootsCONSTANT has no input
+        w[g.out] = orc.gate_batch(g.op, i0, i1, i2)
     return w
 
 
@@ -145,6 +146,10 @@ def test_string_api_and_host_batch_api(eoc):
         assert T.decryptBit(T.nand(c1, c1)) == 0 and T.decryptBit(T.nand(c0, c1)) == 1
         assert T.decryptBit(T.xor(c0, c1)) == 1 and T.decryptBit(T.and_(c1, c1)) == 1
         assert T.decryptBit(T.not_(c1)) == 0
+        k0, k1 = T.constantBit(0), T.constantBit(1)       # bootsCONSTANT: trivial samples, variance field 0
+        assert T.decryptBit(k0) == 0 and T.decryptBit(k1) == 1
+        assert base64.b64decode(k1)[: 4 * 500] == bytes(4 * 500) and base64.b64decode(k1)[-8:] == bytes(8)
+        assert T.decryptBit(T.and_(k1, c1)) == 1 and T.decryptBit(T.or_(k0, c0)) == 0
         assert T.decryptBit(T.mux(c1, c0, c1)) == 0 and T.decryptBit(T.mux(c0, c0, c1)) == 1
         assert T.nand("not base64!", c1) is None          # malformed input -> NULL
         # host-buffer batch API on the same global engine
@@ -198,13 +203,16 @@ def test_random_netlists_bit_exact(eoc, seed):
     p, sk, eng, orc = _setup(eoc, seed % 2, 20 + seed, 12 + seed)
     rng = np.random.default_rng(seed)
     n_in, n_wires, n_gates, S = 5, 11, 40, 3
-    names = ["NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NOT", "COPY"]
+    names = ["NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NOT", "COPY",
+             "CONST0", "CONST1"]
     gates = []
     for _ in range(n_gates):
         op = eoc.OPS[names[rng.integers(0, len(names))]]
         a, b, c = (int(x) for x in rng.integers(0, n_wires, 3))
         out = int(rng.integers(n_in, n_wires))     # may overwrite a wire that earlier gates read or wrote
-        if op in (eoc.OPS["NOT"], eoc.OPS["COPY"]):
+        if op in (eoc.OPS["CONST0"], eoc.OPS["CONST1"]):
+            gates.append(eoc.Gate(op, -1, -1, -1, out))
+        elif op in (eoc.OPS["NOT"], eoc.OPS["COPY"]):
             gates.append(eoc.Gate(op, a, -1, -1, out))
         elif op == eoc.OPS["MUX"]:
             gates.append(eoc.Gate(op, a, b, c, out))

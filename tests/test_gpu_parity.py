@@ -159,6 +159,18 @@ def test_mux_not_copy_small(eoc, rig_small):
     assert np.array_equal(r.gate(eoc.OPS["MUX"], a, b, c), r.orc.gate_batch(ol.OPS["MUX"], a, b, c))
     assert np.array_equal(r.gate(eoc.OPS["NOT"], a), r.orc.gate_batch(ol.OPS["NOT"], a))
     assert np.array_equal(r.gate(eoc.OPS["COPY"], a), a)
+    # bootsCONSTANT: no input (NULL), noiseless trivial sample; mixed into a batch it needs no operand either
+    torch = torch_cuda()
+    for name, bit in (("CONST0", 0), ("CONST1", 1)):
+        out = torch.empty((5, r.p.n + 1), dtype=torch.int32, device="cuda")
+        r.eng.gate_batch_device(eoc.OPS[name], None, None, None, out.data_ptr(), 5)
+        sync()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, r.orc.gate_batch(ol.OPS[name], np.zeros_like(a)))
+        assert not got[:, :-1].any() and np.all(got[:, -1] == (1 << 29) * (2 * bit - 1))
+        assert np.array_equal(r.sk.decrypt_bits(got), np.full(5, bit, np.uint8))
+    ops = np.array([eoc.OPS["CONST1"], eoc.OPS["AND"], eoc.OPS["CONST0"], eoc.OPS["NOT"], eoc.OPS["XOR"]], np.uint8)
+    assert np.array_equal(r.gate(0, a, b, None, ops=ops), r.orc.gate_batch(0, a, b, None, ops=ops))
 
 
 def test_mixed_ops_small(eoc, rig_small):

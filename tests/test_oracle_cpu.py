@@ -209,3 +209,12 @@ def test_oracle_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="2")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "oracle_sanitize OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_constant_gate_is_the_noiseless_trivial_sample(orc_a):
+    """bootsCONSTANT: (0, ..., 0, +-1/8); decrypts to the bit under any key"""
+    z = np.zeros((3, orc_a.n + 1), np.int32)
+    for name, bit in (("CONST0", 0), ("CONST1", 1)):
+        out = orc_a.gate_batch(ol.OPS[name], z)
+        assert not out[:, :-1].any() and np.all(out[:, -1] == (1 << 29) * (2 * bit - 1))
+        assert np.array_equal(orc_a.decrypt_bits(out), np.full(3, bit))
