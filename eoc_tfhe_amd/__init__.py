@@ -124,6 +124,7 @@ def lib():
         "eoc_blind_rotate_device": (C.c_int, [vp, vp, vp, sz, vp]),
         "eoc_keyswitch_device": (C.c_int, [vp, vp, vp, sz, vp]),
         "eoc_engine_stats": (C.c_int, [vp, C.POINTER(u64 * 3)]),
+        "eoc_stats": (C.c_int, [C.POINTER(u64 * 3)]),
         "eoc_gpu_init": (C.c_int, [C.c_int, PP]),
         "eoc_upload_cloud_key": (C.c_int, [vp]),
         "eoc_global_engine": (vp, []),
@@ -442,6 +443,13 @@ def gpu_init(params, device=0):
 
 def gpu_shutdown():
     lib().eoc_gpu_shutdown()
+
+
+def stats():
+    """eoc_stats: counters of the global engine (batches, bootstraps, key switches)"""
+    out = (C.c_uint64 * 3)()
+    _check(lib().eoc_stats(C.byref(out)), "eoc_stats")
+    return dict(batches=out[0], bootstraps=out[1], keyswitches=out[2])
 
 
 def upload_cloud_key(sk):

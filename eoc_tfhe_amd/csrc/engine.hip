@@ -863,6 +863,15 @@ extern "C" void eoc_gpu_shutdown(void)
     eoc_engine_destroy(g_engine);
     g_engine = nullptr;
 }
+extern "C" int eoc_stats(uint64_t out[3])
+{
+    std::lock_guard<std::mutex> g(g_engine_mu);
+    if (!g_engine) {
+        eoc_set_error("eoc_stats: no global engine (eoc_gpu_init)");
+        return EOC_ERR_STATE;
+    }
+    return eoc_engine_stats(g_engine, out);
+}
 extern "C" int eoc_upload_cloud_key(const eoc_secret_key *sk)
 {
     if (!g_engine) {

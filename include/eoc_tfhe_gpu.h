@@ -202,6 +202,7 @@ int eoc_gpu_init(int device, const eoc_params *p);     /* create the global engi
 int eoc_upload_cloud_key(const eoc_secret_key *sk);    /* push sk's BK/KSK to the global engine */
 eoc_engine *eoc_global_engine(void);
 void eoc_gpu_shutdown(void);
+int eoc_stats(uint64_t out[3]);                        /* eoc_engine_stats of the global engine */
 int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
                    const int32_t *in2, int32_t *out, size_t count);
 int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,

@@ -229,6 +229,8 @@ def test_random_netlists_bit_exact(eoc, seed):
     try:
         eoc.upload_cloud_key(sk)
         assert np.array_equal(eoc.circuit_run(gates, wires.copy(), S), want)
+        st = eoc.stats()
+        assert st["bootstraps"] == eoc.circuit_bootstraps(gates) * S and st["batches"] >= 1
     finally:
         eoc.gpu_shutdown()
 
