@@ -34,5 +34,7 @@ const toBits = s => Buffer.from([...Buffer.from(s)].flatMap(c => [...Array(8).ke
 const eq = (s, t) => tfhe.backend.decryptBits(tfhe.equalBits(tfhe.backend.encryptBits(toBits(s)), tfhe.backend.encryptBits(toBits(t))))[0];
 assert.strictEqual(eq('sixteen byte str', 'sixteen byte str'), 1);
 assert.strictEqual(eq('sixteen byte str', 'sixteen byte stR'), 0);
+assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptStringBits('abc'), tfhe.encryptStringBits('abc')))[0], 1);
+assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptStringBits('abc'), tfhe.encryptStringBits('abd')))[0], 0);
 tfhe.backend.resetGateKey();
 console.log('node gpu tests OK');

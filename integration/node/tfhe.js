@@ -60,6 +60,9 @@ Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1]
   }
   return B.gateBatch(11 /* NOT */, level, null, null);
 };
+// string helpers of the gate path: a string travels as 8 bit-ciphertexts per byte, LSB first (raw Buffer of samples)
+Tfhe.encryptStringBits = str => B.encryptBits(Buffer.from([...Buffer.from(str)].flatMap(c => [...Array(8).keys()].map(k => (c >> k) & 1))));
+Tfhe.equalStrings = (X, Y) => Tfhe.equalBits(X, Y);   // one ciphertext: 1 iff the two encrypted strings are equal
 // unsigned comparison and min/max over bit-sliced ciphertext arrays (LSB first), string API:
 // lt_0 = (not a_0) and b_0 -- written NOT + AND here; the batch/circuit layer uses bootsANDNY directly --
 // lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i)
