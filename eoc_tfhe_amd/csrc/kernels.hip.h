@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 
 // Tuning switches kept from measured experiments (tools/ablate.sh, tools/variants.sh; 1024 gates, Set A):
 //   EOC_ACC_REGS  register copy of the accumulator next to the LDS copy the rotation reads: -1.7 %  (on)
-//   EOC_LATE_BK   load all key rows after the transforms: 178 VGPRs but +12 % time                  (off)
-//   EOC_BK_PREFETCH 2    partner rows issued at the start (1, mid-transform, was removed): no gain, spills (0)
+//   (removed) loading all key rows after the transforms: 178 VGPRs but +12 % time; the partner's rows issued at
+//   the start or mid-transform as well: no gain, spills
 #ifndef EOC_ACC_REGS
 #define EOC_ACC_REGS 1
 #endif
@@ -584,12 +584,14 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 //   (a feedback form -- waves publish their step counters by physical slot, the one behind takes the priority --
 //    gave -7 % on a single round, less than the fixed duty, and as a tail balancer for launches of a few rounds
 //    -5 % at exactly 2 rounds, 0 % beyond 4 and on the circuit workloads, +5 % at 1.5 rounds; a phase-dependent priority inside the step cost +6..20 %; both removed)
-//   EOC_L3_TRIPLE gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 %    (on)
-#define EOC_L3_TRIPLE 1
-//   EOC_THEIRS_FIRST gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (on)
-#define EOC_THEIRS_FIRST 1
+//   gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 % against pair + single (kept)
+//   gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (kept);
+//   EOC_L3_THEIRS_FIRST the same order for gadget length 3: -0.4 %, within the noise                      (off)
+#ifndef EOC_L3_THEIRS_FIRST
+#define EOC_L3_THEIRS_FIRST 0
+#endif
 //   (requesting the inverse transform's twiddles / un-twist factors one pass early was measured too: 0 %, removed)
-//   EOC_STAGGER_MODE     de-phasing the workgroups that share a CU: 0 %                                (off)
+//   (removed) de-phasing the workgroups that share a CU by start-up sleeps: 0 %, before and after the priority fix
 //   (one own key row issued before the forward transforms' last pass: 0 %, 3.756 vs 3.766 ms, removed)
 //   (removed) forward twiddle sets loaded once per skewed pair/triple, ahead of the other transform's
 //                 transpose (7-14 fewer ds_read_b128 per step): +1.5 % (l = 2) / +9.7 % (l = 3) -- the 28 extra
@@ -673,22 +675,6 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
 
     load_tables(s_tw, s_twist, g_tw, g_twist, tid);
-
-#if defined(EOC_STAGGER_MODE)
-    // experiment: de-phase the workgroups that share a CU so that one is in a register pass while the
-    // other is in an LDS phase (speed only; correctness does not depend on it)
-    {
-#if EOC_STAGGER_MODE == 1
-        const bool late = blockIdx.x >= gridDim.x / 2;
-#elif EOC_STAGGER_MODE == 2
-        const bool late = blockIdx.x & 1;
-#else
-        const bool late = (blockIdx.x >> 3) & 1;
-#endif
-        if (late)
-            for (int k = 0; k < EOC_STAGGER_SLEEPS; k++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
     {
@@ -813,59 +799,34 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // digits are transformed two at a time (skewed schedule on one scratch), an odd last one alone
         auto pair_pass = [&](auto pc) __attribute__((always_inline)) {
             constexpr int p = decltype(pc)::value;
-#ifndef EOC_BK_PREFETCH
-#define EOC_BK_PREFETCH 0
-#endif
             d2 ba[8], bb[8], xa[8], xb[8];
-#if defined(EOC_THEIRS_FIRST)
-            load_row(p, L == 2 ? 1 - h : h, ba);
-            load_row(p + 1, L == 2 ? 1 - h : h, bb);
-#elif !defined(EOC_LATE_BK)
-            load_row(p, h, ba);
-            load_row(p + 1, h, bb);
-#endif
-#if EOC_BK_PREFETCH == 2
-            d2 ca[8], cb[8];
-            load_row(p, 1 - h, ca);
-            load_row(p + 1, 1 - h, cb);
-#endif
+            // l = 2: the rows loaded early (under the transforms) are the PARTNER's, so that its partial spectrum is
+            // finished and stored first and the own accumulation runs while that store lands (-1.3 %)
+            const int first = L == 2 ? 1 - h : h;
+            load_row(p, first, ba);
+            load_row(p + 1, first, bb);
             make_x(p, xa);
             make_x(p + 1, xb);
             EOC_STAMP(1);
             fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
             EOC_STAMP(2);
-#ifdef EOC_LATE_BK
-            load_row(p, h, ba);
-            load_row(p + 1, h, bb);
-#endif
-#if defined(EOC_THEIRS_FIRST)
             if constexpr (L == 2) {
-                // early-loaded rows are the PARTNER's: its partial spectrum is stored before the own
-                // accumulation, which then runs while that store lands and the partner catches up
                 mac(true, xa, ba, theirs);
                 mac(false, xb, bb, theirs);
-                load_row(p, h, ba);
+                load_row(p, h, ba); // the own rows re-use the same registers
                 load_row(p + 1, h, bb);
 #pragma unroll
                 for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
                 mac(true, xa, ba, mine);
                 mac(false, xb, bb, mine);
-                EOC_STAMP(3);
-                return;
+            } else {
+                mac(p == 1, xa, ba, mine);
+                mac(false, xb, bb, mine);
+                load_row(p, 1 - h, ba);
+                load_row(p + 1, 1 - h, bb);
+                mac(p == 1, xa, ba, theirs);
+                mac(false, xb, bb, theirs);
             }
-#endif
-            mac(p == 1, xa, ba, mine);
-            mac(false, xb, bb, mine);
-#if EOC_BK_PREFETCH == 0
-            // the partner polynomial's rows re-use the same registers
-            load_row(p, 1 - h, ba);
-            load_row(p + 1, 1 - h, bb);
-            mac(p == 1, xa, ba, theirs);
-            mac(false, xb, bb, theirs);
-#else
-            mac(p == 1, xa, ca, theirs);
-            mac(false, xb, cb, theirs);
-#endif
             EOC_STAMP(3);
         };
         auto single_pass = [&](auto pc) __attribute__((always_inline)) {
@@ -886,6 +847,25 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             make_x(1, xa);
             make_x(2, xb);
             make_x(3, xc);
+#if EOC_L3_THEIRS_FIRST
+            load_row(1, 1 - h, ba);
+            load_row(2, 1 - h, bb);
+            EOC_STAMP(1);
+            fft_fwd_wave_x3(xa, xb, xc, s_tw, scr, lane);
+            EOC_STAMP(2);
+            mac(true, xa, ba, theirs);
+            mac(false, xb, bb, theirs);
+            load_row(3, 1 - h, ba);
+            load_row(1, h, bb);
+            mac(false, xc, ba, theirs);
+#pragma unroll
+            for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
+            mac(true, xa, bb, mine);
+            load_row(2, h, ba);
+            load_row(3, h, bb);
+            mac(false, xb, ba, mine);
+            mac(false, xc, bb, mine);
+#else
             load_row(1, h, ba);
             load_row(2, h, bb);
             EOC_STAMP(1);
@@ -901,23 +881,15 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             load_row(3, 1 - h, bb);
             mac(false, xb, ba, theirs);
             mac(false, xc, bb, theirs);
+#endif
             EOC_STAMP(3);
         };
         if constexpr (L == 1) single_pass(std::integral_constant<int, 1>{});
-#ifdef EOC_L3_TRIPLE
         if constexpr (L == 3) triple_pass();
         if constexpr (L == 2 || L == 4) pair_pass(std::integral_constant<int, 1>{});
-#else
-        (void)triple_pass;
-        if constexpr (L >= 2) pair_pass(std::integral_constant<int, 1>{});
-        if constexpr (L == 3) single_pass(std::integral_constant<int, 3>{});
-#endif
         if constexpr (L == 4) pair_pass(std::integral_constant<int, 3>{});
-        // hand the other polynomial's partial spectrum to the partner wave
-#if defined(EOC_THEIRS_FIRST)
-        if constexpr (L != 2)
-#endif
-        {
+        // hand the other polynomial's partial spectrum to the partner wave (l = 2 stored it already)
+        if constexpr (L != 2 && !(L == 3 && EOC_L3_THEIRS_FIRST)) {
 #pragma unroll
             for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
         }
