@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #endif
 //   (requesting the inverse transform's twiddles / un-twist factors one pass early was measured too: 0 %, removed)
 //   (removed) de-phasing the workgroups that share a CU by start-up sleeps: 0 %, before and after the priority fix
+//   the step's rotation amount (bara[i]) is loaded one step ahead, so no load is waited for at the step top: -1 % (kept)
 //   (one own key row issued before the forward transforms' last pass: 0 %, 3.756 vs 3.766 ms, removed)
 //   (removed) forward twiddle sets loaded once per skewed pair/triple, ahead of the other transform's
 //                 transpose (7-14 fewer ds_read_b128 per step): +1.5 % (l = 2) / +9.7 % (l = 3) -- the 28 extra
@@ -717,6 +718,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 #endif
+    int abar_next = (int)bara[0];
     for (int i = 0; i < A.n; i++) {
         EOC_STAMP(15);
 #if EOC_PRIO_ALT
@@ -736,7 +738,8 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 __builtin_amdgcn_s_setprio(0);
         }
 #endif
-        const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
+        const int abar = __builtin_amdgcn_readfirstlane(abar_next);
+        abar_next = (int)bara[i + 1]; // one step ahead (entry n is barb: always in bounds); retires with the key rows
         // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
         // zero update, which is what skipping the step (as libtfhe does) amounts to.
         uint32_t dlo[8], dhi[8];
