@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / hipIpcGetMemHandle); the pool exports this
+# already, the default keeps a bare shell working too.  Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
