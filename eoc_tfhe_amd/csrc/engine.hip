@@ -478,19 +478,22 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
     HIP_TRY(hipGetLastError());
     const uint32_t ntiles = (S + KS_GT - 1) / KS_GT;
     const int nw = (int)(e->n1p / KS_CW);
-    dim3 grid(ntiles * (kN / KS_IT), ngates), block(64 * nw);
+    dim3 grid(ntiles * (kN / KS_IT), ngates);
     const int bb = e->p.ks_basebit, t = e->p.ks_t;
-#define EOC_KS_LAUNCH(BB, TT, NWV, JBV)                                                                   \
+#define EOC_KS_LAUNCH(BB, TT, NWV, JBV, CWV)                                                              \
     do {                                                                                                  \
-        auto kfn = k_keyswitch<BB, TT, NWV, JBV>;                                                         \
-        constexpr int lds = KSCfg<BB, TT, NWV, JBV>::LDS_BYTES;                                           \
+        auto kfn = k_keyswitch<BB, TT, NWV, JBV, CWV>;                                                    \
+        constexpr int lds = KSCfg<BB, TT, NWV, JBV, CWV>::LDS_BYTES;                                      \
+        static_assert(NWV * CWV % KS_CW == 0, "waves x columns must cover whole 128-column units");       \
         hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, d_descs, a);                                        \
+        hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, st, d_descs, a);                               \
     } while (0)
-    if (bb == 2 && t == 8 && nw == 2) EOC_KS_LAUNCH(2, 8, 2, 4);
-    else if (bb == 2 && t == 8 && nw == 4) EOC_KS_LAUNCH(2, 8, 4, 4);
-    else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 6, 2);
-    else if (bb == 2 && t == 8 && nw == 8) EOC_KS_LAUNCH(2, 8, 8, 2);
+    // n1p = 512 (385 <= n <= 511, Set A): eight waves of 64 columns (122 VGPRs, four waves per SIMD) beat four waves
+    // of 128 columns (200 VGPRs, two per SIMD) by 6 % at 1024 gates and 9 % at 4096
+    if (bb == 2 && t == 8 && nw == 2) EOC_KS_LAUNCH(2, 8, 2, 4, 128);
+    else if (bb == 2 && t == 8 && nw == 4) EOC_KS_LAUNCH(2, 8, 8, 4, 64);
+    else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 6, 2, 128);
+    else if (bb == 2 && t == 8 && nw == 8) EOC_KS_LAUNCH(2, 8, 8, 2, 128);
     else {
         eoc_set_error("key switch: unsupported (basebit=%d, t=%d, n=%d); supported: basebit 2, t 8, n <= 1023",
                       bb, t, e->p.n);

@@ -1187,21 +1187,22 @@ __global__ __launch_bounds__(256) void k_ks_init(const GateDesc *__restrict__ de
     }
 }
 
-// grid: x = ceil(S / 64) * (N / KS_IT), y = gates; block = 64 * NW threads (NW = n1p / 128 waves)
+// grid: x = ceil(S / 64) * (N / KS_IT), y = gates; block = 64 * NW threads, NW * CW = n1p
 // One workgroup = 64 ciphertexts (ONE PER LANE) x a slice of KS_IT indices i; wave w owns key columns
-// [128 w, 128 w + 128).  The base-1 candidate rows of JB consecutive j are staged in LDS next to an
+// [CW w, CW w + CW), CW = 128 (accumulators = 128 VGPRs, two waves per SIMD) or 64 (four waves per SIMD).  The base-1 candidate rows of JB consecutive j are staged in LDS next to an
 // all-zero row (digit 0), and every lane reads the row ITS digit selects (lanes with equal digits
 // share an address = broadcast; rows are skewed by 16 B so that different digits hit different
 // banks).  Per (i, j) a wave issues 32 ds_read_b128 + 128 subtractions for 64 ciphertexts -- no
 // scalar selects.  Partial sums are transposed through LDS and leave as coalesced integer atomics.
 constexpr int KS_IT = 32;
-constexpr int KS_CW = 128; // key columns per wave
+constexpr int KS_CW = 128; // unit of the key image's row padding (n1p = multiple of 2 * KS_CW) and default columns per wave
 
-template <int BASEBIT, int T, int NW, int JB>
+template <int BASEBIT, int T, int NW, int JB, int CWV = KS_CW>
 struct KSCfg {
+    static constexpr int CW = CWV;                        // key columns per wave
     static constexpr int BASE = 1 << BASEBIT;
     static constexpr int NT = 64 * NW;                   // threads
-    static constexpr int N1P = KS_CW * NW;
+    static constexpr int N1P = CW * NW;
     static constexpr int ROWI = N1P + 4;                 // LDS row stride in ints (16-B skew)
     static constexpr int BUFI = JB * BASE * ROWI;        // one staging buffer, ints
     static constexpr int TRANSPOSE_BYTES = NW * 64 * 36 * 4; // final 64 x 32 transposes, one per wave
@@ -1212,10 +1213,10 @@ struct KSCfg {
 
 typedef int i4 __attribute__((ext_vector_type(4)));
 
-template <int BASEBIT, int T, int NW, int JB>
+template <int BASEBIT, int T, int NW, int JB, int CWV = KS_CW>
 __global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
 {
-    typedef KSCfg<BASEBIT, T, NW, JB> C;
+    typedef KSCfg<BASEBIT, T, NW, JB, CWV> C;
     static_assert(T % JB == 0, "JB must divide T");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *s_rows = reinterpret_cast<int *>(smem); // [2][JB][BASE][ROWI]
@@ -1263,9 +1264,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__rest
         }
     };
 
-    i4 acc[KS_CW / 4];
+    i4 acc[C::CW / 4];
 #pragma unroll
-    for (int c = 0; c < KS_CW / 4; c++) acc[c] = (i4){0, 0, 0, 0};
+    for (int c = 0; c < C::CW / 4; c++) acc[c] = (i4){0, 0, 0, 0};
 
     stage_load(0);
     stage_store(0);
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__rest
         if (st + 1 < NSTAGE) stage_load(st + 1);
         const int jb = st % (T / JB);
         if (jb == 0) ub = A.ubarT[(size_t)(slice * KS_IT + st / (T / JB)) * A.jstride + job];
-        const int *base = s_rows + buf * C::BUFI + w * KS_CW;
+        const int *base = s_rows + buf * C::BUFI + w * C::CW;
 #pragma unroll 1
         for (int jj = 0; jj < JB; jj++) {
             const int j = jb * JB + jj;
@@ -1285,7 +1286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__rest
             const i4 *row = reinterpret_cast<const i4 *>(base + (jj * C::BASE + (int)dg) * C::ROWI);
             // 8 reads in flight at a time keeps the accumulators (128 VGPRs) and the reads under 256
 #pragma unroll
-            for (int c0 = 0; c0 < KS_CW / 4; c0 += 8) {
+            for (int c0 = 0; c0 < C::CW / 4; c0 += 8) {
                 i4 v[8];
 #pragma unroll
                 for (int c = 0; c < 8; c++) v[c] = row[c0 + c];
@@ -1301,11 +1302,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__rest
     // transpose 64 ciphertexts x 32 columns at a time through LDS, then coalesced atomics
     int *tb = s_rows + w * (64 * 36); // per wave: 64 rows x 36 ints (32 + 4 pad)
 #pragma unroll
-    for (int piece = 0; piece < KS_CW / 32; piece++) {
+    for (int piece = 0; piece < C::CW / 32; piece++) {
 #pragma unroll
         for (int q = 0; q < 8; q++) *reinterpret_cast<i4 *>(&tb[lane * 36 + q * 4]) = acc[piece * 8 + q];
         wave_lds_fence();
-        const int colbase = w * KS_CW + piece * 32 + (lane & 31);
+        const int colbase = w * C::CW + piece * 32 + (lane & 31);
 #pragma unroll 4
         for (int rr = 0; rr < 32; rr++) {
             const int rowi = rr * 2 + (lane >> 5);
