@@ -489,10 +489,11 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
         hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, st, d_descs, a);                               \
     } while (0)
     // n1p = 512 (385 <= n <= 511, Set A): eight waves of 64 columns (122 VGPRs, four waves per SIMD) beat four waves
-    // of 128 columns (200 VGPRs, two per SIMD) by 6 % at 1024 gates and 9 % at 4096
+    // of 128 columns (200 VGPRs, two per SIMD) by 6 % at 1024 gates and 9 % at 4096; n1p = 768 (Set B): twelve waves
+    // of 64 columns with 4 digits per stage beat six of 128 with 2 (one workgroup per CU either way) by 16 %
     if (bb == 2 && t == 8 && nw == 2) EOC_KS_LAUNCH(2, 8, 2, 4, 128);
     else if (bb == 2 && t == 8 && nw == 4) EOC_KS_LAUNCH(2, 8, 8, 4, 64);
-    else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 6, 2, 128);
+    else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 12, 4, 64);
     else if (bb == 2 && t == 8 && nw == 8) EOC_KS_LAUNCH(2, 8, 8, 2, 128);
     else {
         eoc_set_error("key switch: unsupported (basebit=%d, t=%d, n=%d); supported: basebit 2, t 8, n <= 1023",

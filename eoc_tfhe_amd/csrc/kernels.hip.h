@@ -1214,7 +1214,7 @@ struct KSCfg {
 typedef int i4 __attribute__((ext_vector_type(4)));
 
 template <int BASEBIT, int T, int NW, int JB, int CWV = KS_CW>
-__global__ __launch_bounds__(64 * NW, 2) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
+__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
 {
     typedef KSCfg<BASEBIT, T, NW, JB, CWV> C;
     static_assert(T % JB == 0, "JB must divide T");
