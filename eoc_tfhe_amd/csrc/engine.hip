@@ -48,8 +48,6 @@ struct eoc_engine {
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
     int num_cus = 256;
     int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
-    int br_mode = 0;                        // 0 auto, 1 pair form always, 2 throughput form always
-    uint32_t br_t_threshold = 0xFFFFFFFFu;  // jobs from which the throughput form is used (set after measuring)
     int32_t *d_mixed = nullptr;             // gather/scatter space of mixed batches: 4 row arrays + perm
     size_t ws_mixed = 0;
     size_t ws_jobs = 0;
@@ -115,40 +113,57 @@ extern "C" int eoc_device_count(void)
 
 static int upload_tables(eoc_engine *e)
 {
-    // twiddle tables of kernels.hip.h (W512[k] = E2048[4k]) and the twist table E2048[j]
+    // twiddle tables of kernels.hip.h (canonical transform v3) and the un-twist table E2048[j].
+    // forward: rho(s, b) = E[(256 + 1024 bitrev_s(b)) >> s]; inverse: W[k] = E[4k].  Four entries per lane and pass;
+    // the other three twiddles of a pass are i times these (E[k + 512] = i E[k] exactly).
+    if (EOC_E2048[256][0] != EOC_SQRT_HALF || EOC_E2048[256][1] != EOC_SQRT_HALF || EOC_E2048[128][0] != EOC_E128_RE ||
+        EOC_E2048[128][1] != EOC_E128_IM || EOC_E2048[64][0] != EOC_E64_RE || EOC_E2048[64][1] != EOC_E64_IM ||
+        EOC_E2048[320][0] != EOC_E320_RE || EOC_E2048[320][1] != EOC_E320_IM) {
+        eoc_set_error("kernel register constants differ from canon_twiddles.h");
+        return EOC_ERR_STATE;
+    }
+    for (int k = 0; k < 512; k++)
+        if (EOC_E2048[k + 512][0] != -EOC_E2048[k][1] || EOC_E2048[k + 512][1] != EOC_E2048[k][0]) {
+            eoc_set_error("canon_twiddles.h: E[k + 512] != i E[k] at k = %d", k);
+            return EOC_ERR_STATE;
+        }
     std::vector<double> tw((size_t)kTwEntries * 2), twist((size_t)kNH * 2);
-    auto W = [&](int k, int entry) {
-        tw[(size_t)entry * 2] = EOC_E2048[4 * k][0];
-        tw[(size_t)entry * 2 + 1] = EOC_E2048[4 * k][1];
+    auto put = [&](int idx2048, int entry) {
+        tw[(size_t)entry * 2] = EOC_E2048[idx2048][0];
+        tw[(size_t)entry * 2 + 1] = EOC_E2048[idx2048][1];
     };
-    auto bitrev8 = [](int b) {
+    auto rho = [](int s, int b) { // index into E of the root of stage s, block b
         int r = 0;
-        for (int k = 0; k < 8; k++) r |= ((b >> k) & 1) << (7 - k);
-        return r;
+        for (int k = 0; k < s; k++) r |= ((b >> k) & 1) << (s - 1 - k);
+        return (256 + 1024 * r) >> s;
     };
-    // forward pass 1 (stages 3,4,5): block = (hi << s') | c, hi = lane >> 3
+    // forward pass 1 (stages 3,4,5): block = (hi << s') | c, hi = lane >> 3; entries A, B0, C0, C2
     for (int hi = 0; hi < 8; hi++) {
-        W(bitrev8(hi), kTwF1 + 0 * 8 + hi);
-        for (int c = 0; c < 2; c++) W(bitrev8((hi << 1) | c), kTwF1 + (1 + c) * 8 + hi);
-        for (int c = 0; c < 4; c++) W(bitrev8((hi << 2) | c), kTwF1 + (3 + c) * 8 + hi);
+        put(rho(3, hi), kTwF1 + 0 * 8 + hi);
+        put(rho(4, 2 * hi), kTwF1 + 1 * 8 + hi);
+        put(rho(5, 4 * hi), kTwF1 + 2 * 8 + hi);
+        put(rho(5, 4 * hi + 2), kTwF1 + 3 * 8 + hi);
     }
     // forward pass 2 (stages 6,7,8): block = (lane << s') | c
     for (int lane = 0; lane < 64; lane++) {
-        W(bitrev8(lane), kTwF2 + 0 * 64 + lane);
-        for (int c = 0; c < 2; c++) W(bitrev8((lane << 1) | c), kTwF2 + (1 + c) * 64 + lane);
-        for (int c = 0; c < 4; c++) W(bitrev8((lane << 2) | c), kTwF2 + (3 + c) * 64 + lane);
+        put(rho(6, lane), kTwF2 + 0 * 64 + lane);
+        put(rho(7, 2 * lane), kTwF2 + 1 * 64 + lane);
+        put(rho(8, 4 * lane), kTwF2 + 2 * 64 + lane);
+        put(rho(8, 4 * lane + 2), kTwF2 + 3 * 64 + lane);
     }
-    // inverse last pass (stages 0,1,2): W[(i mod h) << s], i = lane + 64 r
-    for (int lane = 0; lane < 64; lane++) {
-        for (int c = 0; c < 4; c++) W(lane + 64 * c, kTwI0 + c * 64 + lane);
-        for (int c = 0; c < 2; c++) W(2 * (lane + 64 * c), kTwI0 + (4 + c) * 64 + lane);
-        W(4 * lane, kTwI0 + 6 * 64 + lane);
-    }
-    // inverse middle pass (stages 3,4,5): i mod 64 = 8 r' + lo, lo = lane & 7
+    // inverse middle pass (stages 5,4,3): i mod 64 = 8 r' + lo, lo = lane & 7; entries m6, m4, m0, m1
     for (int lo = 0; lo < 8; lo++) {
-        for (int c = 0; c < 4; c++) W((c * 8 + lo) * 8, kTwI1 + c * 8 + lo);
-        for (int c = 0; c < 2; c++) W((c * 8 + lo) * 16, kTwI1 + (4 + c) * 8 + lo);
-        W(lo * 32, kTwI1 + 6 * 8 + lo);
+        put(4 * (lo * 32), kTwI1 + 0 * 8 + lo);
+        put(4 * (lo * 16), kTwI1 + 1 * 8 + lo);
+        put(4 * (lo * 8), kTwI1 + 2 * 8 + lo);
+        put(4 * ((8 + lo) * 8), kTwI1 + 3 * 8 + lo);
+    }
+    // inverse last pass (stages 2,1,0): W[(i mod h) << s], i = lane + 64 r; entries n6, n4, n0, n1
+    for (int lane = 0; lane < 64; lane++) {
+        put(4 * (4 * lane), kTwI0 + 0 * 64 + lane);
+        put(4 * (2 * lane), kTwI0 + 1 * 64 + lane);
+        put(4 * lane, kTwI0 + 2 * 64 + lane);
+        put(4 * (lane + 64), kTwI0 + 3 * 64 + lane);
     }
     for (int j = 0; j < kNH; j++) {
         twist[2 * j] = EOC_E2048[j][0];
@@ -198,14 +213,6 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate_t<3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRTLds);
-    if (const char *m = getenv("EOC_TFHE_BR_MODE")) e->br_mode = atoi(m); // 1 = pair form, 2 = throughput form
-    if (const char *t = getenv("EOC_TFHE_BR_T_THRESHOLD")) e->br_t_threshold = (uint32_t)atol(t);
     *out = e;
     return EOC_OK;
 }
@@ -341,9 +348,8 @@ static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_
         eoc_set_error("cloud key upload failed");
         return EOC_ERR_HIP;
     }
-    // the key image carries the inverse transform's 1/512 and the 2^-32 of the wrap-around rounding
-    // (exact power-of-two scaling; products stay around 2^11, far from underflow)
-    int rc = launch_fft_fwd(e, d_bk, d_bkfft, npoly, 0x1p-41, nullptr);
+    // the key image carries the inverse transform's 1/512 (exact power-of-two scaling)
+    int rc = launch_fft_fwd(e, d_bk, d_bkfft, npoly, 0x1p-9, nullptr);
     hipError_t se = hipDeviceSynchronize();
     hipFree(d_bk);
     if (rc) return rc;
@@ -423,27 +429,6 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
                   : ((njobs + 1) / 2 <= 2u * (uint32_t)e->num_cus ? EOC_PRIO_DUTY : -1);
     dim3 grid((njobs + 1) / 2), block(256);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
-    // large launches take the one-wave-per-ciphertext form (no pair exchange, skewed inverse pair); the
-    // 1024-gate headline needs two waves per ciphertext to put two waves on every SIMD
-    const int mode = e->br_mode; // 0 auto, 1 pair form, 2 throughput form
-    const bool tform = mode == 2 || (mode == 0 && njobs >= e->br_t_threshold);
-    if (tform) {
-        dim3 gt((njobs + 7) / 8), bt(512);
-        if (e->p.l == 2 && e->p.Bgbit == 10)
-            hipLaunchKernelGGL((k_blind_rotate_t<2, 10>), gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist);
-        else if (e->p.l == 3 && e->p.Bgbit == 7)
-            hipLaunchKernelGGL((k_blind_rotate_t<3, 7>), gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist);
-        else
-            switch (e->p.l) {
-            case 1: hipLaunchKernelGGL(k_blind_rotate_t<1>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
-            case 2: hipLaunchKernelGGL(k_blind_rotate_t<2>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
-            case 3: hipLaunchKernelGGL(k_blind_rotate_t<3>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
-            case 4: hipLaunchKernelGGL(k_blind_rotate_t<4>, gt, bt, kBRTLds, st, a, e->d_tw, e->d_twist); break;
-            default: return EOC_ERR_ARG;
-            }
-        HIP_TRY(hipGetLastError());
-        return EOC_OK;
-    }
     if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
         hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
     else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B

@@ -8,13 +8,19 @@
 //   k_keyswitch      lweKeySwitch
 //   k_fft_fwd_polys  tGswToFFTConvert (key load)
 //
-// Arithmetic contract (DESIGN.md "Canonical transform v2"): every floating-point operation below
-// is a separately rounded IEEE-754 binary64 +, -, * or an explicit fma; the file MUST be compiled
-// with -ffp-contract=off.  The data-flow graph is the oracle's radix-2 graph (forward: evaluation
-// tree of X^512 - 1, natural order in, bit-reversed out; inverse: decimation in time); every
-// butterfly is (u + w v, u - w v) in the 6-operation fused form  a' = u + w v by 4 fma,
-// b' = fma(2, u, -a').  Three radix-2 stages are executed per register pass (8 points per lane, one
-// 512-point transform per wave64).
+// Arithmetic contract (DESIGN.md "Canonical transform v3"): every floating-point operation below is a
+// separately rounded IEEE-754 binary64 +, -, * or an explicit fma; the file MUST be compiled with
+// -ffp-contract=off.  The data-flow graph is the oracle's radix-2 graph:
+//   forward  evaluation tree of X^512 - i on c_j = p_j + i p_{j+512} (no twist pass; natural order in,
+//            bit-reversed root index out); stage 0 is written on exact integer sums (4 fma per butterfly),
+//            every later butterfly is (u + w v, u - w v) in the 6-operation fused form
+//            a' = u + w v by 4 fma, b' = fma(2, u, -a');
+//   inverse  decimation in time with conjugate twiddles, three register-constant stages as exact moves, then
+//            the un-twist by conj(E[j]) and the conversion Torus32(int64(.)) (truncation, as upstream).
+// Three radix-2 stages are executed per register pass (8 points per lane, one 512-point transform per wave64).
+// The twiddles of a pass are 1 + 2 + 4 per lane, but the second of every sibling pair is i times the first
+// (E[k + 512] = i E[k] holds exactly in the table), so a pass LOADS four and applies the other three through
+// operand swaps and sign modifiers: bit-identical, 4 instead of 7 ds_read_b128 and 16 instead of 28 registers.
 //
 // Wave layouts of the 512 complex points (e = 9-bit index):
 //   L0: reg r = e[8:6], lane = e[5:0]           (input of forward / output of inverse)
@@ -33,20 +39,26 @@ typedef double d2 __attribute__((ext_vector_type(2))); // (re, im)
 constexpr int kN = 1024;
 constexpr int kNH = 512;
 constexpr int kScr = 568;      // d2 elements of per-wave transpose scratch (f01 needs 72*7+64)
-// twiddle tables in LDS (d2 entries): forward pass 1 [7][8] (by lane>>3), forward pass 2 [7][64] (by lane),
-// inverse last pass [7][64] (by lane), inverse middle pass [7][8] (by lane&7)
-constexpr int kTwF1 = 0, kTwF2 = 56, kTwI0 = 56 + 448, kTwI1 = 56 + 448 + 448;
-constexpr int kTwEntries = 56 + 448 + 448 + 56;
+// twiddle tables in LDS (d2 entries), FOUR per lane and pass {A, B0, C0, C2}: the stage twiddles are
+// A | B0, i B0 | C0, i C0, C2, i C2
+constexpr int kTwF1 = 0;                    // forward pass 1 [4][8]  (by lane >> 3)
+constexpr int kTwF2 = 32;                   // forward pass 2 [4][64] (by lane)
+constexpr int kTwI1 = 32 + 256;             // inverse middle pass [4][8] (by lane & 7)
+constexpr int kTwI0 = 32 + 256 + 32;        // inverse last pass [4][64] (by lane)
+constexpr int kTwEntries = 32 + 256 + 32 + 256;
 
 #define EOC_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
-__device__ __forceinline__ d2 cmul(d2 a, d2 w)
-{ // a * w
-    d2 r;
-    r.x = EOC_FMA(a.x, w.x, -(a.y * w.y));
-    r.y = EOC_FMA(a.x, w.y, a.y * w.x);
-    return r;
-}
+// register constants of the forward transform's first pass: E[256] = (c, c), E[128], E[64], E[320]
+// (checked against canon_twiddles.h when an engine is created)
+#define EOC_SQRT_HALF 0x1.6a09e667f3bcdp-1
+#define EOC_E128_RE 0x1.d906bcf328d46p-1
+#define EOC_E128_IM 0x1.87de2a6aea963p-2
+#define EOC_E64_RE 0x1.f6297cff75cb0p-1
+#define EOC_E64_IM 0x1.8f8b83c69a60bp-3
+#define EOC_E320_RE 0x1.1c73b39ae68c8p-1
+#define EOC_E320_IM 0x1.a9b66290ea1a3p-1
+
 __device__ __forceinline__ d2 cmulc(d2 a, d2 w)
 { // a * conj(w)
     d2 r;
@@ -55,41 +67,47 @@ __device__ __forceinline__ d2 cmulc(d2 a, d2 w)
     return r;
 }
 
-// --- radix-2 butterflies (u, v) -> (u + w v, u - w v) -----------------------------------------------
+// --- radix-2 butterflies (u, v) -> (u + t v, u - t v), fused form ---------------------------------
+#define EOC_BFLY_TAIL()                      \
+    a = n;                                   \
+    b.x = EOC_FMA(2.0, u.x, -n.x);           \
+    b.y = EOC_FMA(2.0, u.y, -n.y)
 __device__ __forceinline__ void ct_w(d2 &a, d2 &b, d2 w)
-{ // fused form, twiddle w
+{ // t = w
     d2 u = a, n;
     n.x = EOC_FMA(-w.y, b.y, EOC_FMA(w.x, b.x, u.x));
     n.y = EOC_FMA(w.x, b.y, EOC_FMA(w.y, b.x, u.y));
-    a = n;
-    b.x = EOC_FMA(2.0, u.x, -n.x);
-    b.y = EOC_FMA(2.0, u.y, -n.y);
+    EOC_BFLY_TAIL();
+}
+__device__ __forceinline__ void ct_iw(d2 &a, d2 &b, d2 w)
+{ // t = i w = (-w.im, w.re)
+    d2 u = a, n;
+    n.x = EOC_FMA(-w.x, b.y, EOC_FMA(-w.y, b.x, u.x));
+    n.y = EOC_FMA(-w.y, b.y, EOC_FMA(w.x, b.x, u.y));
+    EOC_BFLY_TAIL();
 }
 __device__ __forceinline__ void ct_wc(d2 &a, d2 &b, d2 w)
-{ // fused form, twiddle conj(w)
+{ // t = conj(w)
     d2 u = a, n;
     n.x = EOC_FMA(w.y, b.y, EOC_FMA(w.x, b.x, u.x));
     n.y = EOC_FMA(w.x, b.y, EOC_FMA(-w.y, b.x, u.y));
-    a = n;
-    b.x = EOC_FMA(2.0, u.x, -n.x);
-    b.y = EOC_FMA(2.0, u.y, -n.y);
+    EOC_BFLY_TAIL();
+}
+__device__ __forceinline__ void ct_iwc(d2 &a, d2 &b, d2 w)
+{ // t = conj(i w) = (-w.im, -w.re)
+    d2 u = a, n;
+    n.x = EOC_FMA(w.x, b.y, EOC_FMA(-w.y, b.x, u.x));
+    n.y = EOC_FMA(-w.y, b.y, EOC_FMA(-w.x, b.x, u.y));
+    EOC_BFLY_TAIL();
 }
 __device__ __forceinline__ void ct_1(d2 &a, d2 &b)
-{ // w = 1 (register-constant stages only)
+{ // t = 1 (register-constant stages of the inverse only)
     d2 u = a, v = b;
     a = u + v;
     b = u - v;
 }
-__device__ __forceinline__ void ct_i(d2 &a, d2 &b)
-{ // w = i: t = i v = (-v.y, v.x)
-    d2 u = a, t;
-    t.x = -b.y;
-    t.y = b.x;
-    a = u + t;
-    b = u - t;
-}
 __device__ __forceinline__ void ct_ic(d2 &a, d2 &b)
-{ // w = conj(i): t = (v.y, -v.x)
+{ // t = conj(i): t v = (v.y, -v.x)
     d2 u = a, t;
     t.x = b.y;
     t.y = -b.x;
@@ -97,14 +115,10 @@ __device__ __forceinline__ void ct_ic(d2 &a, d2 &b)
     b = u - t;
 }
 
-// W512[64] = (c, c), W512[192] = (-c, c), c = correctly rounded sqrt(1/2) = EOC_E2048[256][0]
-#define EOC_SQRT_HALF 0x1.6a09e667f3bcdp-1
-
 // --- LDS address maps ---------------------------------------------------------------------------
 // f12: XOR swizzle, conflict-free for ds_read_b128 (16-lane groups, 64 banks) AND ds_write_b128 (8-lane
 // groups, 32 banks) in both the L1 and the L2 access pattern (brute-forced against the bank model of
-// MI355X_MICROARCH.md; the first version, (e >> 4) & 7, was 2-way on the inverse transform's L2 writes:
-// SQ_LDS_BANK_CONFLICT showed exactly 64 cycles per wave-step)
+// MI355X_MICROARCH.md)
 __device__ __forceinline__ int f12(int e) { return e ^ (((e >> 3) & 7) | (((e >> 6) & 1) << 3)); }
 
 // compiler-level ordering between a wave's own LDS writes and cross-lane reads (the hardware
@@ -117,175 +131,128 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 // Ablation switches for diagnostic builds (tools/ablate.sh): wrong results, timing only.
-#ifdef EOC_ABL_NOTRANSPOSE
-#define EOC_LDS_T(stmt) do { } while (0)
-#else
-#define EOC_LDS_T(stmt) do { stmt; } while (0)
-#endif
 #ifdef EOC_ABL_NOBAR
 #define EOC_SYNC() do { } while (0)
 #else
 #define EOC_SYNC() __syncthreads()
 #endif
 
-// ---- forward transform, in pieces (x[] in L0, already twisted -> x[] in L2) --------------------
-// tw = LDS table [14][64], scr = this wave's scratch
-__device__ __forceinline__ void fwd_pass0(d2 (&x)[8])
-{ // stages 0,1,2 (bits 8,7,6): twiddles W[bitrev8(block)] are register constants
-    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
-    ct_1(x[0], x[4]);
-    ct_1(x[1], x[5]);
-    ct_1(x[2], x[6]);
-    ct_1(x[3], x[7]);
-    ct_1(x[0], x[2]);
-    ct_1(x[1], x[3]);
-    ct_i(x[4], x[6]);
-    ct_i(x[5], x[7]);
-    ct_1(x[0], x[1]);
-    ct_i(x[2], x[3]);
-    ct_w(x[4], x[5], wc); // W[64]
-    ct_w(x[6], x[7], wd); // W[192]
+// ---- forward transform, in pieces ---------------------------------------------------------------
+// stage 0 on exact integer-valued doubles: u = (a, b), v = (p, q), dm = p - q, dp = p + q
+__device__ __forceinline__ void fwd_stage0(d2 &lo, d2 &hi, double a, double b, double dm, double dp)
+{
+    lo.x = EOC_FMA(EOC_SQRT_HALF, dm, a);
+    lo.y = EOC_FMA(EOC_SQRT_HALF, dp, b);
+    hi.x = EOC_FMA(-EOC_SQRT_HALF, dm, a);
+    hi.y = EOC_FMA(-EOC_SQRT_HALF, dp, b);
 }
-// twiddle sets of the two table-driven passes: 7 per lane each (1 + 2 + 4 for the three stages).  Load and use are
-// separate functions; sharing one loaded set between the transforms of a skewed pair was measured and costs more
-// in spills than it saves in LDS reads (tuning notes further down).
-__device__ __forceinline__ void fwd_tw1_load(d2 (&t)[7], const d2 *tw, int lane)
-{ // stages 3,4,5 (bits 5,4,3): twiddles depend on lane >> 3 (and the upper register bits)
-    const d2 *q = tw + kTwF1 + (lane >> 3);
+__device__ __forceinline__ void fwd_pass0_tail(d2 (&x)[8])
+{ // stages 1, 2 (bits 7, 6): rho(1,0) = E[128], rho(1,1) = i E[128]; rho(2,.) = E[64], i E[64], E[320], i E[320]
+    const d2 w1 = {EOC_E128_RE, EOC_E128_IM}, w2 = {EOC_E64_RE, EOC_E64_IM}, w3 = {EOC_E320_RE, EOC_E320_IM};
+    ct_w(x[0], x[2], w1);
+    ct_w(x[1], x[3], w1);
+    ct_iw(x[4], x[6], w1);
+    ct_iw(x[5], x[7], w1);
+    ct_w(x[0], x[1], w2);
+    ct_iw(x[2], x[3], w2);
+    ct_w(x[4], x[5], w3);
+    ct_iw(x[6], x[7], w3);
+}
+// the four loaded twiddles of a table-driven pass; `stride` = 8 (pass 1, q = table + (lane >> 3)) or 64 (pass 2)
+__device__ __forceinline__ void tw_load(d2 (&t)[4], const d2 *q, int stride)
+{
 #pragma unroll
-    for (int k = 0; k < 7; k++) t[k] = q[k * 8];
+    for (int k = 0; k < 4; k++) t[k] = q[k * stride];
 }
-__device__ __forceinline__ void fwd_tw2_load(d2 (&t)[7], const d2 *tw, int lane)
-{ // stages 6,7,8 (bits 2,1,0): twiddles depend on the lane (and the upper register bits)
-    const d2 *q = tw + kTwF2 + lane;
-#pragma unroll
-    for (int k = 0; k < 7; k++) t[k] = q[k * 64];
-}
-__device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[7])
-{ // three radix-2 stages on the 8 register points with the 1 + 2 + 4 twiddles of t[]
+__device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[4])
+{ // three radix-2 stages on the 8 register points: twiddles A | B0, i B0 | C0, i C0, C2, i C2
     ct_w(x[0], x[4], t[0]);
     ct_w(x[1], x[5], t[0]);
     ct_w(x[2], x[6], t[0]);
     ct_w(x[3], x[7], t[0]);
     ct_w(x[0], x[2], t[1]);
     ct_w(x[1], x[3], t[1]);
-    ct_w(x[4], x[6], t[2]);
-    ct_w(x[5], x[7], t[2]);
-    ct_w(x[0], x[1], t[3]);
-    ct_w(x[2], x[3], t[4]);
-    ct_w(x[4], x[5], t[5]);
-    ct_w(x[6], x[7], t[6]);
-}
-__device__ __forceinline__ void fwd_pass1(d2 (&x)[8], const d2 *tw, int lane)
-{
-    d2 t[7];
-    fwd_tw1_load(t, tw, lane);
-    fwd_pass12(x, t);
-}
-__device__ __forceinline__ void fwd_pass2(d2 (&x)[8], const d2 *tw, int lane)
-{
-    d2 t[7];
-    fwd_tw2_load(t, tw, lane);
-    fwd_pass12(x, t);
+    ct_iw(x[4], x[6], t[1]);
+    ct_iw(x[5], x[7], t[1]);
+    ct_w(x[0], x[1], t[2]);
+    ct_iw(x[2], x[3], t[2]);
+    ct_w(x[4], x[5], t[3]);
+    ct_iw(x[6], x[7], t[3]);
 }
 // transposes: write in the source layout, read in the destination layout.  One wave's LDS operations
 // execute in issue order, so a later write to the same scratch cannot overtake an earlier read.
 __device__ __forceinline__ void t01_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * r + lane] = x[r];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t01_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * hi + 8 * r + lo];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t12_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(hi * 64 + r * 8 + lo)] = x[r];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(lane * 8 + r)];
     wave_lds_fence();
-#endif
 }
 
-__device__ __forceinline__ void fft_fwd_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+// one forward transform after its first pass: x[] in L0 (stages 0-2 done) -> x[] in L2
+__device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
 {
-    fwd_pass0(x);
+    d2 t1[4], t2[4];
+    tw_load(t1, tw + kTwF1 + (lane >> 3), 8);
+    tw_load(t2, tw + kTwF2 + lane, 64);
     t01_write(x, scr, lane);
     t01_read(x, scr, lane);
-    fwd_pass1(x, tw, lane);
+    fwd_pass12(x, t1);
     t12_write(x, scr, lane);
     t12_read(x, scr, lane);
-    fwd_pass2(x, tw, lane);
+    fwd_pass12(x, t2);
 }
-
-// Two independent forward transforms of one wave on ONE scratch, skewed so that each transform's
-// LDS round trip runs under the other's register pass (same arithmetic as two fft_fwd_wave calls).
-__device__ __forceinline__ void fft_fwd_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
+// Two independent forward transforms of one wave on ONE scratch, skewed: xa arrives with its first pass done,
+// make_b() produces xb's first pass and is placed under xa's first LDS round trip; the twiddles of both table passes
+// are requested early, and each transform's LDS round trip is issued so that it runs under the other's register pass.
+// LDS issue order: w01(a) r01(a) w01(b) r01(b) w12(a) r12(a) w12(b) r12(b); a register pass waits only for its own
+// read (counted lgkmcnt), which works because no twiddle read sits between a transpose read and its use.
+template <class MakeB>
+__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, const d2 *tw, d2 *scr, int lane)
 {
-    fwd_pass0(xa);
+    d2 t1[4], t2[4];
+    tw_load(t1, tw + kTwF1 + (lane >> 3), 8);
     t01_write(xa, scr, lane);
+    make_b();
     t01_read(xa, scr, lane);
-    fwd_pass0(xb); // under a's round trip
     t01_write(xb, scr, lane);
     t01_read(xb, scr, lane);
-    fwd_pass1(xa, tw, lane); // under b's round trip
+    tw_load(t2, tw + kTwF2 + lane, 64);
+    wave_lds_fence();
+    fwd_pass12(xa, t1);
     t12_write(xa, scr, lane);
     t12_read(xa, scr, lane);
-    fwd_pass1(xb, tw, lane);
+    fwd_pass12(xb, t1);
     t12_write(xb, scr, lane);
     t12_read(xb, scr, lane);
-    fwd_pass2(xa, tw, lane);
-    fwd_pass2(xb, tw, lane);
-}
-// three transforms on one scratch, same skew (gadget length 3: Set B)
-__device__ __forceinline__ void fft_fwd_wave_x3(d2 (&xa)[8], d2 (&xb)[8], d2 (&xc)[8], const d2 *tw, d2 *scr, int lane)
-{
-    fwd_pass0(xa);
-    t01_write(xa, scr, lane);
-    t01_read(xa, scr, lane);
-    fwd_pass0(xb);
-    t01_write(xb, scr, lane);
-    t01_read(xb, scr, lane);
-    fwd_pass0(xc);
-    t01_write(xc, scr, lane);
-    t01_read(xc, scr, lane);
-    fwd_pass1(xa, tw, lane);
-    t12_write(xa, scr, lane);
-    t12_read(xa, scr, lane);
-    fwd_pass1(xb, tw, lane);
-    t12_write(xb, scr, lane);
-    t12_read(xb, scr, lane);
-    fwd_pass1(xc, tw, lane);
-    t12_write(xc, scr, lane);
-    t12_read(xc, scr, lane);
-    fwd_pass2(xa, tw, lane);
-    fwd_pass2(xb, tw, lane);
-    fwd_pass2(xc, tw, lane);
+    fwd_pass12(xa, t2);
+    fwd_pass12(xb, t2);
 }
 
 // ---- inverse transform, in pieces: x[] in L2 -> x[] in L0 (before the un-twist); decimation in time,
 // conjugate twiddles ---------------------------------------------------------------------------------
 __device__ __forceinline__ void inv_pass2(d2 (&x)[8])
-{ // stages 8,7,6 (bits 0,1,2): register constants
-    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}, wd = {-EOC_SQRT_HALF, EOC_SQRT_HALF};
+{ // stages 8,7,6 (bits 0,1,2): register constants; w = 1 and w = conj(i) are exact moves
+    const d2 wc = {EOC_SQRT_HALF, EOC_SQRT_HALF}; // W[64]; W[192] = i W[64]
     ct_1(x[0], x[1]);
     ct_1(x[2], x[3]);
     ct_1(x[4], x[5]);
@@ -297,164 +264,108 @@ __device__ __forceinline__ void inv_pass2(d2 (&x)[8])
     ct_1(x[0], x[4]);
     ct_wc(x[1], x[5], wc);
     ct_ic(x[2], x[6]);
-    ct_wc(x[3], x[7], wd);
+    ct_iwc(x[3], x[7], wc);
 }
-__device__ __forceinline__ void inv_pass1(d2 (&x)[8], const d2 *tw, int lane)
-{ // stages 5,4,3 (bits 3,4,5): W[(i mod h) << s] depends on lane & 7 (and the lower register bits)
-    const d2 *t = tw + kTwI1 + (lane & 7);
-    const d2 m6 = t[6 * 8];
-    ct_wc(x[0], x[1], m6);
-    ct_wc(x[2], x[3], m6);
-    ct_wc(x[4], x[5], m6);
-    ct_wc(x[6], x[7], m6);
-    const d2 m4 = t[4 * 8], m5 = t[5 * 8];
-    ct_wc(x[0], x[2], m4);
-    ct_wc(x[1], x[3], m5);
-    ct_wc(x[4], x[6], m4);
-    ct_wc(x[5], x[7], m5);
-    const d2 m0 = t[0 * 8], m1 = t[1 * 8], m2 = t[2 * 8], m3 = t[3 * 8];
-    ct_wc(x[0], x[4], m0);
-    ct_wc(x[1], x[5], m1);
-    ct_wc(x[2], x[6], m2);
-    ct_wc(x[3], x[7], m3);
-}
-__device__ __forceinline__ void inv_pass0(d2 (&x)[8], const d2 *tw, int lane)
-{ // stages 2,1,0 (bits 6,7,8): depends on the lane (and the lower register bits)
-    const d2 *t = tw + kTwI0 + lane;
-    const d2 n6 = t[6 * 64];
-    ct_wc(x[0], x[1], n6);
-    ct_wc(x[2], x[3], n6);
-    ct_wc(x[4], x[5], n6);
-    ct_wc(x[6], x[7], n6);
-    const d2 n4 = t[4 * 64], n5 = t[5 * 64];
-    ct_wc(x[0], x[2], n4);
-    ct_wc(x[1], x[3], n5);
-    ct_wc(x[4], x[6], n4);
-    ct_wc(x[5], x[7], n5);
-    const d2 n0 = t[0 * 64], n1 = t[1 * 64], n2 = t[2 * 64], n3 = t[3 * 64];
-    ct_wc(x[0], x[4], n0);
-    ct_wc(x[1], x[5], n1);
-    ct_wc(x[2], x[6], n2);
-    ct_wc(x[3], x[7], n3);
+__device__ __forceinline__ void inv_pass10(d2 (&x)[8], const d2 (&t)[4])
+{ // three DIT stages, twiddles conj of: m6 | m4, i m4 | m0, m1, i m0, i m1   (t = {m6, m4, m0, m1})
+    ct_wc(x[0], x[1], t[0]);
+    ct_wc(x[2], x[3], t[0]);
+    ct_wc(x[4], x[5], t[0]);
+    ct_wc(x[6], x[7], t[0]);
+    ct_wc(x[0], x[2], t[1]);
+    ct_iwc(x[1], x[3], t[1]);
+    ct_wc(x[4], x[6], t[1]);
+    ct_iwc(x[5], x[7], t[1]);
+    ct_wc(x[0], x[4], t[2]);
+    ct_wc(x[1], x[5], t[3]);
+    ct_iwc(x[2], x[6], t[2]);
+    ct_iwc(x[3], x[7], t[3]);
 }
 __device__ __forceinline__ void t21_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t21_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t10_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = x[r];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t10_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
 {
+    d2 t1[4], t0[4];
+    tw_load(t1, tw + kTwI1 + (lane & 7), 8);
     inv_pass2(x);
     t21_write(x, scr, lane);
     t21_read(x, scr, lane);
-    inv_pass1(x, tw, lane);
+    tw_load(t0, tw + kTwI0 + lane, 64);
+    wave_lds_fence();
+    inv_pass10(x, t1);
     t10_write(x, scr, lane);
     t10_read(x, scr, lane);
-    inv_pass0(x, tw, lane);
-}
-// two inverse transforms of one wave on one scratch, skewed like fft_fwd_wave_x2
-__device__ __forceinline__ void fft_inv_wave_x2(d2 (&xa)[8], d2 (&xb)[8], const d2 *tw, d2 *scr, int lane)
-{
-    inv_pass2(xa);
-    t21_write(xa, scr, lane);
-    t21_read(xa, scr, lane);
-    inv_pass2(xb);
-    t21_write(xb, scr, lane);
-    t21_read(xb, scr, lane);
-    inv_pass1(xa, tw, lane);
-    t10_write(xa, scr, lane);
-    t10_read(xa, scr, lane);
-    inv_pass1(xb, tw, lane);
-    t10_write(xb, scr, lane);
-    t10_read(xb, scr, lane);
-    inv_pass0(xa, tw, lane);
-    inv_pass0(xb, tw, lane);
+    inv_pass10(x, t0);
 }
 
-// rint + wrap to 32 bits, exact for |v| < 2^83:  q = rint(v / 2^32);  lo = v - q * 2^32 (exact, |lo| <= 2^31);
-// lo + 1.5 * 2^52 rounds lo to the nearest-even integer in the low mantissa bits, whose low dword
-// is rint(v) mod 2^32 (rint(v) = rint(lo) + q * 2^32).
-__device__ __forceinline__ uint32_t wrap_round(double v)
+// Torus32(int64(v)) for |v| < 2^51: t = trunc(v) (exact), t + 1.5 * 2^52 is exact and carries t mod 2^32 in its
+// low dword.  Two operations.  (An external product is bounded by 2 l N (Bg/2) 2^31 <= 2^52 in exact arithmetic and
+// is statistically near 2^45; tests/ hold the oracle's high-water mark below 2^51.)
+__device__ __forceinline__ uint32_t wrap_trunc(double v)
 {
-    double q = __builtin_rint(v * 0x1p-32);
-    double lo = EOC_FMA(q, -4294967296.0, v);
-    double m = lo + 6755399441055744.0;
-    return (uint32_t)__double2loint(m);
-}
-// the same for a value that arrives pre-scaled, w = v * 2^-32 (exactly: power of two):
-//   q = rint(w);  w - q is exact (|w - q| <= 1/2, a multiple of ulp(w));  fma((w - q), 2^32, 1.5 * 2^52) rounds
-//   v - q * 2^32 to the nearest-even integer in the low mantissa bits.  3 operations instead of 4.
-__device__ __forceinline__ uint32_t wrap_round_scaled(double w)
-{
-    double q = __builtin_rint(w);
-    double m = EOC_FMA(w - q, 4294967296.0, 6755399441055744.0);
+    double m = __builtin_trunc(v) + 6755399441055744.0;
     return (uint32_t)__double2loint(m);
 }
 
-// copy the two constant tables into LDS (called by all 256 threads, followed by __syncthreads)
-__device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_tw, const d2 *g_twist, int tid)
+// copy the two constant tables into LDS (called by all threads of the workgroup, followed by __syncthreads)
+__device__ __forceinline__ void load_tables(d2 *s_tw, d2 *s_twist, const d2 *g_tw, const d2 *g_twist, int tid, int nthreads)
 {
-    for (int i = tid; i < kTwEntries; i += 256) s_tw[i] = g_tw[i];
-    for (int i = tid; i < kNH; i += 256) s_twist[i] = g_twist[i];
+    for (int i = tid; i < kTwEntries; i += nthreads) s_tw[i] = g_tw[i];
+    for (int i = tid; i < kNH; i += nthreads) s_twist[i] = g_twist[i];
 }
 
 // =================================================================================================
 // K4 / debug: forward transform of `count` integer polynomials, one wave each
 // =================================================================================================
-// `scale` must be a power of two (exact): 1 for the plain transform, 2^-41 for the key image so that the
-// inverse transform's 1/512 and the 2^-32 of the wrap-around rounding are already in the products
-// (bit-identical to scaling at the end)
+// `scale` must be a power of two (exact): 1 for the plain transform, 2^-9 for the key image so that the
+// inverse transform's 1/512 is already in the products (bit-identical to scaling at the end)
 __global__ __launch_bounds__(256) void k_fft_fwd_polys(const int32_t *__restrict__ polys,
                                                         double *__restrict__ specs, size_t count,
                                                         const d2 *__restrict__ g_tw,
                                                         const d2 *__restrict__ g_twist, double scale)
 {
     __shared__ d2 s_tw[kTwEntries];
-    __shared__ d2 s_twist[kNH];
     __shared__ d2 s_scr[4][kScr];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    load_tables(s_tw, s_twist, g_tw, g_twist, tid);
+    for (int i = tid; i < kTwEntries; i += 256) s_tw[i] = g_tw[i];
+    (void)g_twist;
     __syncthreads();
     size_t poly = (size_t)blockIdx.x * 4 + w;
     if (poly >= count) return;
     const int32_t *p = polys + poly * kN;
     d2 x[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < 4; r++) { // full-range torus inputs: the integer sums are formed in binary64 (exact, < 2^33)
         int j = lane + 64 * r;
-        d2 v = {(double)p[j], (double)p[j + kNH]};
-        x[r] = cmul(v, s_twist[j]);
+        double a = (double)p[j], b = (double)p[j + kNH], pp = (double)p[j + 256], q = (double)p[j + 256 + kNH];
+        fwd_stage0(x[r], x[r + 4], a, b, pp - q, pp + q);
     }
-    fft_fwd_wave(x, s_tw, s_scr[w], lane);
+    fwd_pass0_tail(x);
+    fft_fwd_rest(x, s_tw, s_scr[w], lane);
     d2 *o = reinterpret_cast<d2 *>(specs) + poly * kNH;
 #pragma unroll
     for (int r = 0; r < 8; r++) o[r * 64 + lane] = x[r] * scale;
@@ -469,7 +380,7 @@ __global__ __launch_bounds__(256) void k_fft_inv_polys(const double *__restrict_
     __shared__ d2 s_twist[kNH];
     __shared__ d2 s_scr[4][kScr];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    load_tables(s_tw, s_twist, g_tw, g_twist, tid);
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid, 256);
     __syncthreads();
     size_t poly = (size_t)blockIdx.x * 4 + w;
     if (poly >= count) return;
@@ -483,8 +394,8 @@ __global__ __launch_bounds__(256) void k_fft_inv_polys(const double *__restrict_
     for (int r = 0; r < 8; r++) {
         int j = lane + 64 * r;
         d2 y = cmulc(x[r], s_twist[j] * 0x1p-9);
-        p[j] = (int32_t)wrap_round(y.x);
-        p[j + kNH] = (int32_t)wrap_round(y.y);
+        p[j] = (int32_t)wrap_trunc(y.x);
+        p[j + kNH] = (int32_t)wrap_trunc(y.y);
     }
 }
 
@@ -559,15 +470,23 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
     d.out[i] = (int32_t)(d.op == OP_NOT ? 0u - v : v);
 }
 
-// Tuning switches kept from measured experiments (tools/ablate.sh, tools/variants.sh; 1024 gates, Set A):
-//   EOC_ACC_REGS  register copy of the accumulator next to the LDS copy the rotation reads: -1.7 %  (on)
-//   (removed) loading all key rows after the transforms: 178 VGPRs but +12 % time; the partner's rows issued at
-//   the start or mid-transform as well: no gain, spills
-#ifndef EOC_ACC_REGS
-#define EOC_ACC_REGS 1
-#endif
-//   (touching a slice of the NEXT step's key rows one step ahead, to pre-load each XCD's L2: 0 %, removed -- the
-//    lockstep penalty of a chip-filling launch is the arbiter's unfairness below, not L2 misses)
+
+// mixed batches in arbitrary opcode order: rows are gathered into opcode-sorted order, evaluated run by
+// run, and scattered back.  perm[i] = original index of the i-th gate in sorted order.
+// grid: x = rows, y = ceil(rowlen / 256)
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                                                     const uint32_t *__restrict__ perm, int rowlen, int scatter)
+{
+    const int m = blockIdx.y * 256 + threadIdx.x;
+    if (m >= rowlen) return;
+    const size_t i = blockIdx.x, j = perm[i];
+    if (scatter) dst[j * rowlen + m] = src[i * rowlen + m];
+    else dst[i * rowlen + m] = src[j * rowlen + m];
+}
+
+
+// Tuning notes kept from measured experiments (round 1: tools/ablate.sh, tools/variants.sh; 1024 gates, Set A):
+//   register copy of the accumulator next to the LDS copy the rotation reads: -1.7 %  (kept: racc[])
 //   EOC_PRIO_ALT  wave-priority alternation between the two waves sharing a SIMD (see the loop): steps per phase
 //                 (power of two; 0 compiles it out).  Single-round launches: -10 % (l = 2) / -13 % (l = 3) at
 //                 EOC_PRIO_DUTY = 11..12 sixteenths and 1 step per phase (8 steps: -8 %, 16: -6 %); level 1, 2, 3 alike.
@@ -581,27 +500,10 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #ifndef EOC_PRIO_HI
 #define EOC_PRIO_HI 1
 #endif
-//   (a feedback form -- waves publish their step counters by physical slot, the one behind takes the priority --
-//    gave -7 % on a single round, less than the fixed duty, and as a tail balancer for launches of a few rounds
-//    -5 % at exactly 2 rounds, 0 % beyond 4 and on the circuit workloads, +5 % at 1.5 rounds; a phase-dependent priority inside the step cost +6..20 %; both removed)
-//   gadget length 3 (Set B): all three digit transforms skewed on one scratch: -7 % against pair + single (kept)
-//   gadget length 2: the partner's partial spectrum is produced and stored first: -1.3 % (kept);
-//   EOC_L3_THEIRS_FIRST the same order for gadget length 3: -0.4 %, within the noise                      (off)
-#ifndef EOC_L3_THEIRS_FIRST
-#define EOC_L3_THEIRS_FIRST 0
-#endif
-//   (requesting the inverse transform's twiddles / un-twist factors one pass early was measured too: 0 %, removed)
-//   (removed) de-phasing the workgroups that share a CU by start-up sleeps: 0 %, before and after the priority fix
 //   the step's rotation amount (bara[i]) is loaded one step ahead, so no load is waited for at the step top: -1 % (kept)
-//   (one own key row issued before the forward transforms' last pass: 0 %, 3.756 vs 3.766 ms, removed)
-//   (removed) forward twiddle sets loaded once per skewed pair/triple, ahead of the other transform's
-//                 transpose (7-14 fewer ds_read_b128 per step): +1.5 % (l = 2) / +9.7 % (l = 3) -- the 28 extra
-//                 live registers spill, and every scratch reload is an s_waitcnt vmcnt(0) that also waits for
-//                 the key rows in flight
-//   (removed) sched_barriers that force the hand-written skew order: +12 %.  The compiler's own order
-//                 (both register passes of a pair back to back = 16 independent FMA chains, then both
-//                 transposes) is faster than strict skew: FP64 dependent-issue latency (about 11 cycles)
-//                 matters more than the LDS round trip, which the second wave on the SIMD covers
+//   measured and rejected in round 1: staggering the workgroups of a CU, feedback priorities, touching the next step's
+//   key rows early, sched_barriers that pin the skew order, a one-wave-per-ciphertext form (k_blind_rotate_t, removed
+//   in round 2: slower at every size).
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -619,28 +521,17 @@ __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__
 #define EOC_STAMP(k) do { } while (0)
 #endif
 
-// mixed batches in arbitrary opcode order: rows are gathered into opcode-sorted order, evaluated run by
-// run, and scattered back.  perm[i] = original index of the i-th gate in sorted order.
-// grid: x = rows, y = ceil(rowlen / 256)
-__global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__ src, int32_t *__restrict__ dst,
-                                                     const uint32_t *__restrict__ perm, int rowlen, int scatter)
-{
-    const int m = blockIdx.y * 256 + threadIdx.x;
-    if (m >= rowlen) return;
-    const size_t i = blockIdx.x, j = perm[i];
-    if (scatter) dst[j * rowlen + m] = src[i * rowlen + m];
-    else dst[i * rowlen + m] = src[j * rowlen + m];
-}
-
 // =================================================================================================
 // K2: blind rotate + sample extract.  One workgroup = 4 waves = 2 ciphertexts; wave pair (h = 0,1)
 // of a ciphertext: wave h owns accumulator polynomial h, decomposes it, runs the l forward
-// transforms of its digits, multiplies by rows (h, p) of BK_i for BOTH output polynomials, hands the
-// partial spectrum of the other polynomial to its partner through LDS, and runs the inverse
-// transform of its own.
+// transforms of its digits, multiplies them by rows (h, p) of BK_i for the OTHER output polynomial and hands
+// that partial chain to its partner through LDS; it then continues the chain it received from the partner with
+// its own digits (rows (h, p), output polynomial h), runs the inverse transform of the sum and updates ACC_h.
+// Accumulation order of output polynomial c (canonical, oracle/tfhe_oracle.c): terms (q_in = 1 - c, p = 1..l)
+// first, then (q_in = c, p = 1..l); first term a product, every later one four fused multiply-adds.
 // =================================================================================================
 struct BRArgs {
-    const double *bkfft;  // [n][2l][2][512] complex, bin order sigma
+    const double *bkfft;  // [n][2l][2][512] complex, bin order sigma, scaled by 2^-9
     const uint16_t *bara; // [jobs][stride], entry n = barb
     int32_t *u;           // [jobs][N+1]
     uint32_t njobs;
@@ -650,7 +541,7 @@ struct BRArgs {
     int prio_duty;              // < 0: leave wave priorities alone; else see the loop (single-round launches)
 };
 
-constexpr int kBRLds = (kTwEntries + kNH + 4 * kScr) * 16 + 4 * kN * 4; // bytes
+constexpr int kBRLds = (kTwEntries + kNH + 4 * kScr) * 16 + 4 * kN * 4; // 70 144 bytes: two workgroups per CU
 
 // BGBIT > 0: gadget base known at compile time (digit extraction becomes one bit-field extract); 0: run time
 template <int L, int BGBIT = 0>
@@ -675,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     if (!valid) job = A.njobs - 1; // idle pair shadows the last job, keeps barriers matched
     const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
 
-    load_tables(s_tw, s_twist, g_tw, g_twist, tid);
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid, 256);
 
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
     {
@@ -692,13 +583,15 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     __syncthreads();
 
     const int Bgbit = BGBIT > 0 ? BGBIT : A.Bgbit;
-    const uint32_t maskBg = (1u << Bgbit) - 1, halfBg = 1u << (Bgbit - 1);
+    const uint32_t Bg = 1u << Bgbit, maskBg = Bg - 1, halfBg = Bg >> 1;
     uint32_t offset = 0;
 #pragma unroll
     for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
     constexpr int KPL = 2 * L;
     const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
-    const double digit_bias = 4503599627370496.0 + (double)halfBg;
+    // digits arrive biased, u = digit + Bg/2 in [0, Bg); as_double(2^52 | u) - (2^52 + Bg/2) is the digit, exactly;
+    // the stage-0 sums p - q and p + q are formed on the biased integers and converted the same way
+    const double bias1 = 4503599627370496.0 + (double)halfBg, bias2 = 4503599627370496.0 + (double)Bg;
 
 #ifdef EOC_STAMPS
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -707,14 +600,12 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     st_acc[14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: CU / SE / SIMD / wave slot
     st_acc[13] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
 #endif
-#if EOC_ACC_REGS
     uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8: low half)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         racc[r] = (uint32_t)acc[lane + 64 * r];
         racc[8 + r] = (uint32_t)acc[lane + 64 * r + kNH];
     }
-#endif
 #if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 #endif
@@ -752,17 +643,10 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             uint32_t v1 = (uint32_t)acc[i1 & (kN - 1)];
             v0 = (i0 & kN) ? 0u - v0 : v0;
             v1 = (i1 & kN) ? 0u - v1 : v1;
-#if EOC_ACC_REGS
             dlo[r] = v0 - racc[r] + offset;
             dhi[r] = v1 - racc[8 + r] + offset;
-#else
-            dlo[r] = v0 - (uint32_t)acc[j] + offset;
-            dhi[r] = v1 - (uint32_t)acc[j + kNH] + offset;
-#endif
         }
         EOC_STAMP(0);
-        // mine[] accumulates output polynomial h (kept by this wave), theirs[] polynomial 1-h
-        d2 mine[8], theirs[8];
         const d2 *rows_i = bk + ((size_t)i * KPL + h * L) * 2 * kNH; // rows (h, p), p = 1..L
         auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
             const d2 *src = rows_i + ((size_t)(p - 1) * 2 + c) * kNH;
@@ -776,16 +660,20 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #endif
             }
         };
-        auto make_x = [&](int p, d2 (&x)[8]) __attribute__((always_inline)) {
+        // digit p of the 16 coefficients of this lane, first pass of its forward transform (stages 0-2)
+        auto make_x0 = [&](int p, d2 (&x)[8]) __attribute__((always_inline)) {
             const int shift = 32 - p * Bgbit;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                // digit in [0, Bg) placed in the low mantissa bits of 2^52, minus (2^52 + Bg/2): exact
-                uint32_t ul = (dlo[r] >> shift) & maskBg, uh = (dhi[r] >> shift) & maskBg;
-                d2 v = {__hiloint2double(0x43300000, (int)ul) - digit_bias,
-                        __hiloint2double(0x43300000, (int)uh) - digit_bias};
-                x[r] = cmul(v, s_twist[lane + 64 * r]);
+            for (int r = 0; r < 4; r++) {
+                const uint32_t ua = (dlo[r] >> shift) & maskBg, ub = (dhi[r] >> shift) & maskBg;
+                const uint32_t up = (dlo[r + 4] >> shift) & maskBg, uq = (dhi[r + 4] >> shift) & maskBg;
+                const double a = __hiloint2double(0x43300000, (int)ua) - bias1;
+                const double b = __hiloint2double(0x43300000, (int)ub) - bias1;
+                const double dm = __hiloint2double(0x43300000, (int)(up - uq + Bg)) - bias2;
+                const double dp = __hiloint2double(0x43300000, (int)(up + uq)) - bias2;
+                fwd_stage0(x[r], x[r + 4], a, b, dm, dp);
             }
+            fwd_pass0_tail(x);
         };
         auto mac = [&](bool first, const d2 (&x)[8], const d2 (&b)[8], d2 (&acc_)[8]) __attribute__((always_inline)) {
 #pragma unroll
@@ -799,128 +687,60 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 }
             }
         };
-        // digits are transformed two at a time (skewed schedule on one scratch), an odd last one alone
-        auto pair_pass = [&](auto pc) __attribute__((always_inline)) {
-            constexpr int p = decltype(pc)::value;
-            d2 ba[8], bb[8], xa[8], xb[8];
-            // l = 2: the rows loaded early (under the transforms) are the PARTNER's, so that its partial spectrum is
-            // finished and stored first and the own accumulation runs while that store lands (-1.3 %)
-            const int first = L == 2 ? 1 - h : h;
-            load_row(p, first, ba);
-            load_row(p + 1, first, bb);
-            make_x(p, xa);
-            make_x(p + 1, xb);
-            EOC_STAMP(1);
-            fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
-            EOC_STAMP(2);
-            if constexpr (L == 2) {
-                mac(true, xa, ba, theirs);
-                mac(false, xb, bb, theirs);
-                load_row(p, h, ba); // the own rows re-use the same registers
-                load_row(p + 1, h, bb);
+        // forward transforms of the l digits (two at a time, skewed on the one scratch; an odd last one alone) and
+        // the chain for the partner's output polynomial.  The spectra stay in registers for the own chain below.
+        d2 xs[L][8], ra[8], rb[8], S[8];
 #pragma unroll
-                for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
-                mac(true, xa, ba, mine);
-                mac(false, xb, bb, mine);
-            } else {
-                mac(p == 1, xa, ba, mine);
-                mac(false, xb, bb, mine);
-                load_row(p, 1 - h, ba);
-                load_row(p + 1, 1 - h, bb);
-                mac(p == 1, xa, ba, theirs);
-                mac(false, xb, bb, theirs);
-            }
-            EOC_STAMP(3);
-        };
-        auto single_pass = [&](auto pc) __attribute__((always_inline)) {
-            constexpr int p = decltype(pc)::value;
-            d2 bm[8], bt[8], x[8];
-            load_row(p, h, bm);
-            load_row(p, 1 - h, bt);
-            make_x(p, x);
+        for (int p0 = 0; p0 + 1 < L; p0 += 2) {
+            load_row(p0 + 1, 1 - h, ra);
+            load_row(p0 + 2, 1 - h, rb);
+            make_x0(p0 + 1, xs[p0]);
             EOC_STAMP(1);
-            fft_fwd_wave(x, s_tw, scr, lane);
+            fft_fwd_rest_x2(xs[p0], xs[p0 + 1], [&]() __attribute__((always_inline)) { make_x0(p0 + 2, xs[p0 + 1]); },
+                            s_tw, scr, lane);
             EOC_STAMP(2);
-            mac(p == 1, x, bm, mine);
-            mac(p == 1, x, bt, theirs);
+            mac(p0 == 0, xs[p0], ra, S);
+            mac(false, xs[p0 + 1], rb, S);
             EOC_STAMP(3);
-        };
-        auto triple_pass = [&]() __attribute__((always_inline)) { // L == 3: all three digits skewed on one scratch
-            d2 ba[8], bb[8], xa[8], xb[8], xc[8];
-            make_x(1, xa);
-            make_x(2, xb);
-            make_x(3, xc);
-#if EOC_L3_THEIRS_FIRST
-            load_row(1, 1 - h, ba);
-            load_row(2, 1 - h, bb);
-            EOC_STAMP(1);
-            fft_fwd_wave_x3(xa, xb, xc, s_tw, scr, lane);
-            EOC_STAMP(2);
-            mac(true, xa, ba, theirs);
-            mac(false, xb, bb, theirs);
-            load_row(3, 1 - h, ba);
-            load_row(1, h, bb);
-            mac(false, xc, ba, theirs);
-#pragma unroll
-            for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
-            mac(true, xa, bb, mine);
-            load_row(2, h, ba);
-            load_row(3, h, bb);
-            mac(false, xb, ba, mine);
-            mac(false, xc, bb, mine);
-#else
-            load_row(1, h, ba);
-            load_row(2, h, bb);
-            EOC_STAMP(1);
-            fft_fwd_wave_x3(xa, xb, xc, s_tw, scr, lane);
-            EOC_STAMP(2);
-            mac(true, xa, ba, mine);
-            mac(false, xb, bb, mine);
-            load_row(3, h, ba);
-            load_row(1, 1 - h, bb);
-            mac(false, xc, ba, mine);
-            mac(true, xa, bb, theirs);
-            load_row(2, 1 - h, ba);
-            load_row(3, 1 - h, bb);
-            mac(false, xb, ba, theirs);
-            mac(false, xc, bb, theirs);
-#endif
-            EOC_STAMP(3);
-        };
-        if constexpr (L == 1) single_pass(std::integral_constant<int, 1>{});
-        if constexpr (L == 3) triple_pass();
-        if constexpr (L == 2 || L == 4) pair_pass(std::integral_constant<int, 1>{});
-        if constexpr (L == 4) pair_pass(std::integral_constant<int, 3>{});
-        // hand the other polynomial's partial spectrum to the partner wave (l = 2 stored it already)
-        if constexpr (L != 2 && !(L == 3 && EOC_L3_THEIRS_FIRST)) {
-#pragma unroll
-            for (int r = 0; r < 8; r++) scr[r * 64 + lane] = theirs[r];
         }
+        if constexpr ((L & 1) != 0) {
+            load_row(L, 1 - h, ra);
+            make_x0(L, xs[L - 1]);
+            EOC_STAMP(1);
+            fft_fwd_rest(xs[L - 1], s_tw, scr, lane);
+            EOC_STAMP(2);
+            mac(L == 1, xs[L - 1], ra, S);
+            EOC_STAMP(3);
+        }
+        // own rows: the first two are requested before the exchange
+        load_row(1, h, ra);
+        if constexpr (L >= 2) load_row(2, h, rb);
+#pragma unroll
+        for (int r = 0; r < 8; r++) scr[r * 64 + lane] = S[r];
         EOC_STAMP(4);
         EOC_SYNC();
         EOC_STAMP(5);
-        d2 x[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) // S = part(q_in=0) + part(q_in=1); IEEE addition commutes
-            x[r] = mine[r] + scr_partner[r * 64 + lane];
+        for (int r = 0; r < 8; r++) S[r] = scr_partner[r * 64 + lane]; // the chain of the other input polynomial
+        mac(false, xs[0], ra, S);
+        if constexpr (L >= 3) load_row(3, h, ra);
+        if constexpr (L >= 2) mac(false, xs[1], rb, S);
+        if constexpr (L >= 4) load_row(4, h, rb);
+        if constexpr (L >= 3) mac(false, xs[2], ra, S);
+        if constexpr (L >= 4) mac(false, xs[3], rb, S);
         EOC_STAMP(6);
-        EOC_SYNC();
+        EOC_SYNC(); // the partner has read this wave's scratch before the inverse transform overwrites it
         EOC_STAMP(7);
-        fft_inv_wave(x, s_tw, scr, lane);
+        fft_inv_wave(S, s_tw, scr, lane);
         EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
-            d2 y = cmulc(x[r], s_twist[j]); // (1/512) * 2^-32 is in the key image
-#if EOC_ACC_REGS
-            racc[r] += wrap_round_scaled(y.x); // the key image carries 2^-41 = (1/512) * 2^-32
-            racc[8 + r] += wrap_round_scaled(y.y);
+            d2 y = cmulc(S[r], s_twist[j]); // 1/512 is in the key image
+            racc[r] += wrap_trunc(y.x);
+            racc[8 + r] += wrap_trunc(y.y);
             acc[j] = (int32_t)racc[r];
             acc[j + kNH] = (int32_t)racc[8 + r];
-#else
-            acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round_scaled(y.x));
-            acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round_scaled(y.y));
-#endif
         }
         wave_lds_fence();
         EOC_STAMP(9);
@@ -944,201 +764,6 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             u[kN] = acc[0];
         }
     }
-}
-
-// =================================================================================================
-// K2t: blind rotate, throughput form for LARGE launches (circuits, mixed batches: >= 2 waves per SIMD are
-// available from the job count alone).  One ciphertext = ONE wave: no partner exchange, no barriers in the
-// loop; the wave transforms the digits of polynomial 0, then of polynomial 1 (each pair skewed on the one
-// scratch), and runs the two inverse transforms as a skewed pair as well.  Same arithmetic, same
-// accumulation order (S_c = chain(q_in = 0) + chain(q_in = 1)) as k_blind_rotate: bit-identical results.
-// Workgroup = 512 threads = 8 ciphertexts; LDS = tables + 8 x (2 accumulator polynomials + scratch).
-// MEASURED SLOWER than the pair form at every size tried (255 k vs 296 k bootstraps/s on 131 072 mixed gates),
-// so the engine never selects it by itself (EOC_TFHE_BR_MODE=2 forces it); kept as a tested alternative.
-// =================================================================================================
-constexpr int kBRTLds = (kTwEntries + kNH + 8 * kScr) * 16 + 8 * 2 * kN * 4; // 162 560 bytes
-
-template <int L, int BGBIT = 0>
-__global__ __launch_bounds__(512, 2) void k_blind_rotate_t(BRArgs A, const d2 *__restrict__ g_tw,
-                                                           const d2 *__restrict__ g_twist)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    d2 *s_tw = reinterpret_cast<d2 *>(smem);
-    d2 *s_twist = s_tw + kTwEntries;
-    d2 *s_scr_all = s_twist + kNH;
-    int32_t *s_acc_all = reinterpret_cast<int32_t *>(s_scr_all + 8 * kScr);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    d2 *scr = s_scr_all + w * kScr;
-    int32_t *acc = s_acc_all + w * 2 * kN; // [2][N]
-
-    for (int i = tid; i < kTwEntries; i += 512) s_tw[i] = g_tw[i];
-    for (int i = tid; i < kNH; i += 512) s_twist[i] = g_twist[i];
-    __syncthreads();
-    const uint32_t job = blockIdx.x * 8 + w;
-    if (job >= A.njobs) return; // no barrier below: idle waves simply leave
-    const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
-    {
-        const int barb = bara[A.n];
-        const int rot = (2 * kN - barb) & (2 * kN - 1);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int j = lane + 64 * r;
-            int idx = (j - rot) & (2 * kN - 1);
-            acc[j] = 0;
-            acc[kN + j] = (idx & kN) ? -A.mu : A.mu;
-        }
-    }
-    wave_lds_fence();
-
-    const int Bgbit = BGBIT > 0 ? BGBIT : A.Bgbit;
-    const uint32_t maskBg = (1u << Bgbit) - 1, halfBg = 1u << (Bgbit - 1);
-    uint32_t offset = 0;
-#pragma unroll
-    for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
-    constexpr int KPL = 2 * L;
-    const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
-    const double digit_bias = 4503599627370496.0 + (double)halfBg;
-
-    for (int i = 0; i < A.n; i++) {
-        const int abar = __builtin_amdgcn_readfirstlane((int)bara[i]);
-        d2 S0[8], S1[8]; // output spectra, accumulated as chain(q_in = 0) + chain(q_in = 1)
-        auto poly_pass = [&](auto hc) __attribute__((always_inline)) {
-            constexpr int hp = decltype(hc)::value; // input polynomial q_in
-            const int32_t *a = acc + hp * kN;
-            uint32_t dlo[8], dhi[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                int j = lane + 64 * r;
-                int i0 = (j - abar) & (2 * kN - 1);
-                int i1 = (j + kNH - abar) & (2 * kN - 1);
-                uint32_t v0 = (uint32_t)a[i0 & (kN - 1)];
-                uint32_t v1 = (uint32_t)a[i1 & (kN - 1)];
-                v0 = (i0 & kN) ? 0u - v0 : v0;
-                v1 = (i1 & kN) ? 0u - v1 : v1;
-                dlo[r] = v0 - (uint32_t)a[j] + offset;
-                dhi[r] = v1 - (uint32_t)a[j + kNH] + offset;
-            }
-            const d2 *rows = bk + ((size_t)i * KPL + hp * L) * 2 * kNH; // rows (hp, p), p = 1..L
-            auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
-                const d2 *src = rows + ((size_t)(p - 1) * 2 + c) * kNH;
-#pragma unroll
-                for (int r = 0; r < 8; r++) b[r] = src[r * 64 + lane];
-            };
-            auto make_x = [&](int p, d2 (&x)[8]) __attribute__((always_inline)) {
-                const int shift = 32 - p * Bgbit;
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    uint32_t ul = (dlo[r] >> shift) & maskBg, uh = (dhi[r] >> shift) & maskBg;
-                    d2 v = {__hiloint2double(0x43300000, (int)ul) - digit_bias,
-                            __hiloint2double(0x43300000, (int)uh) - digit_bias};
-                    x[r] = cmul(v, s_twist[lane + 64 * r]);
-                }
-            };
-            auto mac = [&](bool first, const d2 (&x)[8], const d2 (&b)[8], d2 (&acc_)[8]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    if (first) {
-                        acc_[r].x = EOC_FMA(-x[r].y, b[r].y, x[r].x * b[r].x);
-                        acc_[r].y = EOC_FMA(x[r].y, b[r].x, x[r].x * b[r].y);
-                    } else {
-                        acc_[r].x = EOC_FMA(-x[r].y, b[r].y, EOC_FMA(x[r].x, b[r].x, acc_[r].x));
-                        acc_[r].y = EOC_FMA(x[r].y, b[r].x, EOC_FMA(x[r].x, b[r].y, acc_[r].y));
-                    }
-                }
-            };
-            // chain over the digits of this polynomial for output c, then folded into S_c
-            auto fold = [&](d2 (&S)[8], const d2 (&Q)[8]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    if (hp == 0) S[r] = Q[r];
-                    else S[r] = S[r] + Q[r];
-                }
-            };
-            d2 ba[8], bb[8], Q[8];
-            if constexpr (L == 1) {
-                d2 x[8];
-                load_row(1, 0, ba);
-                make_x(1, x);
-                fft_fwd_wave(x, s_tw, scr, lane);
-                mac(true, x, ba, Q);
-                fold(S0, Q);
-                load_row(1, 1, ba);
-                mac(true, x, ba, Q);
-                fold(S1, Q);
-            } else {
-                d2 xa[8], xb[8];
-                load_row(1, 0, ba);
-                load_row(2, 0, bb);
-                make_x(1, xa);
-                make_x(2, xb);
-                fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
-                if constexpr (L == 2) {
-                    mac(true, xa, ba, Q);
-                    mac(false, xb, bb, Q);
-                    fold(S0, Q);
-                    load_row(1, 1, ba);
-                    load_row(2, 1, bb);
-                    mac(true, xa, ba, Q);
-                    mac(false, xb, bb, Q);
-                    fold(S1, Q);
-                } else { // L = 3 or 4: the remaining digit(s) after the first pair
-                    d2 Q1[8];
-                    mac(true, xa, ba, Q);
-                    mac(false, xb, bb, Q);
-                    load_row(1, 1, ba);
-                    load_row(2, 1, bb);
-                    mac(true, xa, ba, Q1);
-                    mac(false, xb, bb, Q1);
-                    if constexpr (L == 3) {
-                        load_row(3, 0, ba);
-                        load_row(3, 1, bb);
-                        make_x(3, xa);
-                        fft_fwd_wave(xa, s_tw, scr, lane);
-                        mac(false, xa, ba, Q);
-                        mac(false, xa, bb, Q1);
-                    } else {
-                        load_row(3, 0, ba);
-                        load_row(4, 0, bb);
-                        make_x(3, xa);
-                        make_x(4, xb);
-                        fft_fwd_wave_x2(xa, xb, s_tw, scr, lane);
-                        mac(false, xa, ba, Q);
-                        mac(false, xb, bb, Q);
-                        load_row(3, 1, ba);
-                        load_row(4, 1, bb);
-                        mac(false, xa, ba, Q1);
-                        mac(false, xb, bb, Q1);
-                    }
-                    fold(S0, Q);
-                    fold(S1, Q1);
-                }
-            }
-        };
-        poly_pass(std::integral_constant<int, 0>{});
-        poly_pass(std::integral_constant<int, 1>{});
-        fft_inv_wave_x2(S0, S1, s_tw, scr, lane);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int j = lane + 64 * r;
-            d2 tw_ = s_twist[j];
-            d2 y0 = cmulc(S0[r], tw_), y1 = cmulc(S1[r], tw_); // (1/512) * 2^-32 is in the key image
-            acc[j] = (int32_t)((uint32_t)acc[j] + wrap_round_scaled(y0.x));
-            acc[j + kNH] = (int32_t)((uint32_t)acc[j + kNH] + wrap_round_scaled(y0.y));
-            acc[kN + j] = (int32_t)((uint32_t)acc[kN + j] + wrap_round_scaled(y1.x));
-            acc[kN + j + kNH] = (int32_t)((uint32_t)acc[kN + j + kNH] + wrap_round_scaled(y1.y));
-        }
-        wave_lds_fence();
-    }
-    // tLweExtractLweSample, index 0
-    int32_t *u = A.u + (size_t)job * (kN + 1);
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        int j = lane + 64 * r;
-        u[j] = j == 0 ? acc[0] : (int32_t)(0u - (uint32_t)acc[kN - j]);
-    }
-    if (lane == 0) u[kN] = acc[kN];
 }
 
 // =================================================================================================

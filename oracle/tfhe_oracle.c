@@ -208,45 +208,58 @@ int orc_decrypt_bit(const orc_params *p, const int32_t *lwe_key, const int32_t *
 }
 
 /* ------------------------------------------------------------------------------------------
- * Canonical transform v2 (SURVEY.md A.7 gives the maths).
+ * Canonical transform v3 (SURVEY.md A.7 gives the maths).
  *
  * Replaces upstream IntPolynomial_ifft / TorusPolynomial_ifft / TorusPolynomial_fft (SURVEY.md
  * 8a a8,a10; the nayuki-portable FFT the reference selects in config.yml:22-26).  The upstream
- * butterfly order is unknowable here, so this repo owns the data-flow graph.  W[k] = E[4k] =
- * exp(2 pi i k / 512).  Every butterfly multiplies BEFORE it adds, which allows the 6-operation
- * fused form (Linzer-Feig):
+ * butterfly order is unknowable here, so this repo owns the data-flow graph.  E[k] = exp(2 pi i k / 2048)
+ * (canon_twiddles.h, correctly rounded, E[k+512] = i E[k] exactly), zeta = E[1], W[k] = E[4k].
+ * Every butterfly multiplies BEFORE it adds, which allows the 6-operation fused form (Linzer-Feig):
  *
  *     a' = u + w v :  a'.re = fma(-w.im, v.im, fma(w.re, v.re, u.re))
  *                     a'.im = fma( w.re, v.im, fma(w.im, v.re, u.im))
  *     b' = u - w v =  2u - a' :  b' = fma(2, u, -a')           (component-wise)
- *     in the three register-constant stages (forward 0,1,2; inverse 8,7,6) w = 1 and w = i are exact moves:
- *     w = 1 -> (u + v, u - v);  w = i -> t = (-v.im, v.re), (u + t, u - t)  (conj(i): t = (v.im, -v.re));
- *     all other stages use the fused form for every twiddle (conjugate twiddle: w.im negated)
  *
- *   forward:  c_j = (p_j + i p_{j+512}) * E[j]                       (twist, j < 512)
- *             9 stages s = 0..8, h = 256 >> s, evaluation tree of X^512 - 1 (natural order in,
- *             bit-reversed frequency out): for i with (i & h) == 0,
- *               (u, v) = (x_i, x_{i+h}),  w = W[bitrev8(i >> (9 - s))],  (x_i, x_{i+h}) = (u + w v, u - w v)
- *             output bin e (= frequency bitrev9(e)) is stored at sigma(e) = (e & 7)*64 + (e >> 3)
+ *   forward (integer polynomial p -> 512 complex values p(zeta^(4m+1))): NO twist pass.  With
+ *             c_j = p_j + i p_{j+512} the wanted values are the evaluations of sum_j c_j X^j at the roots of
+ *             X^512 - i, so the evaluation tree of X^512 - i is walked directly (natural order in,
+ *             bit-reversed root index out):  9 stages s = 0..8, h = 256 >> s, block b = i >> (9 - s),
+ *               rho(s, b) = E[(256 + 1024 bitrev_s(b)) >> s],  (x_i, x_{i+h}) = (u + rho v, u - rho v).
+ *             Stage 0 has the single root rho = e^{i pi/4} = (c, c), c = E[256].re, and integer inputs
+ *             u = (a, b), v = (p, q); it is written on the exact integer sums dm = p - q, dp = p + q:
+ *               x_j = (fma(c, dm, a), fma(c, dp, b)),  x_{j+256} = (fma(-c, dm, a), fma(-c, dp, b)).
+ *             Stages 1..8 use the fused form for every root.
+ *             Output bin e (root zeta^(4 bitrev9(e) + 1)) is stored at sigma(e) = (e & 7)*64 + (e >> 3).
  *   inverse:  stages s = 8..0 (decimation in time, bit-reversed in, natural out), h = 256 >> s:
- *               (u, v) = (x_i, x_{i+h}),  w = conj(W[(i mod h) << s]),  (x_i, x_{i+h}) = (u + w v, u - w v)
- *             y_j = x_j * conj(E[j]) / 512;  p_j = rint(Re y_j), p_{j+512} = rint(Im y_j), wrapped
- *   twist products are   re = fma(a.re, b.re, -(a.im*b.im)),  im = fma(a.re, b.im, a.im*b.re)
- *   (untwist: re = fma(a.re, b.re, a.im*b.im),  im = fma(a.im, b.re, -(a.re*b.im))).
+ *               (u, v) = (x_i, x_{i+h}),  w = conj(W[(i mod h) << s]),  (x_i, x_{i+h}) = (u + w v, u - w v);
+ *             in the three register-constant stages 8,7,6 w = 1 and w = conj(i) are exact moves:
+ *               w = 1 -> (u + v, u - v);  w = conj(i) -> t = (v.im, -v.re), (u + t, u - t);
+ *             y_j = x_j * conj(E[j]) / 512:  re = fma(x.re, t.re, x.im*t.im),  im = fma(x.im, t.re, -(x.re*t.im))
+ *             with t = E[j]/512 (exact scaling);  p_j = Torus32(int64(Re y_j)), p_{j+512} = Torus32(int64(Im y_j)):
+ *             TRUNCATION toward zero, then wrap -- the conversion of upstream's TorusPolynomial_fft
+ *             (SURVEY.md 8a a10 / A.7).  v2 of this repo rounded to nearest; ORC_ROUND_NEAREST=1 in the
+ *             environment selects that again (named, non-default mode, for A/B noise measurements only).
  * ---------------------------------------------------------------------------------------- */
 static inline int sigma_of(int e) { return ((e & 7) << 6) | (e >> 3); }
-static inline int bitrev8(int b)
+static inline int bitrev_n(int b, int bits)
 {
     int r = 0;
-    for (int k = 0; k < 8; k++) r |= ((b >> k) & 1) << (7 - k);
+    for (int k = 0; k < bits; k++) r |= ((b >> k) & 1) << (bits - 1 - k);
     return r;
 }
 
-/* (u, v) -> (u + w v, u - w v), w = W[k] (conj = 0) or conj(W[k]) (conj = 1).
- * `moves`: this stage applies w = 1 and w = i as exact moves (the three register-constant stages:
- * forward 0,1,2 and inverse 8,7,6); every other stage uses the fused form for EVERY twiddle, also
- * where the table value happens to be 1 or i, because that is what a lane-uniform kernel executes. */
-static inline __attribute__((always_inline)) void butterfly(double *ur, double *ui, double *vr, double *vi, int k, int conj, int moves)
+/* (u, v) -> (u + w v, u - w v) in the fused form, w = (wr, wi) */
+static inline __attribute__((always_inline)) void butterfly_w(double *ur, double *ui, double *vr, double *vi, double wr, double wi)
+{
+    double ar = FMA(-wi, *vi, FMA(wr, *vr, *ur));
+    double ai = FMA(wr, *vi, FMA(wi, *vr, *ui));
+    *vr = FMA(2.0, *ur, -ar);
+    *vi = FMA(2.0, *ui, -ai);
+    *ur = ar; *ui = ai;
+}
+
+/* inverse butterfly with w = conj(W[k]); `moves`: stages 8,7,6 apply w = 1 and w = conj(i) as exact moves */
+static inline __attribute__((always_inline)) void butterfly_inv(double *ur, double *ui, double *vr, double *vi, int k, int moves)
 {
     double ar, ai;
     if (moves && k == 0) {
@@ -255,42 +268,35 @@ static inline __attribute__((always_inline)) void butterfly(double *ur, double *
         *ur = ar; *ui = ai;
         return;
     }
-    if (moves && k == 128) { /* w = i or -i */
-        double tr = conj ? *vi : -*vi, ti = conj ? -*vr : *vr;
+    if (moves && k == 128) { /* w = conj(i) */
+        double tr = *vi, ti = -*vr;
         ar = *ur + tr; ai = *ui + ti;
         *vr = *ur - tr; *vi = *ui - ti;
         *ur = ar; *ui = ai;
         return;
     }
-    double wr = EOC_E2048[4 * k][0], wi = conj ? -EOC_E2048[4 * k][1] : EOC_E2048[4 * k][1];
-    ar = FMA(-wi, *vi, FMA(wr, *vr, *ur));
-    ai = FMA(wr, *vi, FMA(wi, *vr, *ui));
-    *vr = FMA(2.0, *ur, -ar);
-    *vi = FMA(2.0, *ui, -ai);
-    *ur = ar; *ui = ai;
+    butterfly_w(ur, ui, vr, vi, EOC_E2048[4 * k][0], -EOC_E2048[4 * k][1]);
 }
 
 void orc_fft_fwd(const int32_t *poly, double *spec)
 {
     double xr[NH], xi[NH];
-    for (int j = 0; j < NH; j++) {
+    const double c = EOC_E2048[256][0];
+    for (int j = 0; j < 256; j++) { /* stage 0 on exact integer sums */
         double a = (double)poly[j], b = (double)poly[j + NH];
-        double tc = EOC_E2048[j][0], ts = EOC_E2048[j][1];
-        xr[j] = FMA(a, tc, -(b * ts));
-        xi[j] = FMA(a, ts, b * tc);
+        double pp = (double)poly[j + 256], q = (double)poly[j + 256 + NH];
+        double dm = pp - q, dp = pp + q; /* exact: |.| <= 2^32 */
+        xr[j] = FMA(c, dm, a);
+        xi[j] = FMA(c, dp, b);
+        xr[j + 256] = FMA(-c, dm, a);
+        xi[j + 256] = FMA(-c, dp, b);
     }
-    for (int s = 0; s < 3; s++) { /* register-constant stages: w = 1, i are moves */
+    for (int s = 1; s < 9; s++) {
         int h = 256 >> s;
         for (int blk = 0; blk < (1 << s); blk++) {
-            int k = bitrev8(blk), base = blk * 2 * h;
-            for (int i = base; i < base + h; i++) butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], k, 0, 1);
-        }
-    }
-    for (int s = 3; s < 9; s++) { /* fused form for every twiddle */
-        int h = 256 >> s;
-        for (int blk = 0; blk < (1 << s); blk++) {
-            int k = bitrev8(blk), base = blk * 2 * h;
-            for (int i = base; i < base + h; i++) butterfly(&xr[i], &xi[i], &xr[i + h], &xi[i + h], k, 0, 0);
+            int k = (256 + 1024 * bitrev_n(blk, s)) >> s, base = blk * 2 * h;
+            double wr = EOC_E2048[k][0], wi = EOC_E2048[k][1];
+            for (int i = base; i < base + h; i++) butterfly_w(&xr[i], &xi[i], &xr[i + h], &xi[i + h], wr, wi);
         }
     }
     for (int e = 0; e < NH; e++) {
@@ -299,38 +305,48 @@ void orc_fft_fwd(const int32_t *poly, double *spec)
     }
 }
 
-static inline int32_t wrap_round(double x)
+static int g_round_nearest = -1; /* ORC_ROUND_NEAREST=1: v2's conversion (non-default, diagnostics) */
+static double g_max_abs_conv = 0.0; /* largest |value| ever converted (tests check it stays < 2^51) */
+double orc_dbg_max_conv(int reset)
 {
-    double r = rint(x);
-    return (int32_t)(uint32_t)(uint64_t)(int64_t)r;
+    double v = g_max_abs_conv;
+    if (reset) g_max_abs_conv = 0.0;
+    return v;
+}
+static inline int32_t wrap_convert(double x)
+{
+    if (g_round_nearest) x = rint(x);
+    return (int32_t)(uint32_t)(uint64_t)(int64_t)x; /* C cast: truncation toward zero */
 }
 
 void orc_fft_inv(const double *spec, int32_t *poly)
 {
     double xr[NH], xi[NH];
+    if (g_round_nearest < 0) {
+        const char *m = getenv("ORC_ROUND_NEAREST");
+        g_round_nearest = (m && m[0] == '1') ? 1 : 0;
+    }
     for (int e = 0; e < NH; e++) {
         xr[e] = spec[2 * sigma_of(e)];
         xi[e] = spec[2 * sigma_of(e) + 1];
     }
-    for (int s = 8; s >= 6; s--) { /* register-constant stages: w = 1, conj(i) are moves */
+    for (int s = 8; s >= 0; s--) {
         int h = 256 >> s;
         for (int base = 0; base < NH; base += 2 * h)
             for (int j = 0; j < h; j++)
-                butterfly(&xr[base + j], &xi[base + j], &xr[base + j + h], &xi[base + j + h], j << s, 1, 1);
+                butterfly_inv(&xr[base + j], &xi[base + j], &xr[base + j + h], &xi[base + j + h], j << s, s >= 6);
     }
-    for (int s = 5; s >= 0; s--) { /* fused form for every twiddle */
-        int h = 256 >> s;
-        for (int base = 0; base < NH; base += 2 * h)
-            for (int j = 0; j < h; j++)
-                butterfly(&xr[base + j], &xi[base + j], &xr[base + j + h], &xi[base + j + h], j << s, 1, 0);
-    }
+    double mx = 0.0;
     for (int j = 0; j < NH; j++) {
         double tc = EOC_E2048[j][0] * 0.001953125, ts = EOC_E2048[j][1] * 0.001953125;
         double re = FMA(xr[j], tc, xi[j] * ts);
         double im = FMA(xi[j], tc, -(xr[j] * ts));
-        poly[j] = wrap_round(re);
-        poly[j + NH] = wrap_round(im);
+        if (fabs(re) > mx) mx = fabs(re);
+        if (fabs(im) > mx) mx = fabs(im);
+        poly[j] = wrap_convert(re);
+        poly[j + NH] = wrap_convert(im);
     }
+    if (mx > g_max_abs_conv) g_max_abs_conv = mx; /* benign race between threads: a diagnostic high-water mark */
 }
 
 /* tGswToFFTConvert (keygen side): every BK polynomial through the forward map */
@@ -405,9 +421,11 @@ static inline uint32_t decomp_offset(int l, int Bgbit)
 }
 
 /* tfhe_MuxRotate_FFT + tLweAddTo: acc += BK_i (x) ((X^a - 1) acc).
- * FFT path: tGswFFTExternMulToTLwe with this repo's canonical accumulation order
- *   S_c = [chain over p for q_in = 0] + [chain over p for q_in = 1],
- * first term of a chain as a plain product, later terms as 4 fused multiply-adds.
+ * FFT path: tGswFFTExternMulToTLwe with this repo's canonical accumulation order (v3): output polynomial c is ONE
+ * chain over the 2l (q_in, p) terms, the digits of the OTHER input polynomial (q_in = 1 - c, p = 1..l) first, then
+ * the own ones (q_in = c); first term a plain product (2 mul + 2 fma), every later term 4 fused multiply-adds.
+ * (This is the order in which a wave pair of the HIP kernel produces it: the partner's partial chain arrives
+ * through LDS and the own terms are accumulated onto it.)
  * Exact path (use_fft = 0): the same external product as a schoolbook negacyclic
  * convolution mod 2^32 -- the mathematical definition the FFT path approximates. */
 void orc_blind_rotate_step(const orc_params *p, const double *bkfft_i, const int32_t *bk_i,
@@ -421,36 +439,37 @@ void orc_blind_rotate_step(const orc_params *p, const double *bkfft_i, const int
             diff[q][j] = (int32_t)((uint32_t)rot_coef(acc + q * N, a, j) - (uint32_t)acc[q * N + j]);
 
     if (use_fft) {
-        static _Thread_local double part[2][2][N]; /* [q_in][c][512 complex] */
-        double D[N];
+        static _Thread_local double D[2][4][N]; /* [q_in][p-1][512 complex]: spectra of the digit polynomials */
         int32_t dec[N];
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < 2; q++)
             for (int pp = 1; pp <= l; pp++) {
-                int row = q * l + (pp - 1);
                 for (int j = 0; j < N; j++) dec[j] = decomp_digit((uint32_t)diff[q][j], off, pp, Bgbit);
-                orc_fft_fwd(dec, D);
-                for (int c = 0; c < 2; c++) {
-                    const double *B = bkfft_i + ((size_t)row * 2 + c) * N;
-                    double *P = part[q][c];
-                    for (int e = 0; e < NH; e++) {
-                        double dr = D[2 * e], di = D[2 * e + 1], br = B[2 * e], bi = B[2 * e + 1];
-                        if (pp == 1) {
-                            P[2 * e] = FMA(-di, bi, dr * br);
-                            P[2 * e + 1] = FMA(di, br, dr * bi);
-                        } else {
-                            double r = FMA(dr, br, P[2 * e]);
-                            P[2 * e] = FMA(-di, bi, r);
-                            double im = FMA(dr, bi, P[2 * e + 1]);
-                            P[2 * e + 1] = FMA(di, br, im);
-                        }
-                    }
-                }
+                orc_fft_fwd(dec, D[q][pp - 1]);
             }
-        }
         for (int c = 0; c < 2; c++) {
             double S[N];
             int32_t r[N];
-            for (int e = 0; e < N; e++) S[e] = part[0][c][e] + part[1][c][e];
+            int first = 1;
+            for (int qq = 0; qq < 2; qq++) {
+                int q = qq == 0 ? 1 - c : c; /* the other input polynomial's digits first, then the own ones */
+                for (int pp = 1; pp <= l; pp++) {
+                    const double *B = bkfft_i + ((size_t)(q * l + (pp - 1)) * 2 + c) * N;
+                    const double *X = D[q][pp - 1];
+                    for (int e = 0; e < NH; e++) {
+                        double dr = X[2 * e], di = X[2 * e + 1], br = B[2 * e], bi = B[2 * e + 1];
+                        if (first) {
+                            S[2 * e] = FMA(-di, bi, dr * br);
+                            S[2 * e + 1] = FMA(di, br, dr * bi);
+                        } else {
+                            double re = FMA(dr, br, S[2 * e]);
+                            S[2 * e] = FMA(-di, bi, re);
+                            double im = FMA(dr, bi, S[2 * e + 1]);
+                            S[2 * e + 1] = FMA(di, br, im);
+                        }
+                    }
+                    first = 0;
+                }
+            }
             orc_fft_inv(S, r);
             for (int j = 0; j < N; j++) acc[c * N + j] = (int32_t)((uint32_t)acc[c * N + j] + (uint32_t)r[j]);
         }

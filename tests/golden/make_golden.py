@@ -4,7 +4,7 @@
     python tests/golden/make_golden.py
 
 PARITY UNPINNED: the reference holds no golden vector for gate bootstrapping and upstream libtfhe
-is absent, so these vectors pin THIS repo's oracle (canonical transform v1, PRNG v1)
+is absent, so these vectors pin THIS repo's oracle (canonical transform v3, PRNG v1)
 against regressions and pin the GPU path to it; they are not outputs of the reference.
 Fixtures are data only: seeds, inputs, expected outputs, SHA-256 of the large arrays.
 """
@@ -28,7 +28,7 @@ def sha(a):
 
 def main():
     L = ol.lib()
-    g = {"version": {"transform": "canonical-v2", "prng": "splitmix-ctr-v1"}}
+    g = {"version": {"transform": "canonical-v3", "prng": "splitmix-ctr-v1"}}
     # PRNG / scalar KATs
     g["prng"] = {
         "stream_key(1,3,5)": str(L.orc_stream_key(1, 3, 5)),

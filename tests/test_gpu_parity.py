@@ -104,7 +104,7 @@ def test_keygen_and_bkfft_parity(eoc, rig_small):
     assert np.array_equal(r.sk.ksk, r.orc.ksk)
     d_bk, d_ksk = r.eng.cloud_key_device()
     got = r.eng.download(d_bk, r.eng.bkfft_bytes, np.float64).reshape(r.orc.bkfft.shape)
-    assert np.array_equal(got, r.orc.bkfft * 2.0**-41)  # the image carries 1/512 and 2^-32 (exact scaling)
+    assert np.array_equal(got, r.orc.bkfft * 2.0**-9)  # the image carries 1/512 (exact scaling)
     # KSK device image: [N*t][base-1][n1p], padding zero
     p = r.p
     base, n1p = 1 << p.ks_basebit, (p.n + 1 + 255) // 256 * 256
