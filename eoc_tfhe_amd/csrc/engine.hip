@@ -424,10 +424,10 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     a.bara_stride = e->bara_stride;
     a.mu = (int32_t)(1u << 29);
     a.stamps = e->d_stamps;
-    // priority alternation pays only when every workgroup is resident from the start (two per CU)
+    // priority alternation pays only when every workgroup is resident from the start (four per CU)
     a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
-                  : ((njobs + 1) / 2 <= 2u * (uint32_t)e->num_cus ? EOC_PRIO_DUTY : -1);
-    dim3 grid((njobs + 1) / 2), block(256);
+                  : (njobs <= 4u * (uint32_t)e->num_cus ? EOC_PRIO_DUTY : -1);
+    dim3 grid(njobs), block(128);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
     if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
         hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);

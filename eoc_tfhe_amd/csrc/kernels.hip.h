@@ -161,8 +161,13 @@ __device__ __forceinline__ void fwd_pass0_tail(d2 (&x)[8])
 // the four loaded twiddles of a table-driven pass; `stride` = 8 (pass 1, q = table + (lane >> 3)) or 64 (pass 2)
 __device__ __forceinline__ void tw_load(d2 (&t)[4], const d2 *q, int stride)
 {
+#ifdef EOC_ABL_NOTW
+    (void)q; (void)stride;
+    for (int k = 0; k < 4; k++) t[k] = d2{0.7 + 0.01 * k, 0.7 - 0.01 * k};
+#else
 #pragma unroll
     for (int k = 0; k < 4; k++) t[k] = q[k * stride];
+#endif
 }
 __device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[4])
 { // three radix-2 stages on the 8 register points: twiddles A | B0, i B0 | C0, i C0, C2, i C2
@@ -183,29 +188,37 @@ __device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[4])
 // execute in issue order, so a later write to the same scratch cannot overtake an earlier read.
 __device__ __forceinline__ void t01_write(const d2 (&x)[8], d2 *scr, int lane)
 {
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * r + lane] = x[r];
     wave_lds_fence();
+#endif
 }
 __device__ __forceinline__ void t01_read(d2 (&x)[8], const d2 *scr, int lane)
 {
+#ifndef EOC_ABL_NOTRANSPOSE
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * hi + 8 * r + lo];
     wave_lds_fence();
+#endif
 }
 __device__ __forceinline__ void t12_write(const d2 (&x)[8], d2 *scr, int lane)
 {
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(hi * 64 + r * 8 + lo)] = x[r];
     wave_lds_fence();
+#endif
 }
 __device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
 {
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(lane * 8 + r)];
     wave_lds_fence();
+#endif
 }
 
 // one forward transform after its first pass: x[] in L0 (stages 0-2 done) -> x[] in L2
@@ -226,25 +239,92 @@ __device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, 
 // are requested early, and each transform's LDS round trip is issued so that it runs under the other's register pass.
 // LDS issue order: w01(a) r01(a) w01(b) r01(b) w12(a) r12(a) w12(b) r12(b); a register pass waits only for its own
 // read (counted lgkmcnt), which works because no twiddle read sits between a transpose read and its use.
+// EOC_PIN_SKEW: scheduling barriers that pin the phase order below (the machine scheduler otherwise sinks the early
+// twiddle reads under the transposes and waits for BOTH transposes before the first register pass)
+#ifndef EOC_PIN_SKEW
+#define EOC_PIN_SKEW 1
+#endif
+#if EOC_PIN_SKEW
+#define EOC_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define EOC_SB() do { } while (0)
+#endif
+// EOC_ILV: the stores of one transform's transpose are interleaved one by one with the other transform's register pass
+// (sched_group_barrier pipelines): a ds_write_b128 holds the CU's LDS store path for about 13 cycles, and a wave that
+// issues eight of them back to back is issue-blocked for all of them (SQ_WAIT_INST_LDS was 22 % of the wave cycles)
+#ifndef EOC_ILV
+#define EOC_ILV 1
+#endif
+#define EOC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+#define EOC_M_VALU 0x002
+#define EOC_M_DSR 0x100
+#define EOC_M_DSW 0x200
 template <class MakeB>
 __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, const d2 *tw, d2 *scr, int lane)
 {
     d2 t1[4], t2[4];
+    EOC_SB();
+    // region B: first pass of b, a's stores spread through it; then a's reads
     tw_load(t1, tw + kTwF1 + (lane >> 3), 8);
+    wave_lds_fence();
     t01_write(xa, scr, lane);
     make_b();
     t01_read(xa, scr, lane);
+#if EOC_ILV
+    EOC_SGB(EOC_M_DSR, 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 10);
+    }
+    EOC_SGB(EOC_M_VALU, 64);
+    EOC_SGB(EOC_M_DSR, 8);
+#endif
+    EOC_SB();
+    // region C: second pass of a; b's stores spread through its first half, then b's reads and the last twiddle set
     t01_write(xb, scr, lane);
     t01_read(xb, scr, lane);
     tw_load(t2, tw + kTwF2 + lane, 64);
     wave_lds_fence();
     fwd_pass12(xa, t1);
+#if EOC_ILV
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 4);
+    }
+    EOC_SGB(EOC_M_DSR, 12);
+    EOC_SGB(EOC_M_VALU, 40);
+#endif
+    EOC_SB();
+    // region D: second pass of b under a's second transpose
     t12_write(xa, scr, lane);
     t12_read(xa, scr, lane);
     fwd_pass12(xb, t1);
+#if EOC_ILV
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 4);
+    }
+    EOC_SGB(EOC_M_DSR, 8);
+    EOC_SGB(EOC_M_VALU, 40);
+#endif
+    EOC_SB();
+    // region E: third pass of a under b's second transpose
     t12_write(xb, scr, lane);
     t12_read(xb, scr, lane);
     fwd_pass12(xa, t2);
+#if EOC_ILV
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 4);
+    }
+    EOC_SGB(EOC_M_DSR, 8);
+    EOC_SGB(EOC_M_VALU, 40);
+#endif
+    EOC_SB();
     fwd_pass12(xb, t2);
 }
 
@@ -283,42 +363,65 @@ __device__ __forceinline__ void inv_pass10(d2 (&x)[8], const d2 (&t)[4])
 }
 __device__ __forceinline__ void t21_write(const d2 (&x)[8], d2 *scr, int lane)
 {
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
     wave_lds_fence();
+#endif
 }
 __device__ __forceinline__ void t21_read(d2 (&x)[8], const d2 *scr, int lane)
 {
+#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
+#endif
 }
 __device__ __forceinline__ void t10_write(const d2 (&x)[8], d2 *scr, int lane)
 {
+#ifndef EOC_ABL_NOTRANSPOSE
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = x[r];
     wave_lds_fence();
+#endif
 }
 __device__ __forceinline__ void t10_read(d2 (&x)[8], const d2 *scr, int lane)
 {
+#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
     wave_lds_fence();
+#endif
 }
-__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
+// inverse transform + un-twist factors: the twiddles of both table passes and the 8 un-twist factors are requested
+// under the first transpose, so that no table read sits between a transpose read and its use
+#ifndef EOC_PIN_INV
+#define EOC_PIN_INV 1
+#endif
+#if EOC_PIN_INV
+#define EOC_SBI() __builtin_amdgcn_sched_barrier(0)
+#else
+#define EOC_SBI() do { } while (0)
+#endif
+__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *tw, const d2 *s_twist, d2 *scr, int lane)
 {
     d2 t1[4], t0[4];
+    EOC_SBI();
     tw_load(t1, tw + kTwI1 + (lane & 7), 8);
     inv_pass2(x);
     t21_write(x, scr, lane);
     t21_read(x, scr, lane);
     tw_load(t0, tw + kTwI0 + lane, 64);
+#pragma unroll
+    for (int r = 0; r < 8; r++) ut[r] = s_twist[lane + 64 * r];
     wave_lds_fence();
+    EOC_SBI();
     inv_pass10(x, t1);
     t10_write(x, scr, lane);
     t10_read(x, scr, lane);
+    EOC_SBI();
     inv_pass10(x, t0);
 }
 
@@ -388,12 +491,13 @@ __global__ __launch_bounds__(256) void k_fft_inv_polys(const double *__restrict_
     d2 x[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = in[r * 64 + lane];
-    fft_inv_wave(x, s_tw, s_scr[w], lane);
+    d2 ut[8];
+    fft_inv_wave(x, ut, s_tw, s_twist, s_scr[w], lane);
     int32_t *p = polys + poly * kN;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         int j = lane + 64 * r;
-        d2 y = cmulc(x[r], s_twist[j] * 0x1p-9);
+        d2 y = cmulc(x[r], ut[r] * 0x1p-9);
         p[j] = (int32_t)wrap_trunc(y.x);
         p[j + kNH] = (int32_t)wrap_trunc(y.y);
     }
@@ -495,7 +599,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 #define EOC_PRIO_ALT 1
 #endif
 #ifndef EOC_PRIO_DUTY
-#define EOC_PRIO_DUTY 12
+#define EOC_PRIO_DUTY 11
 #endif
 #ifndef EOC_PRIO_HI
 #define EOC_PRIO_HI 1
@@ -522,8 +626,9 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 #endif
 
 // =================================================================================================
-// K2: blind rotate + sample extract.  One workgroup = 4 waves = 2 ciphertexts; wave pair (h = 0,1)
-// of a ciphertext: wave h owns accumulator polynomial h, decomposes it, runs the l forward
+// K2: blind rotate + sample extract.  One workgroup = ONE ciphertext = a wave pair (h = 0,1), four workgroups per
+// CU (35.6 KB of LDS each), so that s_barrier couples only the two waves that exchange data (with two ciphertexts per
+// workgroup the barriers cost 6 % of the launch).  Wave h owns accumulator polynomial h, decomposes it, runs the l forward
 // transforms of its digits, multiplies them by rows (h, p) of BK_i for the OTHER output polynomial and hands
 // that partial chain to its partner through LDS; it then continues the chain it received from the partner with
 // its own digits (rows (h, p), output polynomial h), runs the inverse transform of the sum and updates ACC_h.
@@ -541,43 +646,47 @@ struct BRArgs {
     int prio_duty;              // < 0: leave wave priorities alone; else see the loop (single-round launches)
 };
 
-constexpr int kBRLds = (kTwEntries + kNH + 4 * kScr) * 16 + 4 * kN * 4; // 70 144 bytes: two workgroups per CU
+// LDS: the two tables + one 9 KB scratch per wave.  Between two steps the scratch holds the accumulator polynomial of
+// its wave as a signed 2N-periodic image ext[k] = ACC[k], ext[k + N] = -ACC[k] (8 KB), which turns the negacyclic
+// rotation of the next step into plain reads at (k - abar) mod 2N; the transposes of the step then overwrite it (one
+// wave's LDS operations execute in order, and only the owning wave ever touches the image).
+constexpr int kBRLds = (kTwEntries + kNH + 2 * kScr) * 16; // 35 584 bytes: four workgroups per CU
 
 // BGBIT > 0: gadget base known at compile time (digit extraction becomes one bit-field extract); 0: run time
 template <int L, int BGBIT = 0>
-__global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__restrict__ g_tw,
+__global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__restrict__ g_tw,
                                                          const d2 *__restrict__ g_twist)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     d2 *s_tw = reinterpret_cast<d2 *>(smem);
     d2 *s_twist = s_tw + kTwEntries;
     d2 *s_scr_all = s_twist + kNH;
-    int32_t *s_acc_all = reinterpret_cast<int32_t *>(s_scr_all + 4 * kScr);
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = w & 1;
-    d2 *scr = s_scr_all + w * kScr;
-    d2 *scr_partner = s_scr_all + (w ^ 1) * kScr;
-    int32_t *acc = s_acc_all + w * kN;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    d2 *scr = s_scr_all + h * kScr;
+    d2 *scr_partner = s_scr_all + (h ^ 1) * kScr;
+    int32_t *ext = reinterpret_cast<int32_t *>(scr); // [2N] signed periodic image of ACC_h (between steps)
 
-    uint32_t job = blockIdx.x * 2 + (w >> 1);
-    const bool valid = job < A.njobs;
-    if (!valid) job = A.njobs - 1; // idle pair shadows the last job, keeps barriers matched
+    const uint32_t job = blockIdx.x; // grid = number of jobs
     const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
 
-    load_tables(s_tw, s_twist, g_tw, g_twist, tid, 256);
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid, 128);
 
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
+    uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8), lane + 64 r + 512 in racc[8 + r]
     {
         const int barb = bara[A.n];
         const int rot = (2 * kN - barb) & (2 * kN - 1);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            int j = lane + 64 * r;
+            int j = lane + 64 * (r & 7) + (r >> 3) * kNH;
             int idx = (j - rot) & (2 * kN - 1);
             int32_t v = (idx & kN) ? -A.mu : A.mu;
-            acc[j] = h ? v : 0;
+            v = h ? v : 0;
+            racc[r] = (uint32_t)v;
+            ext[j] = v;
+            ext[j + kN] = -v;
         }
     }
     __syncthreads();
@@ -600,12 +709,6 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     st_acc[14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: CU / SE / SIMD / wave slot
     st_acc[13] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
 #endif
-    uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8: low half)
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        racc[r] = (uint32_t)acc[lane + 64 * r];
-        racc[8 + r] = (uint32_t)acc[lane + 64 * r + kNH];
-    }
 #if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 #endif
@@ -634,17 +737,15 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
         // zero update, which is what skipping the step (as libtfhe does) amounts to.
         uint32_t dlo[8], dhi[8];
+        {
+            const int k = (lane - abar) & (2 * kN - 1);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int j = lane + 64 * r;
-            int i0 = (j - abar) & (2 * kN - 1);
-            int i1 = (j + kNH - abar) & (2 * kN - 1);
-            uint32_t v0 = (uint32_t)acc[i0 & (kN - 1)];
-            uint32_t v1 = (uint32_t)acc[i1 & (kN - 1)];
-            v0 = (i0 & kN) ? 0u - v0 : v0;
-            v1 = (i1 & kN) ? 0u - v1 : v1;
-            dlo[r] = v0 - racc[r] + offset;
-            dhi[r] = v1 - racc[8 + r] + offset;
+            for (int r = 0; r < 8; r++) {
+                const uint32_t v0 = (uint32_t)ext[(k + 64 * r) & (2 * kN - 1)];
+                const uint32_t v1 = (uint32_t)ext[(k + 64 * r + kNH) & (2 * kN - 1)];
+                dlo[r] = v0 - racc[r] + offset;
+                dhi[r] = v1 - racc[8 + r] + offset;
+            }
         }
         EOC_STAMP(0);
         const d2 *rows_i = bk + ((size_t)i * KPL + h * L) * 2 * kNH; // rows (h, p), p = 1..L
@@ -731,16 +832,19 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(6);
         EOC_SYNC(); // the partner has read this wave's scratch before the inverse transform overwrites it
         EOC_STAMP(7);
-        fft_inv_wave(S, s_tw, scr, lane);
+        d2 ut[8];
+        fft_inv_wave(S, ut, s_tw, s_twist, scr, lane);
         EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             int j = lane + 64 * r;
-            d2 y = cmulc(S[r], s_twist[j]); // 1/512 is in the key image
+            d2 y = cmulc(S[r], ut[r]); // 1/512 is in the key image
             racc[r] += wrap_trunc(y.x);
             racc[8 + r] += wrap_trunc(y.y);
-            acc[j] = (int32_t)racc[r];
-            acc[j + kNH] = (int32_t)racc[8 + r];
+            ext[j] = (int32_t)racc[r];
+            ext[j + kN] = (int32_t)(0u - racc[r]);
+            ext[j + kNH] = (int32_t)racc[8 + r];
+            ext[j + kNH + kN] = (int32_t)(0u - racc[8 + r]);
         }
         wave_lds_fence();
         EOC_STAMP(9);
@@ -748,20 +852,20 @@ __global__ __launch_bounds__(256, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #ifdef EOC_STAMPS
     st_acc[11] = __builtin_amdgcn_s_memtime(); // loop exit time
     if (A.stamps && lane == 0)
-        for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * 4 + w) * 16 + k] = st_acc[k];
+        for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * 2 + h) * 16 + k] = st_acc[k];
 #endif
 
-    // tLweExtractLweSample, index 0
-    if (valid) {
+    // tLweExtractLweSample, index 0: u_0 = ACC_0[0], u_j = -ACC_0[N - j] = ext[2N - j]; b = ACC_1[0]
+    {
         int32_t *u = A.u + (size_t)job * (kN + 1);
         if (h == 0) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int j = lane + 64 * r;
-                u[j] = j == 0 ? acc[0] : (int32_t)(0u - (uint32_t)acc[kN - j]);
+                u[j] = ext[(2 * kN - j) & (2 * kN - 1)];
             }
         } else if (lane == 0) {
-            u[kN] = acc[0];
+            u[kN] = ext[0];
         }
     }
 }

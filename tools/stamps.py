@@ -20,7 +20,7 @@ eng = eoc.Engine(p)
 eng.load_cloud_key(sk)
 L = eoc.lib()
 L.eoc_dbg_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
-waves = (G + 1) // 2 * 4
+waves = G * 2
 bits = np.random.default_rng(0).integers(0, 2, G)
 c0 = torch.from_numpy(sk.encrypt_bits(bits, 2, 0)).cuda()
 c1 = torch.from_numpy(sk.encrypt_bits(bits, 3, 0)).cuda()
@@ -46,13 +46,13 @@ for k in sorted(names):
 # per-workgroup loop durations: a launch ends with its slowest workgroup
 dur = (meta[:, 0].astype(np.int64) - meta[:, 1].astype(np.int64)).astype(np.float64)   # exit - entry
 t0 = meta[:, 1].astype(np.int64)
-wg = dur.reshape(-1, 4).max(axis=1)
-start = (t0.reshape(-1, 4).min(axis=1) - t0.min()).astype(np.float64)
+wg = dur.reshape(-1, 2).max(axis=1)
+start = (t0.reshape(-1, 2).min(axis=1) - t0.min()).astype(np.float64)
 end = start + wg
 print(f"workgroup loop duration [cycles]: min {wg.min():.0f}  mean {wg.mean():.0f}  max {wg.max():.0f}  (max/mean = {wg.max() / wg.mean():.3f})")
 print(f"loop entry spread: {start.max():.0f} cycles;  last exit at {end.max():.0f};  mean exit at {end.mean():.0f}")
-xcc = (meta[:, 2] & 0xF).reshape(-1, 4)[:, 0]
-hw = meta[:, 3].reshape(-1, 4)[:, 0]
+xcc = (meta[:, 2] & 0xF).reshape(-1, 2)[:, 0]
+hw = meta[:, 3].reshape(-1, 2)[:, 0]
 cu = (hw >> 8) & 0xF
 sh = (hw >> 12) & 0x1
 se = (hw >> 13) & 0x7
