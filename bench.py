@@ -12,8 +12,11 @@ data-path collective); the cloud key is built once on rank 0 and RCCL-broadcast 
 before the timed region.
 
 Prints ONE JSON line (rank 0).  Extra keys:
-  roofline     -- dominant kernel (k_blind_rotate): algorithmic BK-FFT stream bytes per launch
-                  divided by the HIP-event duration measured in this run, against 8 TB/s HBM
+  roofline     -- dominant kernel (k_blind_rotate), bound = FP64 vector issue: SURVEY.md 8(d)'s algorithmic flops per
+                  blind rotation x jobs per launch / the HIP-event duration measured in this run, against the 78.6
+                  TFLOP/s datasheet peak.  The algorithmic HBM figure (every gate streams the whole BK-FFT) and the
+                  measured fabric traffic are secondary keys: batched execution serves BK from L2, so HBM is not
+                  the bound and the algorithmic byte rate is not a fraction of anything
   cpu_baseline -- the CPU oracle (a port: restatement of the reference algorithm, upstream libtfhe
                   is absent) on a bounded sample of the same batch, on the host cores
 """
@@ -35,6 +38,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PSETS = {"A": 0, "B": 1}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # datasheet FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz)
+FP64_SUSTAINED_TFLOPS = 62.0  # pure v_fma_f64 loop, tools/fp64_issue_bench.hip: the clock drops under FP64 load
+
+
+def algorithmic_flops(p):
+    """FP64 flops per blind rotation = n x [(kpl + k + 1) folded 512-point complex FFTs at 5 N log2 N
+    = 23 040 flop plus a 3 072-flop twist each, plus kpl (k+1) 512 complex multiply-adds at 8 flop].
+    Set A: 189 440 x 500 = 94.7 Mflop; Set B: 258 048 x 630 = 162.6 Mflop."""
+    kpl = 2 * p.l
+    per_step = (kpl + 2) * (23040 + 3072) + kpl * 2 * 512 * 8
+    return p.n * per_step
 
 
 def algorithmic_bytes(p):
@@ -58,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer API (H2D + D2H included)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workload lines (adder8 / streq32 / mixed)")
     ap.add_argument("--workload", default="nand", choices=["nand", "adder8", "streq32", "mixed"],
                     help="nand = BASELINE configs[1] (headline); adder8 / streq32 / mixed = configs[2] / [4] / [3] "
                          "shapes on this rank's shard (secondary lines, same metric)")
@@ -125,62 +140,69 @@ def main():
     def step():
         eng.gate_batch_device(op, d0.data_ptr(), d1.data_ptr(), None, dout.data_ptr(), G, stream=stream)
 
-    boots_per_step = G
-    workload_desc = None
-    circuit_check = None
-    if args.workload != "nand":
+    def make_workload(name, instances):
+        """(step, bootstraps per step, description, check) of a secondary workload on this rank's shard"""
         from eoc_tfhe_amd import circuits
         wrng = np.random.default_rng(7000 + rank)
-        if args.workload in ("adder8", "streq32"):
-            if args.workload == "adder8":
-                S = args.instances or 4096 // max(1, world) or 1
+        if name in ("adder8", "streq32"):
+            if name == "adder8":
+                S = instances or 4096 // max(1, world) or 1
                 gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8)
                 A, B = wrng.integers(0, 256, S), wrng.integers(0, 256, S)
                 bits_in = {aw[0]: ((A[:, None] >> np.arange(8)) & 1), bw[0]: ((B[:, None] >> np.arange(8)) & 1)}
-                workload_desc = f"8-bit ripple-carry add, {S} input pairs per GPU (BASELINE configs[2])"
+                desc = (f"8-bit ripple-carry add, {S} input pairs per GPU (BASELINE configs[2]); "
+                        f"{eoc.circuit_bootstraps(gates)} bootstraps per pair (half adder at bit 0; BASELINE.md counts 40)")
             else:
-                S = args.instances or 1024 // max(1, world) or 1
+                S = instances or 1024 // max(1, world) or 1
                 gates, n_wires, xw, yw, outw = circuits.string_equal(32)
                 X = wrng.integers(32, 127, (S, 32)).astype(np.uint8)
                 Y = X.copy()
                 Y[1::2, 0] ^= 1
                 bits_in = {xw[0]: np.unpackbits(X, axis=1, bitorder="little"),
                            yw[0]: np.unpackbits(Y, axis=1, bitorder="little")}
-                workload_desc = f"ASCII string equality, {S} pairs of 32-byte strings per GPU (BASELINE configs[4])"
+                desc = f"ASCII string equality, {S} pairs of 32-byte strings per GPU (BASELINE configs[4])"
             wires = torch.zeros((n_wires, S, n + 1), dtype=torch.int32, device=dev)
             for w0, bb in bits_in.items():
                 planes = np.stack([sk.encrypt_bits(bb[:, i].astype(np.uint8), 9000 + w0 + i, 0) for i in range(bb.shape[1])])
                 wires[w0: w0 + bb.shape[1]] = torch.from_numpy(planes).to(dev)
-            boots_per_step = eoc.circuit_bootstraps(gates) * S
+            boots = eoc.circuit_bootstraps(gates) * S
 
-            def step():  # noqa: F811
+            def wstep():
                 eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S, stream=stream)
 
-            if args.workload == "adder8":
-                def circuit_check():
+            if name == "adder8":
+                def check():
                     sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
                     tot = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
                     return bool(np.array_equal(tot, A + B))
             else:
-                def circuit_check():
+                def check():
                     return bool(np.array_equal(sk.decrypt_bits(wires[outw].cpu().numpy()), (X == Y).all(axis=1)))
-        else:  # mixed: NAND / XOR / MUX in arbitrary order (the engine groups equal opcodes on the device)
-            S = args.instances or (1 << 20) // 8
-            mops = wrng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), S)
-            mb = [wrng.integers(0, 2, S).astype(np.uint8) for _ in range(3)]
-            mc = [torch.from_numpy(sk.encrypt_bits(mb[k], 9500 + k, 0)).to(dev) for k in range(3)]
-            mout = torch.empty_like(mc[0])
-            boots_per_step = S + int((mops == eoc.OPS["MUX"]).sum())
-            workload_desc = f"{S} mixed NAND/XOR/MUX gates per GPU (BASELINE configs[3] shard), MUX = 2 bootstraps"
+            return wstep, boots, desc, check
+        # mixed: NAND / XOR / MUX in arbitrary order (the engine groups equal opcodes on the device)
+        S = instances or (1 << 20) // 8
+        mops = wrng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), S)
+        mb = [wrng.integers(0, 2, S).astype(np.uint8) for _ in range(3)]
+        mc = [torch.from_numpy(sk.encrypt_bits(mb[k], 9500 + k, 0)).to(dev) for k in range(3)]
+        mout = torch.empty_like(mc[0])
+        boots = S + int((mops == eoc.OPS["MUX"]).sum())
+        desc = f"{S} mixed NAND/XOR/MUX gates per GPU (BASELINE configs[3] shard), MUX = 2 bootstraps"
 
-            def step():  # noqa: F811
-                eng.gate_batch_device(0, mc[0].data_ptr(), mc[1].data_ptr(), mc[2].data_ptr(), mout.data_ptr(), S,
-                                      ops=mops, stream=stream)
+        def wstep():
+            eng.gate_batch_device(0, mc[0].data_ptr(), mc[1].data_ptr(), mc[2].data_ptr(), mout.data_ptr(), S,
+                                  ops=mops, stream=stream)
 
-            def circuit_check():
-                want = np.where(mops == eoc.OPS["NAND"], 1 - (mb[0] & mb[1]),
-                                np.where(mops == eoc.OPS["XOR"], mb[0] ^ mb[1], np.where(mb[0] == 1, mb[1], mb[2])))
-                return bool(np.array_equal(sk.decrypt_bits(mout.cpu().numpy()), want))
+        def check():
+            want = np.where(mops == eoc.OPS["NAND"], 1 - (mb[0] & mb[1]),
+                            np.where(mops == eoc.OPS["XOR"], mb[0] ^ mb[1], np.where(mb[0] == 1, mb[1], mb[2])))
+            return bool(np.array_equal(sk.decrypt_bits(mout.cpu().numpy()), want))
+        return wstep, boots, desc, check
+
+    boots_per_step = G
+    workload_desc = None
+    circuit_check = None
+    if args.workload != "nand":
+        step, boots_per_step, workload_desc, circuit_check = make_workload(args.workload, args.instances)
 
     # pre-flight (set-up, untimed, not one of the W warm-up steps): the key images just built/received are
     # exercised twice so that a bad broadcast or key load fails here, before anything is measured
@@ -233,25 +255,19 @@ def main():
         br_ms = br["ms"] / max(1, br["launches"])
         ks_ms = kt["keyswitch"]["ms"] / max(1, kt["keyswitch"]["launches"])
         pr_ms = kt["prepare"]["ms"] / max(1, kt["prepare"]["launches"])
-        # BK-FFT stream + bara in + extracted sample out, per blind-rotate job; launches differ in size for
-        # circuits, so use the jobs the engine counted over the timed region
+        # launches differ in size for circuits, so use the jobs the engine counted over the timed region
         jobs_per_launch = boots_per_step * args.steps / max(1, br["launches"])
+        flop_job = algorithmic_flops(p)
+        tf = flop_job * jobs_per_launch / (br_ms * 1e-3) / 1e12 if br_ms > 0 else 0.0
+        # secondary: the algorithmic HBM figure (BK-FFT stream + bara in + extracted sample out per job) and the
+        # measured fabric traffic of the same launch (profiles/traffic.json, rocprofv3 PMC, FETCH_SIZE doubled)
         br_bytes = int((bk_b + (n + 1) * 2 + 1025 * 4) * jobs_per_launch)
-        achieved = br_bytes / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
-        # secondary, and the meaningful one for this kernel: FP64 vector issue.  flop per blind-rotate job from the
-        # rocprofv3 instruction mix of profiles/r01_final_pmc_summary.txt (fma = 2 flop): (2*643 + 188 + 82)e6 * 64 / 1024
-        fp64_flop_per_job = {"A": 97.25e6}.get(args.pset)
-        fp64 = None
-        if fp64_flop_per_job and br_ms > 0:
-            tf = fp64_flop_per_job * jobs_per_launch / (br_ms * 1e-3) / 1e12
-            fp64 = {"achieved": round(tf, 2), "peak_measured": 62.0, "peak_spec": 78.6, "unit": "TFLOP/s",
-                    "frac_of_measured_peak": round(tf / 62.0, 3),
-                    "note": "peak_measured = pure v_fma_f64 loop, tools/fp64_issue_bench.hip (clock drops under FP64 load)"}
+        hbm_alg = br_bytes / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "nand":
             try:
-                traffic = json.load(open(tpath)).get(f"blind_rotate_{args.pset}_{G}") if args.workload == "nand" else None
+                traffic = json.load(open(tpath)).get(f"blind_rotate_{args.pset}_{G}")
             except Exception:
                 traffic = None
         res = {
@@ -275,24 +291,63 @@ def main():
                        "key_broadcast_s": round(t_bcast, 4)},
             "decrypt_ok": decrypt_ok,
             "kernels_ms": {"prepare": round(pr_ms, 4), "blind_rotate": round(br_ms, 4), "keyswitch": round(ks_ms, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_blind_rotate", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic,
-                         "bytes_per_launch": br_bytes, "avg_launch_ms": round(br_ms, 4), "fp64_valu": fp64,
-                         "note": "algorithmic bytes = every gate streams the whole BK-FFT once; the batch "
-                                 "re-uses BK slices from L2/Infinity Cache so measured HBM traffic is far lower "
-                                 "and the kernel is FP64-VALU/LDS bound (DESIGN.md)"},
+            "roofline": {"bound": "fp64_valu", "kernel": "k_blind_rotate", "achieved": round(tf, 2),
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                         "traffic": traffic, "traffic_unit": "HBM/fabric bytes per launch (rocprofv3 PMC)",
+                         "flop_per_job": flop_job, "jobs_per_launch": round(jobs_per_launch, 1),
+                         "avg_launch_ms": round(br_ms, 4),
+                         "peak_sustained": FP64_SUSTAINED_TFLOPS,
+                         "frac_of_sustained": round(tf / FP64_SUSTAINED_TFLOPS, 4),
+                         "hbm_algorithmic": {"bytes_per_launch": br_bytes, "GBps": round(hbm_alg, 1),
+                                             "peak_GBps": HBM_PEAK_GBPS,
+                                             "note": "every gate streams the whole BK-FFT once; a batch re-uses BK "
+                                                     "slices from L2, so this rate is not HBM-bound and may exceed the peak"},
+                         "note": "FP64 vector issue + LDS transposes bound the kernel (DESIGN.md 5.1); flops are "
+                                 "SURVEY.md 8(d)'s algorithmic count, not executed instructions"},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "nand":
             res["cpu_baseline"] = cpu_baseline(args, p, c0, c1, out, key_seed, op)
-        if args.pcie:
+        if world == 1 and args.workload == "nand" and not args.no_secondary:
+            # the other single-GPU configurations of BASELINE.json, one timed pass each (same metric, decrypt-checked)
+            sec = {}
+            for wname, inst in (("adder8", 0), ("streq32", 256), ("mixed", 32768)):
+                wstep, wboots, wdesc, wcheck = make_workload(wname, inst)
+                wstep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                wstep()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                sec[wname] = {"bootstraps_per_s": round(wboots / dt, 1), "bootstraps": wboots, "workload": wdesc,
+                              "decrypt_ok": wcheck()}
+                del wstep, wcheck
+                torch.cuda.empty_cache()
+            res["secondary"] = sec
+        if (world == 1 and args.workload == "nand") or args.pcie:
+            # SURVEY.md 8(d) wall-clock definition: first H2D of inputs -> last D2H of outputs, through the host-buffer
+            # C ABI (eoc_gate_batch); reported beside `value`, never as `value`
             eoc.gpu_init(p, device=local_rank)
             eoc.upload_cloud_key(sk)
-            eoc.gate_batch(op, c0, c1)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                eoc.gate_batch(op, c0, c1)
-            res["pcie_inclusive_gates_per_s"] = round(3 * G / (time.perf_counter() - t0), 1)
+            pin = [eoc.PinnedArray(c0.shape) for _ in range(3)]   # I/O buffers from eoc_host_alloc (pinned: true DMA)
+            pin[0].array[:] = c0
+            pin[1].array[:] = c1
+            reps = 5
+
+            def timed(a, b, o):
+                eoc.gate_batch(op, a, b, out=o)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    eoc.gate_batch(op, a, b, out=o)
+                return reps * G / (time.perf_counter() - t0)
+
+            res["pcie_inclusive_gates_per_s"] = round(timed(pin[0].array, pin[1].array, pin[2].array), 1)
+            res["pcie_inclusive_ok"] = bool(np.array_equal(pin[2].array, out))
+            hout = np.empty_like(c0)
+            res["pcie_inclusive_pageable_gates_per_s"] = round(timed(c0, c1, hout), 1)
+            res["pcie_inclusive_note"] = ("eoc_gate_batch on host buffers, first H2D to last D2H (SURVEY.md 8d); pinned = "
+                                          "buffers from eoc_host_alloc, pageable = ordinary malloc'ed arrays")
+            for a in pin:
+                a.free()
             eoc.gpu_shutdown()
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())

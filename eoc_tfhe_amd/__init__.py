@@ -126,6 +126,22 @@ def lib():
         "eoc_engine_stats": (C.c_int, [vp, C.POINTER(u64 * 3)]),
         "eoc_stats": (C.c_int, [C.POINTER(u64 * 3)]),
         "eoc_gpu_init": (C.c_int, [C.c_int, PP]),
+        "eoc_gpu_init_multi": (C.c_int, [vp, C.c_int, PP]),
+        "eoc_gpu_init_from_env": (C.c_int, [PP]),
+        "eoc_gpu_engine_count": (C.c_int, []),
+        "eoc_global_engine_at": (vp, [C.c_int]),
+        "eoc_upload_cloud_key_arrays": (C.c_int, [vp, vp]),
+        "eoc_stats_multi": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
+        "eoc_key_broadcast_method": (C.c_char_p, []),
+        "eoc_host_path_buffer_grows": (u64, []),
+        "eoc_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
+        "eoc_host_alloc": (vp, [sz]),
+        "eoc_host_free": (None, [vp]),
+        "eoc_engine_reserve": (C.c_int, [vp, sz, sz, sz]),
+        "eoc_engine_workspace_grows": (u64, [vp]),
+        "eoc_engine_device": (C.c_int, [vp]),
+        "eoc_engine_params": (PP, [vp]),
+        "eoc_engine_adopt_cloud_key_device": (C.c_int, [vp, vp, vp]),
         "eoc_upload_cloud_key": (C.c_int, [vp]),
         "eoc_global_engine": (vp, []),
         "eoc_gpu_shutdown": (None, []),
@@ -436,9 +452,62 @@ def netlist_optimize(gates, outputs):
     return [Gate(out[k].op, out[k].in0, out[k].in1, out[k].in2, out[k].out) for k in range(n)]
 
 
-# ---- host-buffer batch API (global engine), numpy in / numpy out ----------------------------------
-def gpu_init(params, device=0):
-    _check(lib().eoc_gpu_init(device, C.byref(params)), "eoc_gpu_init")
+# ---- host-buffer batch API (global context: one key, any number of GPUs), numpy in / numpy out ---------
+def gpu_init(params, device=0, devices=None):
+    """eoc_gpu_init / eoc_gpu_init_multi: `devices` = list of device ordinals (a device may repeat: several engines
+    then share it, the one-GPU rehearsal of the N-GPU path)"""
+    if devices is None:
+        _check(lib().eoc_gpu_init(device, C.byref(params)), "eoc_gpu_init")
+    else:
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().eoc_gpu_init_multi(C.addressof(arr), len(devices), C.byref(params)), "eoc_gpu_init_multi")
+
+
+def gpu_engine_count():
+    return lib().eoc_gpu_engine_count()
+
+
+def shard_range(total, rank, world):
+    lo, hi = C.c_size_t(), C.c_size_t()
+    lib().eoc_shard_range(total, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def stats_multi():
+    """per-engine counters, key replication seconds and method of the global context"""
+    n = lib().eoc_gpu_engine_count()
+    buf = (C.c_uint64 * (3 * max(1, n)))()
+    secs = C.c_double()
+    rc = lib().eoc_stats_multi(C.addressof(buf), n, C.byref(secs))
+    if rc < 0:
+        _check(rc, "eoc_stats_multi")
+    per = [dict(batches=buf[3 * i], bootstraps=buf[3 * i + 1], keyswitches=buf[3 * i + 2]) for i in range(n)]
+    return dict(engines=per, key_broadcast_s=secs.value, key_broadcast_method=lib().eoc_key_broadcast_method().decode(),
+                host_buffer_grows=int(lib().eoc_host_path_buffer_grows()))
+
+
+class PinnedArray:
+    """numpy view of pinned host memory from eoc_host_alloc (true DMA source/target of the batch API)."""
+
+    def __init__(self, shape, dtype=np.int32):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib().eoc_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise EocError("eoc_host_alloc failed")
+        buf = (C.c_char * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().eoc_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def gpu_shutdown():
@@ -456,16 +525,39 @@ def upload_cloud_key(sk):
     _check(lib().eoc_upload_cloud_key(sk.h), "eoc_upload_cloud_key")
 
 
-def gate_batch(op, in0, in1=None, in2=None, ops=None):
-    in0 = np.ascontiguousarray(in0, np.int32)
-    out = np.empty_like(in0)
-    p = lambda a: None if a is None else np.ascontiguousarray(a, np.int32).ctypes.data  # noqa: E731
+def gate_batch(op, in0, in1=None, in2=None, ops=None, out=None, count=None, rowlen=None):
+    """eoc_gate_batch on host arrays [count][n+1] int32.  Operand shapes are checked here (the C ABI takes bare
+    pointers): every supplied operand must have exactly in0's shape, `ops` one opcode per row.  CONST0/CONST1 take
+    no input: pass in0=None with `count` and `rowlen`."""
+    if in0 is None:
+        if ops is not None or int(op) not in (OPS["CONST0"], OPS["CONST1"]) or count is None or rowlen is None:
+            raise EocError("gate_batch: in0 may be omitted only for CONST0/CONST1 with count and rowlen given")
+        shape = (int(count), int(rowlen))
+    else:
+        in0 = np.ascontiguousarray(in0, np.int32)
+        if in0.ndim != 2:
+            raise EocError("gate_batch: operands are 2-d arrays [count][n+1]")
+        shape = in0.shape
     in1c = None if in1 is None else np.ascontiguousarray(in1, np.int32)
     in2c = None if in2 is None else np.ascontiguousarray(in2, np.int32)
     opsc = None if ops is None else np.ascontiguousarray(ops, np.uint8)
-    _check(lib().eoc_gate_batch(int(op), None if opsc is None else opsc.ctypes.data, in0.ctypes.data,
+    for name, a in (("in1", in1c), ("in2", in2c)):
+        if a is not None and a.shape != shape:
+            raise EocError(f"gate_batch: {name} has shape {a.shape}, expected {shape}")
+    if opsc is not None and opsc.shape != (shape[0],):
+        raise EocError(f"gate_batch: ops has shape {opsc.shape}, expected ({shape[0]},)")
+    e0 = lib().eoc_global_engine()
+    if e0 and shape[1] != lib().eoc_engine_params(e0).contents.n + 1:
+        raise EocError(f"gate_batch: rows have {shape[1]} words, the engine's samples have n + 1 = "
+                       f"{lib().eoc_engine_params(e0).contents.n + 1}")
+    if out is None:
+        out = np.empty(shape, np.int32)
+    elif out.shape != shape or out.dtype != np.int32 or not out.flags.c_contiguous:
+        raise EocError("gate_batch: out must be a C-contiguous int32 array of the operands' shape")
+    _check(lib().eoc_gate_batch(int(op), None if opsc is None else opsc.ctypes.data,
+                                None if in0 is None else in0.ctypes.data,
                                 None if in1c is None else in1c.ctypes.data,
-                                None if in2c is None else in2c.ctypes.data, out.ctypes.data, in0.shape[0]),
+                                None if in2c is None else in2c.ctypes.data, out.ctypes.data, shape[0]),
            "eoc_gate_batch")
     return out
 

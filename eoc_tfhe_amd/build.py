@@ -51,8 +51,11 @@ def build_stamps(verbose=False):
         _run([GXX, *CXX_FLAGS, "-c", os.path.join(CSRC, "host.cpp"), "-o", host_obj], verbose)
     if not os.path.exists(leg_obj):
         _run([GXX, *CXX_FLAGS, "-c", os.path.join(CSRC, "legacy.cpp"), "-o", leg_obj], verbose)
-    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", eng_obj, host_obj, leg_obj, "-o", out,
-          "-lgomp", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+    mul_obj = os.path.join(OBJ, "multi.o")
+    if not os.path.exists(mul_obj):
+        _run([HIPCC, *HIP_FLAGS, "-c", os.path.join(CSRC, "multi.hip"), "-o", mul_obj], verbose)
+    _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", eng_obj, mul_obj, host_obj, leg_obj, "-o", out,
+          "-lgomp", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], verbose)
     return out
 
 
@@ -61,18 +64,21 @@ def build(force=False, verbose=False, extra_hip_flags=()):
     hdrs = [os.path.join(CSRC, f) for f in ("kernels.hip.h", "canon_twiddles.h", "common.h")]
     hdrs.append(os.path.join(ROOT, "include", "eoc_tfhe_gpu.h"))
     eng_src, eng_obj = os.path.join(CSRC, "engine.hip"), os.path.join(OBJ, "engine.o")
+    mul_src, mul_obj = os.path.join(CSRC, "multi.hip"), os.path.join(OBJ, "multi.o")
     host_src, host_obj = os.path.join(CSRC, "host.cpp"), os.path.join(OBJ, "host.o")
     leg_src, leg_obj = os.path.join(CSRC, "legacy.cpp"), os.path.join(OBJ, "legacy.o")
     hdrs.append(os.path.join(CSRC, "host_internal.h"))
     if force or _newer(eng_obj, [eng_src] + hdrs):
         _run([HIPCC, *HIP_FLAGS, *extra_hip_flags, "-c", eng_src, "-o", eng_obj], verbose)
+    if force or _newer(mul_obj, [mul_src] + hdrs):
+        _run([HIPCC, *HIP_FLAGS, "-c", mul_src, "-o", mul_obj], verbose)
     if force or _newer(host_obj, [host_src] + hdrs):
         _run([GXX, *CXX_FLAGS, "-c", host_src, "-o", host_obj], verbose)
     if force or _newer(leg_obj, [leg_src] + hdrs):
         _run([GXX, *CXX_FLAGS, "-c", leg_src, "-o", leg_obj], verbose)
-    if force or _newer(LIB, [eng_obj, host_obj, leg_obj]):
-        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", eng_obj, host_obj, leg_obj, "-o", LIB,
-              "-lgomp", "-Wl,-rpath,/opt/rocm/lib"], verbose)
+    if force or _newer(LIB, [eng_obj, mul_obj, host_obj, leg_obj]):
+        _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", eng_obj, mul_obj, host_obj, leg_obj, "-o", LIB,
+              "-lgomp", "-ldl", "-Wl,-rpath,/opt/rocm/lib"], verbose)
     return LIB
 
 

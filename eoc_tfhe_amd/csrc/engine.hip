@@ -41,20 +41,28 @@ struct eoc_engine {
     bool own_keys = false;
     const double *bkfft = nullptr; // in use (owned or adopted)
     const int32_t *ksk = nullptr;
-    // workspaces
-    uint16_t *d_bara = nullptr;
-    int32_t *d_u = nullptr;
-    uint32_t *d_ubarT = nullptr; // [N][ws_jobs] key-switch operand, transposed
+    // workspaces: two independent sets, so that two chunks of one host-buffer call can be in flight on two streams
+    // (set 0 serves the device-pointer API).  Each set owns device buffers AND a pinned host ring for the gate
+    // descriptors / opcode permutations that every launch sends ahead of its kernels: nothing on the launch path reads
+    // pageable memory asynchronously, allocates or synchronises once the sets have their size (eoc_engine_reserve).
+    struct Workspace {
+        uint16_t *d_bara = nullptr;
+        int32_t *d_u = nullptr;
+        uint32_t *d_ubarT = nullptr; // [N][ws_jobs + 64] key-switch operand, transposed
+        size_t ws_jobs = 0;
+        GateDesc *d_descs = nullptr, *h_descs = nullptr; // device ring + pinned host ring, same capacity
+        size_t ws_descs = 0, desc_pos = 0;
+        int32_t *d_mixed = nullptr; // gather/scatter space of mixed batches: 4 row arrays + perm
+        uint32_t *h_perm = nullptr; // pinned
+        hipEvent_t perm_ev = nullptr; // the last copy out of h_perm (awaited before h_perm is rewritten)
+        size_t ws_mixed = 0;
+    } ws[2];
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
     int num_cus = 256;
     int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
-    int32_t *d_mixed = nullptr;             // gather/scatter space of mixed batches: 4 row arrays + perm
-    size_t ws_mixed = 0;
-    size_t ws_jobs = 0;
-    GateDesc *d_descs = nullptr;
-    size_t ws_descs = 0;
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
+    uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
     bool profiling = false;
     struct Span { hipEvent_t a, b; int kind; };
@@ -206,15 +214,30 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->num_cus = cus;
         if (const char *s = getenv("EOC_TFHE_PRIO_DUTY")) e->prio_duty_override = atoi(s);
     }
-    // blind-rotate kernels use > 64 KiB of dynamic LDS
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<4>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_blind_rotate<3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, kBRLds);
+    // key-switch kernels use > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
+#define EOC_KS_ATTR(BB, TT, NWV, JBV, CWV)                                                                       \
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_keyswitch<BB, TT, NWV, JBV, CWV>),                      \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, KSCfg<BB, TT, NWV, JBV, CWV>::LDS_BYTES)
+    EOC_KS_ATTR(2, 8, 2, 4, 128);
+    EOC_KS_ATTR(2, 8, 8, 4, 64);
+    EOC_KS_ATTR(2, 8, 12, 4, 64);
+    EOC_KS_ATTR(2, 8, 8, 2, 128);
+#undef EOC_KS_ATTR
     *out = e;
     return EOC_OK;
+}
+
+static void free_ws(eoc_engine::Workspace &W)
+{
+    hipFree(W.d_bara);
+    hipFree(W.d_u);
+    hipFree(W.d_ubarT);
+    hipFree(W.d_descs);
+    hipFree(W.d_mixed);
+    if (W.h_descs) hipHostFree(W.h_descs);
+    if (W.h_perm) hipHostFree(W.h_perm);
+    if (W.perm_ev) hipEventDestroy(W.perm_ev);
+    W = eoc_engine::Workspace();
 }
 
 extern "C" void eoc_engine_destroy(eoc_engine *e)
@@ -228,41 +251,74 @@ extern "C" void eoc_engine_destroy(eoc_engine *e)
         hipFree(e->d_bkfft);
         hipFree(e->d_ksk);
     }
-    hipFree(e->d_bara);
-    hipFree(e->d_u);
-    hipFree(e->d_ubarT);
-    hipFree(e->d_descs);
-    hipFree(e->d_mixed);
+    free_ws(e->ws[0]);
+    free_ws(e->ws[1]);
+    hipFree(e->d_stamps);
     delete e;
 }
 
-static int ensure_ws(eoc_engine *e, size_t jobs, size_t descs)
+// Grow a workspace set (outside the kernels: the device is synchronised and buffers are re-allocated; callers that
+// must not stall or want hipGraph capture size the sets once with eoc_engine_reserve).  jobs = blind rotations of the
+// widest level, descs = gate descriptors in flight between two wrap-arounds of the ring, mixed = rows of a mixed batch.
+static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_t descs, size_t mixed)
 {
-    if (jobs > e->ws_jobs) {
+    if (jobs > W.ws_jobs) {
         hipDeviceSynchronize();
-        hipFree(e->d_bara);
-        hipFree(e->d_u);
-        hipFree(e->d_ubarT);
-        e->d_bara = nullptr;
-        e->d_u = nullptr;
-        e->d_ubarT = nullptr;
-        e->ws_jobs = 0;
+        hipFree(W.d_bara);
+        hipFree(W.d_u);
+        hipFree(W.d_ubarT);
+        W.d_bara = nullptr;
+        W.d_u = nullptr;
+        W.d_ubarT = nullptr;
+        W.ws_jobs = 0;
         size_t cap = (std::max<size_t>(jobs, 1024) + 63) / 64 * 64;
-        HIP_TRY(hipMalloc(&e->d_bara, cap * e->bara_stride * sizeof(uint16_t)));
-        HIP_TRY(hipMalloc(&e->d_u, cap * (kN + 1) * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&e->d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(e->d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
-        e->ws_jobs = cap;
+        HIP_TRY(hipMalloc(&W.d_bara, cap * e->bara_stride * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc(&W.d_u, cap * (kN + 1) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&W.d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(W.d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        W.ws_jobs = cap;
+        e->ws_grows++;
     }
-    if (descs > e->ws_descs) {
+    if (descs > W.ws_descs) {
         hipDeviceSynchronize();
-        hipFree(e->d_descs);
-        e->d_descs = nullptr;
-        e->ws_descs = 0;
-        size_t cap = std::max<size_t>(descs, 256);
-        HIP_TRY(hipMalloc(&e->d_descs, cap * sizeof(GateDesc)));
-        e->ws_descs = cap;
+        hipFree(W.d_descs);
+        if (W.h_descs) hipHostFree(W.h_descs);
+        W.d_descs = W.h_descs = nullptr;
+        W.ws_descs = 0;
+        W.desc_pos = 0;
+        size_t cap = std::max<size_t>(descs, 1024);
+        HIP_TRY(hipMalloc(&W.d_descs, cap * sizeof(GateDesc)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&W.h_descs), cap * sizeof(GateDesc), hipHostMallocDefault));
+        W.ws_descs = cap;
+        e->ws_grows++;
     }
+    if (mixed > W.ws_mixed) {
+        hipDeviceSynchronize();
+        hipFree(W.d_mixed);
+        if (W.h_perm) hipHostFree(W.h_perm);
+        W.d_mixed = nullptr;
+        W.h_perm = nullptr;
+        W.ws_mixed = 0;
+        const size_t rows_bytes = mixed * ((size_t)e->p.n + 1) * 4;
+        HIP_TRY(hipMalloc(&W.d_mixed, 4 * rows_bytes + mixed * 4));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&W.h_perm), mixed * 4, hipHostMallocDefault));
+        if (!W.perm_ev) HIP_TRY(hipEventCreateWithFlags(&W.perm_ev, hipEventDisableTiming));
+        W.ws_mixed = mixed;
+        e->ws_grows++;
+    }
+    return EOC_OK;
+}
+
+extern "C" int eoc_engine_reserve(eoc_engine *e, size_t max_jobs, size_t max_descs, size_t max_mixed_rows)
+{
+    if (!e) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    for (int k = 0; k < 2; k++) {
+        int rc = ensure_ws(e, e->ws[k], max_jobs, max_descs, k == 0 ? max_mixed_rows : 0);
+        if (rc) return rc;
+    }
+    e->ws_grows = 0;
     return EOC_OK;
 }
 
@@ -403,6 +459,23 @@ extern "C" int eoc_engine_set_cloud_key_device(eoc_engine *e, const void *d_bkff
     e->ksk = static_cast<const int32_t *>(d_ksk);
     return EOC_OK;
 }
+// take ownership of device images the engine's allocator produced (eoc_device_alloc): used for key replicas
+extern "C" int eoc_engine_adopt_cloud_key_device(eoc_engine *e, void *d_bkfft, void *d_ksk)
+{
+    if (!e || !d_bkfft || !d_ksk) return EOC_ERR_ARG;
+    std::lock_guard<std::mutex> g(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->own_keys) {
+        hipFree(e->d_bkfft);
+        hipFree(e->d_ksk);
+    }
+    e->d_bkfft = static_cast<double *>(d_bkfft);
+    e->d_ksk = static_cast<int32_t *>(d_ksk);
+    e->own_keys = true;
+    e->bkfft = e->d_bkfft;
+    e->ksk = e->d_ksk;
+    return EOC_OK;
+}
 extern "C" int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void **d_ksk)
 {
     if (!e || !e->bkfft || !e->ksk) return EOC_ERR_NO_KEY;
@@ -412,12 +485,14 @@ extern "C" int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, 
 }
 
 // ---- launch helpers -------------------------------------------------------------------------
-static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
+typedef eoc_engine::Workspace WS;
+
+static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs, hipStream_t st)
 {
     BRArgs a;
     a.bkfft = e->bkfft;
-    a.bara = e->d_bara;
-    a.u = e->d_u;
+    a.bara = W.d_bara;
+    a.u = W.d_u;
     a.njobs = njobs;
     a.n = e->p.n;
     a.Bgbit = e->p.Bgbit;
@@ -445,18 +520,18 @@ static int launch_blind_rotate(eoc_engine *e, uint32_t njobs, hipStream_t st)
     return EOC_OK;
 }
 
-static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t ngates, uint32_t S, hipStream_t st)
+static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint32_t ngates, uint32_t S, hipStream_t st)
 {
     KSArgs a;
     a.ksk = e->ksk;
-    a.u = e->d_u;
-    a.ubarT = e->d_ubarT;
+    a.u = W.d_u;
+    a.ubarT = W.d_ubarT;
     a.n = e->p.n;
     a.n1p = (int)e->n1p;
     a.t = e->p.ks_t;
     a.basebit = e->p.ks_basebit;
     a.S = S;
-    a.jstride = (uint32_t)e->ws_jobs + KS_GT;
+    a.jstride = (uint32_t)W.ws_jobs + KS_GT;
     a.mu = (int32_t)(1u << 29);
     SpanGuard span(e, st, KIND_KEYSWITCH);
     hipLaunchKernelGGL(k_ks_init, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
@@ -470,7 +545,6 @@ static int launch_keyswitch(eoc_engine *e, const GateDesc *d_descs, uint32_t nga
         auto kfn = k_keyswitch<BB, TT, NWV, JBV, CWV>;                                                    \
         constexpr int lds = KSCfg<BB, TT, NWV, JBV, CWV>::LDS_BYTES;                                      \
         static_assert(NWV * CWV % KS_CW == 0, "waves x columns must cover whole 128-column units");       \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, st, d_descs, a);                               \
     } while (0)
     // n1p = 512 (385 <= n <= 511, Set A): eight waves of 64 columns (122 VGPRs, four waves per SIMD) beat four waves
@@ -495,65 +569,90 @@ static inline bool op_free(int op) { return op == OP_NOT || op == OP_COPY || op_
 static inline bool op_valid(int op) { return (op >= 0 && op <= OP_CONST1); }
 static inline int op_inputs(int op) { return op_const(op) ? 0 : (op_free(op) ? 1 : (op == OP_MUX ? 3 : 2)); }
 
+// kernels index gates with a grid dimension (y or z <= 65535): wider levels are cut into slices of this many gates
+constexpr size_t kMaxGatesPerLaunch = 32768;
+
+// Descriptors of one launch group: written into the pinned host ring, copied to the same position of the device ring
+// ahead of the kernels.  The ring only wraps after a stream synchronisation, so a slot is never overwritten while a
+// copy that reads it may still be in flight (sized by ensure_ws for everything a call sends, the wrap is rare).
+static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, GateDesc **d_out)
+{
+    if (count > W.ws_descs) {
+        eoc_set_error("internal: descriptor ring too small (%zu > %zu)", count, W.ws_descs);
+        return EOC_ERR_STATE;
+    }
+    if (W.desc_pos + count > W.ws_descs) {
+        HIP_TRY(hipStreamSynchronize(st));
+        W.desc_pos = 0;
+    }
+    memcpy(W.h_descs + W.desc_pos, src, count * sizeof(GateDesc));
+    HIP_TRY(hipMemcpyAsync(W.d_descs + W.desc_pos, W.h_descs + W.desc_pos, count * sizeof(GateDesc),
+                           hipMemcpyHostToDevice, st));
+    *d_out = W.d_descs + W.desc_pos;
+    W.desc_pos += count;
+    return EOC_OK;
+}
+
 // One "level": a set of gates that all run over the same S instances.  descs are host-side and
 // carry device pointers; free gates and bootstrapped gates are separated here.
-static int run_level(eoc_engine *e, std::vector<GateDesc> &boot, std::vector<GateDesc> &freeg, size_t S,
-                     GateDesc *d_descs_slot, hipStream_t st)
+static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vector<GateDesc> &freeg, size_t S,
+                     hipStream_t st)
 {
     const int n = e->p.n;
-    size_t ofs = 0;
-    if (!freeg.empty()) {
-        HIP_TRY(hipMemcpyAsync(d_descs_slot, freeg.data(), freeg.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
+    for (size_t g0 = 0; g0 < freeg.size(); g0 += kMaxGatesPerLaunch) {
+        const size_t cnt = std::min(kMaxGatesPerLaunch, freeg.size() - g0);
+        GateDesc *dd = nullptr;
+        int rc = push_descs(W, freeg.data() + g0, cnt, st, &dd);
+        if (rc) return rc;
         size_t total = S * (size_t)(n + 1);
-        dim3 grid((unsigned)((total + 255) / 256), (unsigned)freeg.size());
-        hipLaunchKernelGGL(k_free_gates, grid, dim3(256), 0, st, d_descs_slot, total, n + 1, (int32_t)(1u << 29));
-        HIP_TRY(hipGetLastError());
-        ofs = freeg.size();
-    }
-    if (boot.empty()) return EOC_OK;
-    // jobs: [gate][variant][instance]
-    uint32_t jobs = 0;
-    bool any_mux = false;
-    for (auto &d : boot) {
-        d.job_base = jobs;
-        jobs += (uint32_t)S * (d.op == OP_MUX ? 2u : 1u);
-        any_mux |= d.op == OP_MUX;
-    }
-    GateDesc *dd = d_descs_slot + ofs;
-    HIP_TRY(hipMemcpyAsync(dd, boot.data(), boot.size() * sizeof(GateDesc), hipMemcpyHostToDevice, st));
-    {
-        dim3 grid((unsigned)(S * (any_mux ? 2 : 1)), (unsigned)((n + 1 + 255) / 256), (unsigned)boot.size());
-        SpanGuard span(e, st, KIND_PREPARE);
-        hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, e->d_bara, e->bara_stride);
+        dim3 grid((unsigned)((total + 255) / 256), (unsigned)cnt);
+        hipLaunchKernelGGL(k_free_gates, grid, dim3(256), 0, st, dd, total, n + 1, (int32_t)(1u << 29));
         HIP_TRY(hipGetLastError());
     }
-    int rc = launch_blind_rotate(e, jobs, st);
-    if (rc) return rc;
-    rc = launch_keyswitch(e, dd, (uint32_t)boot.size(), (uint32_t)S, st);
-    if (rc) return rc;
-    e->stats[0] += 1;
-    e->stats[1] += jobs;
-    e->stats[2] += S * boot.size();
+    // bootstrapped gates, in slices whose job count fits the workspace and whose gate count fits a grid dimension
+    size_t g0 = 0;
+    while (g0 < boot.size()) {
+        uint32_t jobs = 0;
+        bool any_mux = false;
+        size_t g1 = g0;
+        while (g1 < boot.size() && g1 - g0 < kMaxGatesPerLaunch) {
+            const uint32_t w = (uint32_t)S * (boot[g1].op == OP_MUX ? 2u : 1u);
+            if (g1 > g0 && (size_t)jobs + w > W.ws_jobs) break;
+            boot[g1].job_base = jobs;
+            jobs += w;
+            any_mux |= boot[g1].op == OP_MUX;
+            g1++;
+        }
+        if (jobs > W.ws_jobs) {
+            eoc_set_error("internal: workspace too small for one gate (%u jobs > %zu)", jobs, W.ws_jobs);
+            return EOC_ERR_STATE;
+        }
+        const size_t cnt = g1 - g0;
+        GateDesc *dd = nullptr;
+        int rc = push_descs(W, boot.data() + g0, cnt, st, &dd);
+        if (rc) return rc;
+        {
+            dim3 grid((unsigned)(S * (any_mux ? 2 : 1)), (unsigned)((n + 1 + 255) / 256), (unsigned)cnt);
+            SpanGuard span(e, st, KIND_PREPARE);
+            hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, W.d_bara, e->bara_stride);
+            HIP_TRY(hipGetLastError());
+        }
+        rc = launch_blind_rotate(e, W, jobs, st);
+        if (rc) return rc;
+        rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st);
+        if (rc) return rc;
+        e->stats[0] += 1;
+        e->stats[1] += jobs;
+        e->stats[2] += S * cnt;
+        g0 = g1;
+    }
     return EOC_OK;
 }
 
 // ---- batch of independent gates --------------------------------------------------------------
-extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
-                                     const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
-                                     void *hip_stream)
+static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const int32_t *d_in0, const int32_t *d_in1,
+                         const int32_t *d_in2, int32_t *d_out, size_t count, hipStream_t st)
 {
-    if (!e || !d_out || (!d_in0 && !(ops == nullptr && op_const(op)))) {
-        eoc_set_error("eoc_gate_batch_device: null argument");
-        return EOC_ERR_ARG;
-    }
-    if (!count) return EOC_OK;
-    std::lock_guard<std::mutex> g(e->mu);
-    if (!e->bkfft || !e->ksk) {
-        eoc_set_error("eoc_gate_batch_device: no cloud key loaded");
-        return EOC_ERR_NO_KEY;
-    }
-    HIP_TRY(hipSetDevice(e->device));
-    hipStream_t st = (hipStream_t)hip_stream;
     const size_t stride = (size_t)e->p.n + 1;
     std::vector<GateDesc> boot, freeg;
     if (!ops) {
@@ -563,9 +662,9 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
         }
         GateDesc d{op, 0, d_in0, d_in1, d_in2, d_out};
         (op_free(op) ? freeg : boot).push_back(d);
-        int rc = ensure_ws(e, count * (op == OP_MUX ? 2 : 1), 2);
+        int rc = ensure_ws(e, W, count * (op == OP_MUX ? 2 : 1), 64, 0);
         if (rc) return rc;
-        return run_level(e, boot, freeg, count, e->d_descs, st);
+        return run_level(e, W, boot, freeg, count, st);
     }
     // mixed batch.  Every maximal run of equal opcodes is one batch; when the caller's order has many
     // runs the rows are first gathered into opcode-sorted order on the device (stable, so equal opcodes keep
@@ -575,7 +674,7 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
             eoc_set_error("eoc_gate_batch_device: bad opcode %d at %zu", (int)ops[k], k);
             return EOC_ERR_ARG;
         }
-        if ((!op_free(ops[k]) && !d_in1) || (ops[k] == OP_MUX && !d_in2)) {
+        if ((!op_free(ops[k]) && !d_in1) || (ops[k] == OP_MUX && !d_in2) || (!op_const(ops[k]) && !d_in0)) {
             eoc_set_error("eoc_gate_batch_device: missing operand for opcode %d", (int)ops[k]);
             return EOC_ERR_ARG;
         }
@@ -587,8 +686,24 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
     const int32_t *in0 = d_in0, *in1 = d_in1, *in2 = d_in2;
     int32_t *out = d_out;
     const bool gather = runs > 15; // more runs than opcodes: sorting pays
+    size_t max_jobs = 0;
+    {
+        size_t cnt_op[OP_CONST1 + 1] = {0}, run = 0;
+        for (size_t k = 0; k < count; k++) {
+            cnt_op[ops[k]]++;
+            run = (k && ops[k] == ops[k - 1]) ? run + 1 : 1;
+            if (!gather) max_jobs = std::max(max_jobs, run * (ops[k] == OP_MUX ? 2 : 1));
+        }
+        if (gather)
+            for (int o = 0; o <= OP_CONST1; o++) max_jobs = std::max(max_jobs, cnt_op[o] * (o == OP_MUX ? 2 : 1));
+    }
+    int rc = ensure_ws(e, W, max_jobs, 2 * (gather ? OP_CONST1 + 1 : runs) + 64, gather ? count : 0);
+    if (rc) return rc;
     if (gather) {
-        std::vector<uint32_t> perm(count);
+        // stable counting sort by opcode on the host (the opcode array is a host array); the permutation goes through
+        // the workspace's pinned buffer, so nothing here waits for the device
+        uint32_t *perm = W.h_perm;
+        HIP_TRY(hipEventSynchronize(W.perm_ev)); // the previous mixed batch's copy out of h_perm (long done, normally)
         size_t bucket[OP_CONST1 + 2] = {0};
         for (size_t k = 0; k < count; k++) bucket[ops[k] + 1]++;
         for (int o = 1; o < OP_CONST1 + 2; o++) bucket[o] += bucket[o - 1];
@@ -598,61 +713,67 @@ extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, 
             perm[pos] = (uint32_t)k;
             sorted_ops[pos] = ops[k];
         }
-        const size_t rows_bytes = count * stride * 4;
-        if (count > e->ws_mixed) {
-            hipDeviceSynchronize();
-            hipFree(e->d_mixed);
-            e->d_mixed = nullptr;
-            e->ws_mixed = 0;
-            HIP_TRY(hipMalloc(&e->d_mixed, 4 * rows_bytes + count * 4));
-            e->ws_mixed = count;
-        }
-        int32_t *g0 = e->d_mixed, *g1 = g0 + count * stride, *g2 = g1 + count * stride, *go = g2 + count * stride;
-        uint32_t *d_perm = reinterpret_cast<uint32_t *>(go + count * stride);
-        HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), count * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st)); // perm is a local vector: the copy must finish before it dies
+        int32_t *g0 = W.d_mixed, *g1 = g0 + count * stride, *g2 = g1 + count * stride, *go = g2 + count * stride;
+        uint32_t *d_perm = reinterpret_cast<uint32_t *>(W.d_mixed + 4 * W.ws_mixed * stride);
+        HIP_TRY(hipMemcpyAsync(d_perm, perm, count * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(W.perm_ev, st));
         dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
-        hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in0, g0, d_perm, (int)stride, 0);
+        if (d_in0) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in0, g0, d_perm, (int)stride, 0);
         if (d_in1) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in1, g1, d_perm, (int)stride, 0);
         if (d_in2) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in2, g2, d_perm, (int)stride, 0);
         HIP_TRY(hipGetLastError());
-        in0 = g0;
+        in0 = d_in0 ? g0 : nullptr;
         in1 = d_in1 ? g1 : nullptr;
         in2 = d_in2 ? g2 : nullptr;
         out = go;
         run_ops = sorted_ops.data();
     }
-    size_t max_jobs = 0;
-    {
-        size_t run = 0;
-        for (size_t k = 0; k < count; k++) {
-            run = (k && run_ops[k] == run_ops[k - 1]) ? run + 1 : 1;
-            max_jobs = std::max(max_jobs, run * (run_ops[k] == OP_MUX ? 2 : 1));
-        }
-    }
-    int rc = ensure_ws(e, max_jobs, 2);
-    if (rc) return rc;
     size_t i = 0;
     while (i < count) {
         size_t j = i;
         while (j < count && run_ops[j] == run_ops[i]) j++;
         int o = run_ops[i];
-        GateDesc d{o, 0, in0 + i * stride, in1 ? in1 + i * stride : nullptr, in2 ? in2 + i * stride : nullptr,
-                   out + i * stride};
+        GateDesc d{o, 0, in0 ? in0 + i * stride : nullptr, in1 ? in1 + i * stride : nullptr,
+                   in2 ? in2 + i * stride : nullptr, out + i * stride};
         boot.clear();
         freeg.clear();
         (op_free(o) ? freeg : boot).push_back(d);
-        rc = run_level(e, boot, freeg, j - i, e->d_descs, st);
+        rc = run_level(e, W, boot, freeg, j - i, st);
         if (rc) return rc;
         i = j;
     }
     if (gather) {
-        const uint32_t *d_perm = reinterpret_cast<const uint32_t *>(e->d_mixed + 4 * count * stride);
+        const uint32_t *d_perm = reinterpret_cast<const uint32_t *>(W.d_mixed + 4 * W.ws_mixed * stride);
         dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
         hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, out, d_out, d_perm, (int)stride, 1);
         HIP_TRY(hipGetLastError());
     }
     return EOC_OK;
+}
+
+// ws_index selects the workspace set (0: the public device API; 1: the second chunk stream of the host-buffer path)
+extern "C" int eoc_gate_batch_device_ws(eoc_engine *e, int ws_index, int op, const uint8_t *ops, const int32_t *d_in0,
+                                        const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
+                                        void *hip_stream)
+{
+    if (!e || !d_out || ws_index < 0 || ws_index > 1 || (!d_in0 && !ops && !op_const(op))) {
+        eoc_set_error("eoc_gate_batch_device: null argument");
+        return EOC_ERR_ARG;
+    }
+    if (!count) return EOC_OK;
+    std::lock_guard<std::mutex> g(e->mu);
+    if (!e->bkfft || !e->ksk) {
+        eoc_set_error("eoc_gate_batch_device: no cloud key loaded");
+        return EOC_ERR_NO_KEY;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    return gate_batch_ws(e, e->ws[ws_index], op, ops, d_in0, d_in1, d_in2, d_out, count, (hipStream_t)hip_stream);
+}
+extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
+                                     const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
+                                     void *hip_stream)
+{
+    return eoc_gate_batch_device_ws(e, 0, op, ops, d_in0, d_in1, d_in2, d_out, count, hip_stream);
 }
 
 // ---- circuits -------------------------------------------------------------------------------
@@ -678,6 +799,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
+    WS &W = e->ws[0];
     // levelise: RAW, WAR and WAW hazards on wires
     std::vector<int> wr_level(n_wires, 0), rd_level(n_wires, 0), level(n_gates, 0);
     int nlev = 0;
@@ -705,7 +827,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     }
     std::vector<std::vector<GateDesc>> boot(nlev + 1), freeg(nlev + 1);
     const size_t wstride = instances * ((size_t)e->p.n + 1);
-    size_t max_jobs = 0, total_descs = 0;
+    size_t max_jobs = 0, max_gate_jobs = 0;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &q = gates[k];
         GateDesc d{q.op, 0, q.in0 >= 0 ? d_wires + (size_t)q.in0 * wstride : nullptr,
@@ -715,17 +837,21 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     }
     for (int lv = 1; lv <= nlev; lv++) {
         size_t jobs = 0;
-        for (auto &d : boot[lv]) jobs += instances * (d.op == OP_MUX ? 2 : 1);
+        for (auto &d : boot[lv]) {
+            const size_t w = instances * (d.op == OP_MUX ? 2 : 1);
+            jobs += w;
+            max_gate_jobs = std::max(max_gate_jobs, w);
+        }
         max_jobs = std::max(max_jobs, jobs);
-        total_descs += boot[lv].size() + freeg[lv].size();
     }
-    int rc = ensure_ws(e, max_jobs, total_descs);
+    // a level wider than the job cap is evaluated in slices (run_level), so the workspace is bounded: 2^20 blind
+    // rotations in flight need 9.6 GB of extracted samples and rotation amounts; wider levels gain nothing
+    const size_t job_cap = std::max<size_t>(max_gate_jobs, (size_t)1 << 20);
+    int rc = ensure_ws(e, W, std::min(max_jobs, job_cap), n_gates + 64, 0);
     if (rc) return rc;
-    size_t ofs = 0;
     for (int lv = 1; lv <= nlev; lv++) {
-        rc = run_level(e, boot[lv], freeg[lv], instances, e->d_descs + ofs, st);
+        rc = run_level(e, W, boot[lv], freeg[lv], instances, st);
         if (rc) return rc;
-        ofs += boot[lv].size() + freeg[lv].size();
     }
     return EOC_OK;
 }
@@ -740,17 +866,18 @@ extern "C" int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_
     if (!e->bkfft) return EOC_ERR_NO_KEY;
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    int rc = ensure_ws(e, count, 2);
+    WS &W = e->ws[0];
+    int rc = ensure_ws(e, W, count, 64, 0);
     if (rc) return rc;
-    GateDesc d{OP_RAW, 0, d_t, nullptr, nullptr, nullptr};
-    HIP_TRY(hipMemcpyAsync(e->d_descs, &d, sizeof d, hipMemcpyHostToDevice, st));
+    GateDesc d{OP_RAW, 0, d_t, nullptr, nullptr, nullptr}, *dd = nullptr;
+    rc = push_descs(W, &d, 1, st, &dd);
+    if (rc) return rc;
     dim3 grid((unsigned)count, (unsigned)((e->p.n + 1 + 255) / 256), 1);
-    hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, e->d_descs, e->p.n, (uint32_t)count, e->d_bara,
-                       e->bara_stride);
+    hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, e->p.n, (uint32_t)count, W.d_bara, e->bara_stride);
     HIP_TRY(hipGetLastError());
-    rc = launch_blind_rotate(e, (uint32_t)count, st);
+    rc = launch_blind_rotate(e, W, (uint32_t)count, st);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_u, e->d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_u, W.d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
     return EOC_OK;
 }
 
@@ -763,12 +890,14 @@ extern "C" int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *
     if (!e->ksk) return EOC_ERR_NO_KEY;
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    int rc = ensure_ws(e, count, 2);
+    WS &W = e->ws[0];
+    int rc = ensure_ws(e, W, count, 64, 0);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(e->d_u, d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
-    GateDesc d{OP_RAW, 0, nullptr, nullptr, nullptr, d_out};
-    HIP_TRY(hipMemcpyAsync(e->d_descs, &d, sizeof d, hipMemcpyHostToDevice, st));
-    return launch_keyswitch(e, e->d_descs, 1, (uint32_t)count, st);
+    HIP_TRY(hipMemcpyAsync(W.d_u, d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
+    GateDesc d{OP_RAW, 0, nullptr, nullptr, nullptr, d_out}, *dd = nullptr;
+    rc = push_descs(W, &d, 1, st, &dd);
+    if (rc) return rc;
+    return launch_keyswitch(e, W, dd, 1, (uint32_t)count, st);
 }
 
 extern "C" int eoc_engine_set_profiling(eoc_engine *e, int on)
@@ -831,89 +960,6 @@ extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])
     for (int i = 0; i < 3; i++) out[i] = e->stats[i];
     return EOC_OK;
 }
-
-// ---- batch API on host buffers (layer 2) -----------------------------------------------------
-static eoc_engine *g_engine = nullptr;
-static std::mutex g_engine_mu;
-
-extern "C" int eoc_gpu_init(int device, const eoc_params *p)
-{
-    std::lock_guard<std::mutex> g(g_engine_mu);
-    if (g_engine) {
-        eoc_set_error("eoc_gpu_init: engine already initialised");
-        return EOC_ERR_STATE;
-    }
-    return eoc_engine_create(device, p, &g_engine);
-}
-extern "C" eoc_engine *eoc_global_engine(void) { return g_engine; }
-extern "C" void eoc_gpu_shutdown(void)
-{
-    std::lock_guard<std::mutex> g(g_engine_mu);
-    eoc_engine_destroy(g_engine);
-    g_engine = nullptr;
-}
-extern "C" int eoc_stats(uint64_t out[3])
-{
-    std::lock_guard<std::mutex> g(g_engine_mu);
-    if (!g_engine) {
-        eoc_set_error("eoc_stats: no global engine (eoc_gpu_init)");
-        return EOC_ERR_STATE;
-    }
-    return eoc_engine_stats(g_engine, out);
-}
-extern "C" int eoc_upload_cloud_key(const eoc_secret_key *sk)
-{
-    if (!g_engine) {
-        eoc_set_error("eoc_upload_cloud_key: call eoc_gpu_init first");
-        return EOC_ERR_STATE;
-    }
-    if (!sk || !eoc_sk_bk(sk) || !eoc_sk_ksk(sk)) return EOC_ERR_NO_KEY;
-    return eoc_engine_load_cloud_key(g_engine, eoc_sk_bk(sk), eoc_sk_ksk(sk));
-}
-
-extern "C" int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
-                              const int32_t *in2, int32_t *out, size_t count)
-{
-    eoc_engine *e = g_engine;
-    if (!e) {
-        eoc_set_error("eoc_gate_batch: no GPU engine (eoc_gpu_init not called or failed); there is no CPU fallback");
-        return EOC_ERR_NO_DEVICE;
-    }
-    if (!in0 || !out) return EOC_ERR_ARG;
-    if (!count) return EOC_OK;
-    HIP_TRY(hipSetDevice(e->device));
-    const size_t bytes = count * ((size_t)e->p.n + 1) * 4;
-    int32_t *d[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int32_t *h[3] = {in0, in1, in2};
-    int rc = EOC_OK;
-    for (int k = 0; k < 4 && rc == EOC_OK; k++) {
-        if (k < 3 && !h[k]) continue;
-        if (hipMalloc(&d[k], bytes) != hipSuccess) rc = EOC_ERR_ALLOC;
-        else if (k < 3 && hipMemcpy(d[k], h[k], bytes, hipMemcpyHostToDevice) != hipSuccess) rc = EOC_ERR_HIP;
-    }
-    if (rc == EOC_OK) rc = eoc_gate_batch_device(e, op, ops, d[0], d[1], d[2], d[3], count, nullptr);
-    if (rc == EOC_OK && hipMemcpy(out, d[3], bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = EOC_ERR_HIP;
-    for (int k = 0; k < 4; k++) hipFree(d[k]);
-    return rc;
-}
-
-extern "C" int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,
-                               size_t instances)
-{
-    eoc_engine *e = g_engine;
-    if (!e) {
-        eoc_set_error("eoc_circuit_run: no GPU engine; there is no CPU fallback");
-        return EOC_ERR_NO_DEVICE;
-    }
-    if (!gates || !wires) return EOC_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->device));
-    const size_t bytes = n_wires * instances * ((size_t)e->p.n + 1) * 4;
-    int32_t *d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
-    int rc = EOC_OK;
-    if (hipMemcpy(d, wires, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = EOC_ERR_HIP;
-    if (rc == EOC_OK) rc = eoc_circuit_run_device(e, gates, n_gates, d, n_wires, instances, nullptr);
-    if (rc == EOC_OK && hipMemcpy(wires, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = EOC_ERR_HIP;
-    hipFree(d);
-    return rc;
-}
+extern "C" uint64_t eoc_engine_workspace_grows(eoc_engine *e) { return e ? e->ws_grows : 0; }
+extern "C" int eoc_engine_device(eoc_engine *e) { return e ? e->device : -1; }
+extern "C" const eoc_params *eoc_engine_params(eoc_engine *e) { return e ? &e->p : nullptr; }

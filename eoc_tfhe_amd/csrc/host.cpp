@@ -370,12 +370,12 @@ int ensure_engine_locked()
     GlobalCtx &c = ctx();
     if (!c.sk) return EOC_ERR_NO_KEY;
     if (c.engine_ready) return EOC_OK;
-    if (!eoc_global_engine()) {
-        int rc = eoc_gpu_init(0, &c.sk->p);
+    if (!eoc_global_engine()) { // EOC_TFHE_DEVICES = "all" | "0,1,..." puts several GPUs behind the one global key
+        int rc = eoc_gpu_init_from_env(&c.sk->p);
         if (rc) return rc;
     }
     if (c.sk->bk.empty() || c.sk->ksk.empty()) return EOC_ERR_NO_KEY;
-    int rc = eoc_engine_load_cloud_key(eoc_global_engine(), c.sk->bk.data(), c.sk->ksk.data());
+    int rc = eoc_upload_cloud_key_arrays(c.sk->bk.data(), c.sk->ksk.data());
     if (rc) return rc;
     c.engine_ready = true;
     return EOC_OK;

@@ -221,24 +221,20 @@ __device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
 #endif
 }
 
-// one forward transform after its first pass: x[] in L0 (stages 0-2 done) -> x[] in L2
+// one forward transform after its first pass: x[] in L0 (stages 0-2 done) -> x[] in L2.  The second twiddle set is
+// requested under the second transpose (register-lean: this form runs next to the live spectra of a finished pair)
 __device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, int lane)
 {
     d2 t1[4], t2[4];
     tw_load(t1, tw + kTwF1 + (lane >> 3), 8);
-    tw_load(t2, tw + kTwF2 + lane, 64);
     t01_write(x, scr, lane);
     t01_read(x, scr, lane);
     fwd_pass12(x, t1);
     t12_write(x, scr, lane);
+    tw_load(t2, tw + kTwF2 + lane, 64);
     t12_read(x, scr, lane);
     fwd_pass12(x, t2);
 }
-// Two independent forward transforms of one wave on ONE scratch, skewed: xa arrives with its first pass done,
-// make_b() produces xb's first pass and is placed under xa's first LDS round trip; the twiddles of both table passes
-// are requested early, and each transform's LDS round trip is issued so that it runs under the other's register pass.
-// LDS issue order: w01(a) r01(a) w01(b) r01(b) w12(a) r12(a) w12(b) r12(b); a register pass waits only for its own
-// read (counted lgkmcnt), which works because no twiddle read sits between a transpose read and its use.
 // EOC_PIN_SKEW: scheduling barriers that pin the phase order below (the machine scheduler otherwise sinks the early
 // twiddle reads under the transposes and waits for BOTH transposes before the first register pass)
 #ifndef EOC_PIN_SKEW
@@ -259,8 +255,8 @@ __device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, 
 #define EOC_M_VALU 0x002
 #define EOC_M_DSR 0x100
 #define EOC_M_DSW 0x200
-template <class MakeB>
-__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, const d2 *tw, d2 *scr, int lane)
+template <class MakeB, class PreLast>
+__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, PreLast pre_last, const d2 *tw, d2 *scr, int lane)
 {
     d2 t1[4], t2[4];
     EOC_SB();
@@ -325,6 +321,7 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     EOC_SGB(EOC_M_VALU, 40);
 #endif
     EOC_SB();
+    pre_last(); // e.g. key-row requests that should be in flight under the last register pass
     fwd_pass12(xb, t2);
 }
 
@@ -598,6 +595,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 #ifndef EOC_PRIO_ALT
 #define EOC_PRIO_ALT 1
 #endif
+//   EOC_OWN_EARLY  (l = 2) the first own key row is requested before the last forward register pass (third row buffer)
+//   EOC_OWN_LATE   only one own key row is requested before the exchange (fewer live registers)
+#ifndef EOC_OWN_EARLY
+#define EOC_OWN_EARLY 0
+#endif
+#ifndef EOC_OWN_LATE
+#define EOC_OWN_LATE 0
+#endif
 #ifndef EOC_PRIO_DUTY
 #define EOC_PRIO_DUTY 11
 #endif
@@ -791,6 +796,9 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // forward transforms of the l digits (two at a time, skewed on the one scratch; an odd last one alone) and
         // the chain for the partner's output polynomial.  The spectra stay in registers for the own chain below.
         d2 xs[L][8], ra[8], rb[8], S[8];
+#if EOC_OWN_EARLY
+        d2 rc[8];
+#endif
 #pragma unroll
         for (int p0 = 0; p0 + 1 < L; p0 += 2) {
             load_row(p0 + 1, 1 - h, ra);
@@ -798,6 +806,11 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             make_x0(p0 + 1, xs[p0]);
             EOC_STAMP(1);
             fft_fwd_rest_x2(xs[p0], xs[p0 + 1], [&]() __attribute__((always_inline)) { make_x0(p0 + 2, xs[p0 + 1]); },
+                            [&]() __attribute__((always_inline)) {
+#if EOC_OWN_EARLY
+                                if (L == 2) load_row(1, h, rc); // first own row under the last register pass
+#endif
+                            },
                             s_tw, scr, lane);
             EOC_STAMP(2);
             mac(p0 == 0, xs[p0], ra, S);
@@ -814,8 +827,16 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             EOC_STAMP(3);
         }
         // own rows: the first two are requested before the exchange
+#if EOC_OWN_EARLY
+        if constexpr (L != 2) load_row(1, h, ra);
+        if constexpr (L == 2) load_row(2, h, rb);
+        else if constexpr (L >= 2) load_row(2, h, rb);
+#elif EOC_OWN_LATE
+        load_row(1, h, ra); // register-lean form: the second own row is requested after the exchange
+#else
         load_row(1, h, ra);
         if constexpr (L >= 2) load_row(2, h, rb);
+#endif
 #pragma unroll
         for (int r = 0; r < 8; r++) scr[r * 64 + lane] = S[r];
         EOC_STAMP(4);
@@ -823,7 +844,15 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 8; r++) S[r] = scr_partner[r * 64 + lane]; // the chain of the other input polynomial
+#if EOC_OWN_EARLY
+        if constexpr (L == 2) mac(false, xs[0], rc, S);
+        else mac(false, xs[0], ra, S);
+#else
+#if EOC_OWN_LATE
+        if constexpr (L >= 2) load_row(2, h, rb);
+#endif
         mac(false, xs[0], ra, S);
+#endif
         if constexpr (L >= 3) load_row(3, h, ra);
         if constexpr (L >= 2) mac(false, xs[1], rb, S);
         if constexpr (L >= 4) load_row(4, h, rb);

@@ -1,0 +1,537 @@
+// multi.hip -- layer 2 of include/eoc_tfhe_gpu.h: the process-global GPU context behind the host-buffer batch API
+// (eoc_gpu_init[_multi], eoc_upload_cloud_key, eoc_gate_batch, eoc_circuit_run, eoc_stats).
+//
+// Mirrors the reference's single global key context (globalSecretKey / globalPublicKey, ao-tfhe/eoc-tfhe-run.cpp:38-40,
+// reached through the luaopen_tfhe registry, ao-tfhe/eoc-tfhe-bindings.c:128-148): ONE host process, ONE key, any number
+// of GPUs behind it.  SURVEY.md 8e: gates and circuit instances are independent given the cloud key, so every call cuts
+// its instances into contiguous blocks (the same blocks as eoc_tfhe_amd.distributed.shard), one block per device, driven
+// by one host thread per device; the only collective is the one-time replication of the two key images, an RCCL
+// broadcast over xGMI when the devices are distinct (librccl is loaded on demand), device-to-device copies otherwise.
+//
+// Host-buffer traffic of one device: persistent device buffers and pinned staging owned by the slot (no hipMalloc /
+// hipFree per call), the block cut into chunks that alternate between two streams and the engine's two workspace sets, so
+// that the copies of one chunk run under the kernels of the other.  Caller buffers from eoc_host_alloc (pinned) are
+// DMA sources / targets directly; pageable caller buffers go through the runtime's staged copies.
+#include "common.h"
+#include "../../include/eoc_tfhe_gpu.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is dlopen'ed when a broadcast is wanted
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" int eoc_gate_batch_device_ws(eoc_engine *e, int ws_index, int op, const uint8_t *ops, const int32_t *d_in0,
+                                        const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
+                                        void *hip_stream);
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            eoc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                        \
+            return EOC_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+namespace {
+
+struct Slot {
+    int device = 0;
+    eoc_engine *e = nullptr;
+    hipStream_t st[2] = {nullptr, nullptr};
+    // persistent buffers of the gate-batch path: 3 inputs + 1 output, `cap_rows` rows each
+    int32_t *d_io[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap_rows = 0;
+    // persistent wire buffer of the circuit path
+    int32_t *d_wires = nullptr;
+    size_t cap_wire_ints = 0;
+    uint64_t grows = 0; // buffer growths (0 in steady state)
+};
+
+struct Global {
+    std::mutex mu;
+    std::vector<Slot> slots;
+    eoc_params p{};
+    double bcast_s = 0.0;
+    std::string bcast_method = "none";
+    bool key_loaded = false;
+};
+Global G;
+
+// contiguous block of `rank` among `world` (eoc_tfhe_amd.distributed.shard)
+void shard_range(size_t total, int rank, int world, size_t *lo, size_t *hi)
+{
+    size_t base = total / (size_t)world, rem = total % (size_t)world;
+    size_t l = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
+    *lo = l;
+    *hi = l + base + ((size_t)rank < rem ? 1 : 0);
+}
+
+bool is_pinned(const void *p)
+{
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory is reported as an error: clear it
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int slot_reserve_rows(Slot &s, size_t rows, size_t stride_ints)
+{
+    if (rows <= s.cap_rows) return EOC_OK;
+    HIP_TRY(hipSetDevice(s.device));
+    HIP_TRY(hipDeviceSynchronize());
+    size_t cap = std::max<size_t>(rows, 1024);
+    for (int k = 0; k < 4; k++) {
+        hipFree(s.d_io[k]);
+        s.d_io[k] = nullptr;
+    }
+    s.cap_rows = 0;
+    for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc(&s.d_io[k], cap * stride_ints * 4));
+    s.cap_rows = cap;
+    s.grows++;
+    return EOC_OK;
+}
+
+// one device's block of a gate batch: chunks alternate between the slot's two streams / the engine's two workspaces
+int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                    int32_t *out, size_t count, size_t stride_ints)
+{
+    if (!count) return EOC_OK;
+    int rc = slot_reserve_rows(s, count, stride_ints);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s.device));
+    const int32_t *h[3] = {in0, in1, in2};
+    const bool pinned = is_pinned(in0) && is_pinned(in1) && is_pinned(in2) && is_pinned(out);
+    // chunking pays only when the copies are true DMA (pinned) and every chunk still fills the device reasonably
+    size_t nchunks = 1;
+    if (pinned && count >= 512) nchunks = count >= 4096 ? 4 : 2;
+    if (const char *c = getenv("EOC_TFHE_HOST_CHUNKS")) nchunks = std::max(1, atoi(c));
+    nchunks = std::min(nchunks, count);
+    const size_t row_bytes = stride_ints * 4;
+    for (size_t c = 0; c < nchunks; c++) {
+        size_t lo, hi;
+        shard_range(count, (int)c, (int)nchunks, &lo, &hi);
+        const size_t cnt = hi - lo;
+        if (!cnt) continue;
+        hipStream_t st = s.st[c & 1];
+        for (int k = 0; k < 3; k++)
+            if (h[k])
+                HIP_TRY(hipMemcpyAsync(s.d_io[k] + lo * stride_ints, h[k] + lo * stride_ints, cnt * row_bytes,
+                                       hipMemcpyHostToDevice, st));
+        rc = eoc_gate_batch_device_ws(s.e, (int)(c & 1), op, ops ? ops + lo : nullptr, in0 ? s.d_io[0] + lo * stride_ints : nullptr,
+                                      in1 ? s.d_io[1] + lo * stride_ints : nullptr, in2 ? s.d_io[2] + lo * stride_ints : nullptr,
+                                      s.d_io[3] + lo * stride_ints, cnt, st);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + lo * stride_ints, s.d_io[3] + lo * stride_ints, cnt * row_bytes, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(s.st[0]));
+    if (nchunks > 1) HIP_TRY(hipStreamSynchronize(s.st[1]));
+    return EOC_OK;
+}
+
+// one device's block of circuit instances [lo, hi) of a host wire array [n_wires][instances][stride]
+int slot_circuit_block(Slot &s, const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires, size_t instances,
+                       size_t lo, size_t hi, size_t stride_ints)
+{
+    const size_t blk = hi - lo;
+    if (!blk) return EOC_OK;
+    HIP_TRY(hipSetDevice(s.device));
+    const size_t need = n_wires * blk * stride_ints;
+    if (need > s.cap_wire_ints) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipFree(s.d_wires);
+        s.d_wires = nullptr;
+        s.cap_wire_ints = 0;
+        HIP_TRY(hipMalloc(&s.d_wires, need * 4));
+        s.cap_wire_ints = need;
+        s.grows++;
+    }
+    hipStream_t st = s.st[0];
+    // strided block copy: row w of the device array holds instances [lo, hi) of wire w
+    HIP_TRY(hipMemcpy2DAsync(s.d_wires, blk * stride_ints * 4, wires + lo * stride_ints, instances * stride_ints * 4,
+                             blk * stride_ints * 4, n_wires, hipMemcpyHostToDevice, st));
+    int rc = eoc_circuit_run_device(s.e, gates, n_gates, s.d_wires, n_wires, blk, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(wires + lo * stride_ints, instances * stride_ints * 4, s.d_wires, blk * stride_ints * 4,
+                             blk * stride_ints * 4, n_wires, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return EOC_OK;
+}
+
+void destroy_slots_locked()
+{
+    for (auto &s : G.slots) {
+        hipSetDevice(s.device);
+        hipDeviceSynchronize();
+        for (int k = 0; k < 4; k++) hipFree(s.d_io[k]);
+        hipFree(s.d_wires);
+        for (int k = 0; k < 2; k++)
+            if (s.st[k]) hipStreamDestroy(s.st[k]);
+        eoc_engine_destroy(s.e);
+    }
+    G.slots.clear();
+    G.key_loaded = false;
+    G.bcast_s = 0.0;
+    G.bcast_method = "none";
+}
+
+// ---- RCCL, loaded on demand ---------------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        return CommInitAll && Broadcast && GroupStart && GroupEnd && CommDestroy && GetErrorString;
+    }
+} R;
+
+// replicate the two key images of slot 0 onto every other slot.  Returns the method used.
+int replicate_key_locked(const void *bk0, const void *ksk0, std::vector<void *> &bk, std::vector<void *> &ksk)
+{
+    const size_t nb = eoc_bkfft_bytes(&G.p), nk = eoc_ksk_dev_bytes(&G.p);
+    const int n = (int)G.slots.size();
+    bool distinct = true;
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++) distinct &= G.slots[i].device != G.slots[j].device;
+    const char *force = getenv("EOC_TFHE_KEY_BCAST"); // "rccl" | "copy"
+    bool use_rccl = distinct && n > 1 && !(force && !strcmp(force, "copy"));
+    if (use_rccl && !R.load()) {
+        if (force && !strcmp(force, "rccl")) {
+            eoc_set_error("EOC_TFHE_KEY_BCAST=rccl but librccl could not be loaded: %s", dlerror());
+            return EOC_ERR_STATE;
+        }
+        use_rccl = false;
+    }
+    if (use_rccl) {
+        std::vector<ncclComm_t> comms(n);
+        std::vector<int> devs(n);
+        for (int i = 0; i < n; i++) devs[i] = G.slots[i].device;
+        ncclResult_t r = R.CommInitAll(comms.data(), n, devs.data());
+        if (r != ncclSuccess) {
+            eoc_set_error("ncclCommInitAll failed: %s; falling back to peer copies", R.GetErrorString(r));
+            use_rccl = false;
+        } else {
+            for (int img = 0; img < 2 && r == ncclSuccess; img++) {
+                R.GroupStart();
+                for (int i = 0; i < n; i++) {
+                    void *buf = img == 0 ? bk[i] : ksk[i];
+                    r = R.Broadcast(buf, buf, img == 0 ? nb : nk, ncclChar, 0, comms[i], G.slots[i].st[0]);
+                    if (r != ncclSuccess) break;
+                }
+                ncclResult_t r2 = R.GroupEnd();
+                if (r == ncclSuccess) r = r2;
+            }
+            for (int i = 0; i < n; i++) {
+                hipSetDevice(G.slots[i].device);
+                hipStreamSynchronize(G.slots[i].st[0]);
+            }
+            for (int i = 0; i < n; i++) R.CommDestroy(comms[i]);
+            if (r != ncclSuccess) {
+                eoc_set_error("ncclBroadcast failed: %s", R.GetErrorString(r));
+                return EOC_ERR_HIP;
+            }
+            G.bcast_method = "rccl";
+            return EOC_OK;
+        }
+    }
+    // device-to-device copies from slot 0 (the only form available when several engines share one device)
+    for (int i = 1; i < n; i++) {
+        HIP_TRY(hipSetDevice(G.slots[i].device));
+        if (G.slots[i].device == G.slots[0].device) {
+            HIP_TRY(hipMemcpyAsync(bk[i], bk0, nb, hipMemcpyDeviceToDevice, G.slots[i].st[0]));
+            HIP_TRY(hipMemcpyAsync(ksk[i], ksk0, nk, hipMemcpyDeviceToDevice, G.slots[i].st[0]));
+        } else {
+            HIP_TRY(hipMemcpyPeerAsync(bk[i], G.slots[i].device, bk0, G.slots[0].device, nb, G.slots[i].st[0]));
+            HIP_TRY(hipMemcpyPeerAsync(ksk[i], G.slots[i].device, ksk0, G.slots[0].device, nk, G.slots[i].st[0]));
+        }
+    }
+    for (int i = 1; i < n; i++) {
+        HIP_TRY(hipSetDevice(G.slots[i].device));
+        HIP_TRY(hipStreamSynchronize(G.slots[i].st[0]));
+    }
+    G.bcast_method = n > 1 ? "peer-copy" : "none";
+    return EOC_OK;
+}
+
+template <class F> int for_each_slot(F fn)
+{ // one host thread per device (inline when there is only one)
+    const int n = (int)G.slots.size();
+    if (n == 1) return fn(0);
+    std::vector<int> rcs(n, EOC_OK);
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (int i = 0; i < n; i++) th.emplace_back([&, i] { rcs[i] = fn(i); });
+    for (auto &t : th) t.join();
+    for (int rc : rcs)
+        if (rc) return rc;
+    return EOC_OK;
+}
+
+} // namespace
+
+// ---- public API -----------------------------------------------------------------------------------------------------
+extern "C" void eoc_shard_range(size_t total, int rank, int world, size_t *lo, size_t *hi)
+{
+    if (world < 1 || rank < 0 || rank >= world) {
+        *lo = *hi = 0;
+        return;
+    }
+    shard_range(total, rank, world, lo, hi);
+}
+
+extern "C" int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_params *p)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (!G.slots.empty()) {
+        eoc_set_error("eoc_gpu_init: engine already initialised");
+        return EOC_ERR_STATE;
+    }
+    if (!devices || n_devices < 1 || n_devices > 64 || !p) {
+        eoc_set_error("eoc_gpu_init_multi: bad arguments");
+        return EOC_ERR_ARG;
+    }
+    G.p = *p;
+    G.slots.resize(n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        Slot &s = G.slots[i];
+        s.device = devices[i];
+        int rc = eoc_engine_create(devices[i], p, &s.e);
+        if (rc == EOC_OK) {
+            if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.st[0], hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&s.st[1], hipStreamNonBlocking) != hipSuccess) {
+                eoc_set_error("eoc_gpu_init_multi: stream creation failed on device %d", s.device);
+                rc = EOC_ERR_HIP;
+            }
+        }
+        if (rc) {
+            destroy_slots_locked();
+            return rc;
+        }
+    }
+    return EOC_OK;
+}
+extern "C" int eoc_gpu_init(int device, const eoc_params *p) { return eoc_gpu_init_multi(&device, 1, p); }
+
+// EOC_TFHE_DEVICES = "all" | "0,1,2,..." | unset (device 0): what a Lua / Node host sets to put several GPUs behind
+// the reference-style global key without any change to its calls
+extern "C" int eoc_gpu_init_from_env(const eoc_params *p)
+{
+    const char *s = getenv("EOC_TFHE_DEVICES");
+    std::vector<int> devs;
+    if (!s || !*s) devs.push_back(0);
+    else if (!strcmp(s, "all")) {
+        int c = eoc_device_count();
+        for (int i = 0; i < c; i++) devs.push_back(i);
+        if (devs.empty()) devs.push_back(0);
+    } else {
+        const char *q = s;
+        while (*q) {
+            char *end = nullptr;
+            long v = strtol(q, &end, 10);
+            if (end == q) {
+                eoc_set_error("EOC_TFHE_DEVICES: cannot parse '%s'", s);
+                return EOC_ERR_ARG;
+            }
+            devs.push_back((int)v);
+            q = *end == ',' ? end + 1 : end;
+        }
+    }
+    return eoc_gpu_init_multi(devs.data(), (int)devs.size(), p);
+}
+
+extern "C" int eoc_gpu_engine_count(void)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    return (int)G.slots.size();
+}
+extern "C" eoc_engine *eoc_global_engine_at(int i)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    return (i >= 0 && (size_t)i < G.slots.size()) ? G.slots[i].e : nullptr;
+}
+extern "C" eoc_engine *eoc_global_engine(void) { return eoc_global_engine_at(0); }
+
+extern "C" void eoc_gpu_shutdown(void)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    destroy_slots_locked();
+}
+
+extern "C" int eoc_stats(uint64_t out[3])
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (G.slots.empty()) {
+        eoc_set_error("eoc_stats: no global engine (eoc_gpu_init)");
+        return EOC_ERR_STATE;
+    }
+    out[0] = out[1] = out[2] = 0;
+    for (auto &s : G.slots) {
+        uint64_t t[3];
+        int rc = eoc_engine_stats(s.e, t);
+        if (rc) return rc;
+        for (int k = 0; k < 3; k++) out[k] += t[k];
+    }
+    return EOC_OK;
+}
+// per-device counters [engines][3], seconds the key replication took, and how it was done
+extern "C" int eoc_stats_multi(uint64_t *per_device, int cap_devices, double *key_broadcast_seconds)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (G.slots.empty()) {
+        eoc_set_error("eoc_stats_multi: no global engine (eoc_gpu_init)");
+        return EOC_ERR_STATE;
+    }
+    const int n = (int)G.slots.size();
+    for (int i = 0; i < n && i < cap_devices; i++) {
+        int rc = eoc_engine_stats(G.slots[i].e, per_device + 3 * (size_t)i);
+        if (rc) return rc;
+    }
+    if (key_broadcast_seconds) *key_broadcast_seconds = G.bcast_s;
+    return n;
+}
+extern "C" const char *eoc_key_broadcast_method(void)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    static thread_local std::string copy;
+    copy = G.bcast_method;
+    return copy.c_str();
+}
+extern "C" uint64_t eoc_host_path_buffer_grows(void)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    uint64_t t = 0;
+    for (auto &s : G.slots) t += s.grows;
+    return t;
+}
+
+extern "C" int eoc_upload_cloud_key_arrays(const int32_t *bk, const int32_t *ksk)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (G.slots.empty()) {
+        eoc_set_error("eoc_upload_cloud_key: call eoc_gpu_init first");
+        return EOC_ERR_STATE;
+    }
+    if (!bk || !ksk) return EOC_ERR_NO_KEY;
+    // images are built once, on the first device (H2D of the torus form, forward transforms on the GPU, KSK padding)
+    int rc = eoc_engine_load_cloud_key(G.slots[0].e, bk, ksk);
+    if (rc) return rc;
+    const int n = (int)G.slots.size();
+    G.bcast_s = 0.0;
+    G.bcast_method = "none";
+    if (n > 1) {
+        const void *bk0 = nullptr, *ksk0 = nullptr;
+        rc = eoc_engine_cloud_key_device(G.slots[0].e, &bk0, &ksk0);
+        if (rc) return rc;
+        std::vector<void *> dbk(n, nullptr), dksk(n, nullptr);
+        dbk[0] = const_cast<void *>(bk0);
+        dksk[0] = const_cast<void *>(ksk0);
+        for (int i = 1; i < n; i++) {
+            // the engine owns replicas allocated through its own allocator entry points
+            rc = eoc_device_alloc(G.slots[i].e, eoc_bkfft_bytes(&G.p), &dbk[i]);
+            if (rc == EOC_OK) rc = eoc_device_alloc(G.slots[i].e, eoc_ksk_dev_bytes(&G.p), &dksk[i]);
+            if (rc) return rc;
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        rc = replicate_key_locked(bk0, ksk0, dbk, dksk);
+        G.bcast_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) return rc;
+        for (int i = 1; i < n; i++) {
+            rc = eoc_engine_adopt_cloud_key_device(G.slots[i].e, dbk[i], dksk[i]);
+            if (rc) return rc;
+        }
+    }
+    G.key_loaded = true;
+    return EOC_OK;
+}
+extern "C" int eoc_upload_cloud_key(const eoc_secret_key *sk)
+{
+    if (!sk || !eoc_sk_bk(sk) || !eoc_sk_ksk(sk)) return EOC_ERR_NO_KEY;
+    return eoc_upload_cloud_key_arrays(eoc_sk_bk(sk), eoc_sk_ksk(sk));
+}
+
+extern "C" void *eoc_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        eoc_set_error("eoc_host_alloc: hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void eoc_host_free(void *p)
+{
+    if (p) hipHostFree(p);
+}
+
+extern "C" int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                              int32_t *out, size_t count)
+{
+    std::lock_guard<std::mutex> g(G.mu); // calls on the global context are serialised, as in the reference (one global key)
+    if (G.slots.empty()) {
+        eoc_set_error("eoc_gate_batch: no GPU engine (eoc_gpu_init not called or failed); there is no CPU fallback");
+        return EOC_ERR_NO_DEVICE;
+    }
+    const bool const_only = !ops && (op == EOC_CONST0 || op == EOC_CONST1);
+    if (!out || (!in0 && !const_only)) {
+        eoc_set_error("eoc_gate_batch: null argument");
+        return EOC_ERR_ARG;
+    }
+    if (!count) return EOC_OK;
+    const size_t stride = (size_t)G.p.n + 1;
+    const int world = (int)G.slots.size();
+    return for_each_slot([&](int i) {
+        size_t lo, hi;
+        shard_range(count, i, world, &lo, &hi);
+        return slot_gate_block(G.slots[i], op, ops ? ops + lo : nullptr, in0 ? in0 + lo * stride : nullptr,
+                               in1 ? in1 + lo * stride : nullptr, in2 ? in2 + lo * stride : nullptr, out + lo * stride,
+                               hi - lo, stride);
+    });
+}
+
+extern "C" int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires, size_t instances)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (G.slots.empty()) {
+        eoc_set_error("eoc_circuit_run: no GPU engine; there is no CPU fallback");
+        return EOC_ERR_NO_DEVICE;
+    }
+    if (!gates || !wires) return EOC_ERR_ARG;
+    if (!n_gates || !instances) return EOC_OK;
+    const size_t stride = (size_t)G.p.n + 1;
+    const int world = (int)G.slots.size();
+    // a whole circuit instance stays on one device: no wire ever crosses GPUs
+    return for_each_slot([&](int i) {
+        size_t lo, hi;
+        shard_range(instances, i, world, &lo, &hi);
+        return slot_circuit_block(G.slots[i], gates, n_gates, wires, n_wires, instances, lo, hi, stride);
+    });
+}

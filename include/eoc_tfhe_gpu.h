@@ -118,8 +118,7 @@ int eoc_device_to_host(eoc_engine *e, void *dst, const void *d_src, size_t bytes
 int eoc_engine_synchronize(eoc_engine *e);
 
 /* device-side key image sizes in bytes: BK-FFT [n][2l][2][512] complex f64 (bin order sigma, values
- * scaled by 2^-41: the image carries the inverse transform's 1/512 and the 2^-32 of the final wrap-around
- * rounding, an exact power-of-two scaling),
+ * scaled by 2^-9: the image carries the inverse transform's 1/512, an exact power-of-two scaling),
  * KSK [N*t][base-1][n1p] int32 (rows d = 1..base-1, zero-padded to n1p = eoc_ksk_row_stride) */
 size_t eoc_bkfft_bytes(const eoc_params *p);
 size_t eoc_ksk_dev_bytes(const eoc_params *p);
@@ -135,14 +134,27 @@ int eoc_engine_build_cloud_key_device(eoc_engine *e, const int32_t *bk, const in
 /* adopt caller-owned device images (e.g. buffers filled by an RCCL broadcast); not freed by the
  * engine; must stay valid while the engine uses them */
 int eoc_engine_set_cloud_key_device(eoc_engine *e, const void *d_bkfft, const void *d_ksk);
+/* take OWNERSHIP of device images allocated with eoc_device_alloc on this engine (key replicas filled by a
+ * broadcast or a peer copy); the engine frees them */
+int eoc_engine_adopt_cloud_key_device(eoc_engine *e, void *d_bkfft, void *d_ksk);
 /* borrow the engine's images (for broadcasting them, or for parity checks) */
 int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void **d_ksk);
 
-/* Concurrency: calls on one engine are serialised by a mutex and share one workspace, so an engine must be
+/* Concurrency: calls on one engine are serialised by a mutex and share one workspace set, so an engine must be
  * driven from ONE stream at a time (launches of successive calls on the same stream are ordered; use one
- * engine per stream, or synchronise, if several streams are needed).  Workspaces grow on demand outside
- * the kernels (hipMalloc), so the first call at a new maximum size is not capturable into a hipGraph.
- *
+ * engine per stream, or synchronise, if several streams are needed).  Workspaces (device buffers and the pinned
+ * host ring that carries gate descriptors) grow on demand outside the kernels (device synchronise + hipMalloc);
+ * eoc_engine_reserve sizes them once, after which the launch path neither allocates nor synchronises and a fixed
+ * netlist / batch shape can be captured into a hipGraph.  eoc_engine_workspace_grows counts growths since the
+ * last reserve (0 in steady state).
+ *   max_jobs       : blind rotations of the widest level (instances x gates of the level, MUX counts twice)
+ *   max_descs      : gate descriptors sent between two wrap-arounds of the ring (>= gates of the netlist)
+ *   max_mixed_rows : rows of the largest mixed (ops != NULL) batch, 0 if none */
+int eoc_engine_reserve(eoc_engine *e, size_t max_jobs, size_t max_descs, size_t max_mixed_rows);
+uint64_t eoc_engine_workspace_grows(eoc_engine *e);
+int eoc_engine_device(eoc_engine *e);
+const eoc_params *eoc_engine_params(eoc_engine *e);
+/*
  * one homogeneous or mixed batch of independent gates, all operands resident on the device.
  *   op      : opcode when ops == NULL
  *   ops     : HOST array [count] of opcodes in any order, or NULL (equal opcodes are grouped on the device:
@@ -195,14 +207,41 @@ int eoc_engine_kernel_times(eoc_engine *e, double ms[3], uint64_t launches[3], i
 int eoc_engine_stats(eoc_engine *e, uint64_t out[3]);
 
 /* ------------------------------------------------------------------------------------------------
- * batch API (host buffers; synchronous: H2D, kernels, D2H).  Uses the global engine on device 0
- * unless eoc_gpu_init() chose another one.
+ * batch API (host buffers; synchronous: H2D, kernels, D2H) on the process-global GPU context: ONE host process and
+ * ONE key -- the reference's globalSecretKey / globalPublicKey (ao-tfhe/eoc-tfhe-run.cpp:38-40) behind the
+ * luaopen_tfhe registry (ao-tfhe/eoc-tfhe-bindings.c:128-148) -- in front of ANY number of GPUs.
+ *   eoc_gpu_init_multi   one engine per listed device (a device may be listed more than once: several engines then
+ *                        share it, which is how a one-GPU box rehearses the N-GPU path)
+ *   eoc_gpu_init         = eoc_gpu_init_multi(&device, 1, p)
+ *   eoc_gpu_init_from_env  devices from EOC_TFHE_DEVICES = "all" | "0,1,2,..." (unset: device 0); what the string API
+ *                        uses on first gate call, so a Lua / Node host scales without changing its calls
+ *   eoc_upload_cloud_key the two key images are built once on the first device and replicated: ncclBroadcast over
+ *                        xGMI (librccl, loaded on demand) when the devices are distinct, device-to-device / peer copies
+ *                        otherwise (EOC_TFHE_KEY_BCAST = rccl | copy forces one).  Keys are replicated, never sharded.
+ *   eoc_gate_batch / eoc_circuit_run  cut their instances into contiguous blocks (eoc_shard_range: blocks differ by at
+ *                        most one, the same blocks as eoc_tfhe_amd.distributed.shard), one block per engine, one host
+ *                        thread per engine; a whole circuit instance stays on one device; no data-path collective.
+ *                        Per device: persistent device buffers, the block cut into chunks on two streams so that
+ *                        copies run under kernels; buffers from eoc_host_alloc (pinned) are DMA'd directly.
  * ---------------------------------------------------------------------------------------------- */
-int eoc_gpu_init(int device, const eoc_params *p);     /* create the global engine */
-int eoc_upload_cloud_key(const eoc_secret_key *sk);    /* push sk's BK/KSK to the global engine */
-eoc_engine *eoc_global_engine(void);
+int eoc_gpu_init(int device, const eoc_params *p);
+int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_params *p);
+int eoc_gpu_init_from_env(const eoc_params *p);
+int eoc_gpu_engine_count(void);
+int eoc_upload_cloud_key(const eoc_secret_key *sk);    /* push sk's BK/KSK to every engine of the global context */
+int eoc_upload_cloud_key_arrays(const int32_t *bk, const int32_t *ksk); /* same from raw torus-form arrays */
+eoc_engine *eoc_global_engine(void);                   /* engine 0 */
+eoc_engine *eoc_global_engine_at(int i);
 void eoc_gpu_shutdown(void);
-int eoc_stats(uint64_t out[3]);                        /* eoc_engine_stats of the global engine */
+int eoc_stats(uint64_t out[3]);                        /* eoc_engine_stats summed over the engines */
+/* per_device[engines][3] counters; returns the number of engines; key replication time and method */
+int eoc_stats_multi(uint64_t *per_device, int cap_devices, double *key_broadcast_seconds);
+const char *eoc_key_broadcast_method(void);            /* "rccl" | "peer-copy" | "none" */
+uint64_t eoc_host_path_buffer_grows(void);             /* growths of the persistent I/O buffers (0 in steady state) */
+void eoc_shard_range(size_t total, int rank, int world, size_t *lo, size_t *hi);
+/* pinned host memory for I/O buffers of the batch API (true DMA, chunked overlap); release with eoc_host_free */
+void *eoc_host_alloc(size_t bytes);
+void eoc_host_free(void *p);
 int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
                    const int32_t *in2, int32_t *out, size_t count);
 int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,

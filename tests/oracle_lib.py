@@ -72,6 +72,8 @@ def lib():
         L.orc_gate_batch.argtypes = [PP, f64p, i32p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, i32p, C.c_size_t, C.c_int]
         L.orc_max_threads.restype = C.c_int
+        L.orc_dbg_max_conv.restype = C.c_double
+        L.orc_dbg_max_conv.argtypes = [C.c_int]
         _lib = L
     return _lib
 

@@ -80,34 +80,41 @@ def test_config5_string_equality_1024x32(eoc, rig):
     assert np.array_equal(got, (~diff).astype(np.uint8))
 
 
-def test_config4_mixed_gates_one_shard(eoc, rig):
-    """1M mixed gates {NAND, XOR, MUX} sharded over 8 GPUs = 131072 gates per GPU: this is rank 0's block
-    (eoc_tfhe_amd.distributed.shard), op stream from seed 4; decrypt-checked in full, oracle-checked on a slice."""
+def test_config4_mixed_gates_all_eight_shards(eoc, rig):
+    """1M mixed gates {NAND, XOR, MUX} sharded over 8 GPUs = 131072 gates per GPU (eoc_tfhe_amd.distributed.shard),
+    op stream from seed 4.  One GPU evaluates ALL EIGHT blocks one after the other, exactly as the eight ranks would:
+    every gate of the 2^20 is decrypt-checked, and a slice of every block (all three opcodes) is compared with the
+    oracle bit for bit."""
     from eoc_tfhe_amd.distributed import shard
     p, sk, eng = rig
     torch = torch_cuda()
     total = 1 << 20
-    lo, hi = shard(total, 0, 8)
-    cnt = hi - lo
     rng = np.random.default_rng(4)
     ops_all = rng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), total)
-    ops = ops_all[lo:hi]                   # arbitrary order: the engine groups equal opcodes on the device
-    b = [np.random.default_rng(40 + k).integers(0, 2, cnt).astype(np.uint8) for k in range(3)]
-    c = [to_dev(sk.encrypt_bits(b[k], 5000 + k, lo)) for k in range(3)]
-    out = torch.empty_like(c[0])
-    before = eng.stats()["bootstraps"]
-    eng.gate_batch_device(0, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), out.data_ptr(), cnt, ops=ops)
-    sync()
-    n_mux = int((ops == eoc.OPS["MUX"]).sum())
-    assert eng.stats()["bootstraps"] - before == cnt + n_mux      # MUX = 2 blind rotations
-    got = out.cpu().numpy()
-    want = np.where(ops == eoc.OPS["NAND"], 1 - (b[0] & b[1]),
-                    np.where(ops == eoc.OPS["XOR"], b[0] ^ b[1], np.where(b[0] == 1, b[1], b[2])))
-    assert np.array_equal(sk.decrypt_bits(got), want)
     orc = ol.Oracle(0, 1)
-    idx = np.concatenate([np.flatnonzero(ops == o)[:6] for o in np.unique(ops)])
-    h = [x.cpu().numpy()[idx] for x in c]
-    assert np.array_equal(got[idx], orc.gate_batch(0, h[0], h[1], h[2], ops=ops[idx]))
+    covered = 0
+    for rank in range(8):
+        lo, hi = shard(total, rank, 8)
+        cnt = hi - lo
+        covered += cnt
+        ops = ops_all[lo:hi]               # arbitrary order: the engine groups equal opcodes on the device
+        b = [np.random.default_rng(40 + 10 * rank + k).integers(0, 2, cnt).astype(np.uint8) for k in range(3)]
+        c = [to_dev(sk.encrypt_bits(b[k], 5000 + k, lo)) for k in range(3)]
+        out = torch.empty_like(c[0])
+        before = eng.stats()["bootstraps"]
+        eng.gate_batch_device(0, c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), out.data_ptr(), cnt, ops=ops)
+        sync()
+        n_mux = int((ops == eoc.OPS["MUX"]).sum())
+        assert eng.stats()["bootstraps"] - before == cnt + n_mux      # MUX = 2 blind rotations
+        got = out.cpu().numpy()
+        want = np.where(ops == eoc.OPS["NAND"], 1 - (b[0] & b[1]),
+                        np.where(ops == eoc.OPS["XOR"], b[0] ^ b[1], np.where(b[0] == 1, b[1], b[2])))
+        assert np.array_equal(sk.decrypt_bits(got), want), f"shard {rank}"
+        idx = np.concatenate([np.flatnonzero(ops == o)[:4] for o in np.unique(ops)])
+        h = [x.cpu().numpy()[idx] for x in c]
+        assert np.array_equal(got[idx], orc.gate_batch(0, h[0], h[1], h[2], ops=ops[idx])), f"shard {rank}"
+        del c, out
+    assert covered == total
 
 
 def test_single_launch_262144_gates(eoc, rig):

@@ -1,0 +1,129 @@
+"""Multi-GPU inside the C ABI: ONE process, ONE global key, several engines.  A one-GPU box
+rehearses the N-GPU path by listing device 0 several times (eoc_gpu_init_multi): same sharding, same replication code
+(device-to-device copies instead of the RCCL broadcast), results compared with the oracle bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpu_util import torch_cuda
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eoc(built_lib):
+    torch_cuda()
+    import eoc_tfhe_amd
+    return eoc_tfhe_amd
+
+
+@pytest.fixture()
+def ctx3(eoc):
+    """global context with three engines on device 0, Set A with a short LWE dimension (fast oracle)"""
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    eoc.gpu_shutdown()
+    eoc.gpu_init(p, devices=[0, 0, 0])
+    eoc.upload_cloud_key(sk)
+    orc = ol.Oracle(0, 9, n_override=40)
+    yield p, sk, orc
+    eoc.gpu_shutdown()
+
+
+def test_blocks_are_distributed_shard(eoc, ctx3):
+    from eoc_tfhe_amd.distributed import shard
+    for total in (0, 1, 2, 3, 11, 1024, 1 << 20):
+        for world in (1, 2, 3, 8):
+            assert [eoc.shard_range(total, r, world) for r in range(world)] == [shard(total, r, world) for r in range(world)]
+
+
+def test_gate_batch_three_engines_ragged(eoc, ctx3):
+    p, sk, orc = ctx3
+    assert eoc.gpu_engine_count() == 3
+    st = eoc.stats_multi()
+    assert st["key_broadcast_method"] == "peer-copy" and st["key_broadcast_s"] > 0
+    total = 11                                   # blocks 4 + 4 + 3
+    rng = np.random.default_rng(1)
+    b0, b1, b2 = (rng.integers(0, 2, total).astype(np.uint8) for _ in range(3))
+    c0, c1, c2 = sk.encrypt_bits(b0, 2, 0), sk.encrypt_bits(b1, 3, 0), sk.encrypt_bits(b2, 4, 0)
+    before = [e["bootstraps"] for e in eoc.stats_multi()["engines"]]
+    out = eoc.gate_batch(eoc.OPS["NAND"], c0, c1)
+    after = [e["bootstraps"] for e in eoc.stats_multi()["engines"]]
+    assert [a - b for a, b in zip(after, before)] == [4, 4, 3]
+    assert np.array_equal(sk.decrypt_bits(out), 1 - (b0 & b1))
+    assert np.array_equal(out, orc.gate_batch(ol.OPS["NAND"], c0, c1))
+    # MUX (two blind rotations per gate) and a mixed batch in arbitrary opcode order
+    out = eoc.gate_batch(eoc.OPS["MUX"], c0, c1, c2)
+    assert np.array_equal(out, orc.gate_batch(ol.OPS["MUX"], c0, c1, c2))
+    ops = np.array([0, 10, 4, 4, 11, 0, 10, 2, 13, 4, 14], np.uint8)
+    out = eoc.gate_batch(0, c0, c1, c2, ops=ops)
+    assert np.array_equal(out, orc.gate_batch(0, c0, c1, c2, ops=ops))
+    # fewer gates than engines: empty blocks are skipped
+    out = eoc.gate_batch(eoc.OPS["XOR"], c0[:2], c1[:2])
+    assert np.array_equal(out, orc.gate_batch(ol.OPS["XOR"], c0[:2], c1[:2]))
+    # bootsCONSTANT needs no operand at all
+    out = eoc.gate_batch(eoc.OPS["CONST1"], None, count=5, rowlen=p.n + 1)
+    assert np.array_equal(sk.decrypt_bits(out), np.ones(5, np.uint8)) and not out[:, :-1].any()
+
+
+def test_circuit_run_instances_stay_on_one_engine(eoc, ctx3):
+    from eoc_tfhe_amd import circuits
+    p, sk, orc = ctx3
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(4)
+    S = 7                                        # blocks 3 + 2 + 2
+    rng = np.random.default_rng(3)
+    A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+    wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+    for i in range(4):
+        wires[aw[0] + i] = sk.encrypt_bits(((A >> i) & 1).astype(np.uint8), 100 + i, 0)
+        wires[bw[0] + i] = sk.encrypt_bits(((B >> i) & 1).astype(np.uint8), 200 + i, 0)
+    ref = wires.copy()
+    eoc.circuit_run(gates, wires, S)
+    tot = sum(sk.decrypt_bits(wires[sw[0] + i]).astype(np.int64) << i for i in range(5))
+    assert np.array_equal(tot, A + B)
+    # the oracle evaluates the same netlist gate by gate on the whole instance range
+    for g in gates:
+        i0 = ref[g.in0] if g.in0 >= 0 else None
+        i1 = ref[g.in1] if g.in1 >= 0 else None
+        i2 = ref[g.in2] if g.in2 >= 0 else None
+        ref[g.out] = orc.gate_batch(g.op, i0, i1, i2)
+    assert np.array_equal(wires[sw[0]: sw[0] + 5], ref[sw[0]: sw[0] + 5])
+
+
+def test_pinned_io_and_steady_state_buffers(eoc, ctx3):
+    """eoc_host_alloc buffers are DMA'd directly (chunks on two streams); a second call of the same size neither grows
+    the persistent I/O buffers nor the engines' workspaces"""
+    p, sk, orc = ctx3
+    total = 1536                                 # 512 per engine: two chunks each
+    rng = np.random.default_rng(5)
+    b0, b1 = rng.integers(0, 2, total).astype(np.uint8), rng.integers(0, 2, total).astype(np.uint8)
+    pin = [eoc.PinnedArray((total, p.n + 1)) for _ in range(3)]
+    pin[0].array[:] = sk.encrypt_bits(b0, 7, 0)
+    pin[1].array[:] = sk.encrypt_bits(b1, 8, 0)
+    eoc.gate_batch(eoc.OPS["AND"], pin[0].array, pin[1].array, out=pin[2].array)
+    g0 = eoc.stats_multi()["host_buffer_grows"]
+    w0 = [eoc.lib().eoc_engine_workspace_grows(eoc.lib().eoc_global_engine_at(i)) for i in range(3)]
+    pin[2].array[:] = 0
+    eoc.gate_batch(eoc.OPS["AND"], pin[0].array, pin[1].array, out=pin[2].array)
+    assert eoc.stats_multi()["host_buffer_grows"] == g0
+    assert [eoc.lib().eoc_engine_workspace_grows(eoc.lib().eoc_global_engine_at(i)) for i in range(3)] == w0
+    assert np.array_equal(sk.decrypt_bits(pin[2].array), b0 & b1)
+    sl = slice(500, 530)                         # straddles the first block boundary (512)
+    assert np.array_equal(pin[2].array[sl], orc.gate_batch(ol.OPS["AND"], pin[0].array[sl].copy(), pin[1].array[sl].copy()))
+    # pageable operands give the same bits
+    out = eoc.gate_batch(eoc.OPS["AND"], pin[0].array.copy(), pin[1].array.copy())
+    assert np.array_equal(out, pin[2].array)
+    for a in pin:
+        a.free()
+
+
+def test_operand_shape_checks(eoc, ctx3):
+    p, sk, orc = ctx3
+    c = sk.encrypt_bits(np.zeros(4, np.uint8), 1, 0)
+    with pytest.raises(eoc.EocError):
+        eoc.gate_batch(eoc.OPS["NAND"], c, c[:3])            # short second operand
+    with pytest.raises(eoc.EocError):
+        eoc.gate_batch(eoc.OPS["NAND"], c[:, :-1], c[:, :-1])  # wrong row length
+    with pytest.raises(eoc.EocError):
+        eoc.gate_batch(0, c, c, ops=np.zeros(3, np.uint8))    # one opcode per row

@@ -203,16 +203,15 @@ def test_full_size_set_a_truth_tables_and_parity(eoc, rig_a):
 
 
 def test_full_size_batch_parity_set_a(eoc, rig_a):
-    """BASELINE config 2 shape at a size the oracle finishes in seconds: 96 NAND gates, bit-exact;
-    then 1024 gates checked by decryption (truth) and by re-running a slice through the oracle."""
+    """BASELINE config 2 at its full size: 1024 NAND gates, decrypt-checked AND compared with the oracle bit for bit
+    (all 1024; the oracle runs OpenMP over the gates, about a second on the GPU box's host cores)."""
     r = rig_a
     cnt = 1024
     b0, c0 = _rand_cts(r, cnt, 2, 0)
     b1, c1 = _rand_cts(r, cnt, 3, 0)
     got = r.gate(eoc.OPS["NAND"], c0, c1)
     assert np.array_equal(r.sk.decrypt_bits(got), 1 - (b0 & b1))
-    sl = slice(0, 96)
-    assert np.array_equal(got[sl], r.orc.gate_batch(ol.OPS["NAND"], c0[sl], c1[sl]))
+    assert np.array_equal(got, r.orc.gate_batch(ol.OPS["NAND"], c0, c1))
     # determinism: same inputs, same bits
     assert np.array_equal(got, r.gate(eoc.OPS["NAND"], c0, c1))
 

@@ -203,6 +203,24 @@ def test_bootstrap_noise_and_truth_many(orc_a):
     assert np.array_equal(o.decrypt_bits(out2), w ^ np.roll(w, 1))
 
 
+def test_conversion_range_stays_below_2_pow_51(orc_a):
+    """a10: the HIP kernel converts with trunc + (1.5 * 2^52) and reads the low dword, which equals upstream's
+    Torus32(int64(x)) for |x| < 2^51.  The oracle keeps the largest magnitude it ever converted: real bootstraps stay
+    near 2^45, six binary orders below the limit."""
+    o = orc_a
+    o.L.orc_dbg_max_conv(1)
+    rng = np.random.default_rng(5)
+    b0, b1 = rng.integers(0, 2, 16), rng.integers(0, 2, 16)
+    out = o.gate_batch(ol.OPS["NAND"], o.encrypt_bits(b0, 21, 0), o.encrypt_bits(b1, 22, 0))
+    assert np.array_equal(o.decrypt_bits(out), 1 - (b0 & b1))
+    mx = o.L.orc_dbg_max_conv(0)
+    assert 2.0**38 < mx < 2.0**48, mx
+    ob = ol.Oracle(1, 1)
+    ob.L.orc_dbg_max_conv(1)
+    ob.gate_batch(ol.OPS["NAND"], ob.encrypt_bits(b0[:4], 21, 0), ob.encrypt_bits(b1[:4], 22, 0))
+    assert ob.L.orc_dbg_max_conv(0) < 2.0**48
+
+
 def test_oracle_under_asan_ubsan(tmp_path):
     """the oracle's C code under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only)"""
     import subprocess

@@ -3,7 +3,7 @@
 # only: no --kernel-trace/--sys-trace combined with --pmc).  Usage: tools/pmc_passes.sh <outdir> [bench args]
 set -e
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline"}
+ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline --no-secondary"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { # name, counters...

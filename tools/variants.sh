@@ -15,7 +15,7 @@ for flags in "" "$@"; do
   (
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result -w $flags \
        -c "$ROOT/eoc_tfhe_amd/csrc/engine.hip" -o "$B/var_engine_$i.o" &&
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 "$B/var_engine_$i.o" "$B/host.o" "$B/legacy.o" -o "$B/var_$i.so" -lgomp -Wl,-rpath,/opt/rocm/lib
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 "$B/var_engine_$i.o" "$B/multi.o" "$B/host.o" "$B/legacy.o" -o "$B/var_$i.so" -lgomp -ldl -Wl,-rpath,/opt/rocm/lib
   ) &
   pids+=($!)
   echo "$i|$flags" >> "$B/variants.txt"
@@ -27,7 +27,7 @@ cat > "$B/run_variants.sh" <<'EOS'
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 while IFS='|' read -r i flags; do
-  res=$(EOC_TFHE_LIB=$PWD/eoc_tfhe_amd/_build/var_$i.so python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline ${BENCH_ARGS} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernels_ms'], d['value'], 'ok' if d['decrypt_ok'] else 'WRONG-RESULT')")
+  res=$(EOC_TFHE_LIB=$PWD/eoc_tfhe_amd/_build/var_$i.so python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-secondary ${BENCH_ARGS} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernels_ms'], d['value'], 'ok' if d['decrypt_ok'] else 'WRONG-RESULT')")
   echo "[$i] flags='$flags' -> $res"
 done < eoc_tfhe_amd/_build/variants.txt
 EOS
