@@ -60,6 +60,8 @@ struct eoc_engine {
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
     int num_cus = 256;
     int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
+    int prio_multi = -1;                    // duty code of launches of several rounds (EOC_TFHE_PRIO_MULTI)
+    int br_slice = 0;                       // jobs per blind-rotate launch: 0 = resident set, < 0 = unlimited (EOC_TFHE_BR_SLICE)
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
     uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
@@ -213,6 +215,8 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->num_cus = cus;
         if (const char *s = getenv("EOC_TFHE_PRIO_DUTY")) e->prio_duty_override = atoi(s);
+        if (const char *s = getenv("EOC_TFHE_PRIO_MULTI")) e->prio_multi = atoi(s);
+        if (const char *s = getenv("EOC_TFHE_BR_SLICE")) e->br_slice = atoi(s);
     }
     // key-switch kernels use > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
 #define EOC_KS_ATTR(BB, TT, NWV, JBV, CWV)                                                                       \
@@ -487,36 +491,49 @@ extern "C" int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, 
 // ---- launch helpers -------------------------------------------------------------------------
 typedef eoc_engine::Workspace WS;
 
-static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs, hipStream_t st)
+// One launch holds at most `br_slice` jobs (default: what is resident at once, four workgroups per CU): a launch in
+// which every workgroup is resident from the start runs with the wave-priority alternation and finishes all its
+// workgroups within half a per cent of each other (3.0 ms per 1024 jobs), while a launch of several rounds settles at
+// a 10 % lower rate (the arbiter's age bias), so wide levels are cut into back-to-back single-round launches.
+static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipStream_t st)
 {
-    BRArgs a;
-    a.bkfft = e->bkfft;
-    a.bara = W.d_bara;
-    a.u = W.d_u;
-    a.njobs = njobs;
-    a.n = e->p.n;
-    a.Bgbit = e->p.Bgbit;
-    a.bara_stride = e->bara_stride;
-    a.mu = (int32_t)(1u << 29);
-    a.stamps = e->d_stamps;
-    // priority alternation pays only when every workgroup is resident from the start (four per CU)
-    a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
-                  : (njobs <= 4u * (uint32_t)e->num_cus ? EOC_PRIO_DUTY : -1);
-    dim3 grid(njobs), block(128);
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
-    if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
-        hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
-    else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
-        hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
-    else
-        switch (e->p.l) {
-        case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-        case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-        case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-        case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-        default: return EOC_ERR_ARG;
-        }
-    HIP_TRY(hipGetLastError());
+    const uint32_t resident = 4u * (uint32_t)e->num_cus;
+    uint32_t slice = e->br_slice > 0 ? (uint32_t)e->br_slice : (e->br_slice == 0 ? resident : njobs_total);
+    {   // even slices: 1536 jobs run as 768 + 768, not 1024 + 512
+        const uint32_t nsl = (njobs_total + slice - 1) / slice;
+        slice = (njobs_total + nsl - 1) / nsl;
+    }
+    for (uint32_t off = 0; off < njobs_total; off += slice) {
+        const uint32_t njobs = std::min(slice, njobs_total - off);
+        BRArgs a;
+        a.bkfft = e->bkfft;
+        a.bara = W.d_bara + (size_t)off * e->bara_stride;
+        a.u = W.d_u + (size_t)off * (kN + 1);
+        a.njobs = njobs;
+        a.n = e->p.n;
+        a.Bgbit = e->p.Bgbit;
+        a.bara_stride = e->bara_stride;
+        a.mu = (int32_t)(1u << 29);
+        a.stamps = e->d_stamps;
+        // priority alternation pays only when every workgroup is resident from the start (four per CU)
+        a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
+                      : (njobs <= resident ? EOC_PRIO_DUTY : e->prio_multi);
+        dim3 grid(njobs), block(128);
+        if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
+            hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+        else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
+            hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+        else
+            switch (e->p.l) {
+            case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+            case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+            case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+            case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+            default: return EOC_ERR_ARG;
+            }
+        HIP_TRY(hipGetLastError());
+    }
     return EOC_OK;
 }
 

@@ -735,6 +735,14 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
                 __builtin_amdgcn_s_setprio(EOC_PRIO_HI);
             else
                 __builtin_amdgcn_s_setprio(0);
+        } else if (A.prio_duty <= -2) {
+            // launches of several rounds: the co-resident waves are at unrelated steps, so the alternation is taken
+            // from the shader clock both of them read (phase length 2^(-prio_duty) cycles), even shares
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if ((int)((now >> (-A.prio_duty)) & 1) == (prio_slot & 1))
+                __builtin_amdgcn_s_setprio(EOC_PRIO_HI);
+            else
+                __builtin_amdgcn_s_setprio(0);
         }
 #endif
         const int abar = __builtin_amdgcn_readfirstlane(abar_next);

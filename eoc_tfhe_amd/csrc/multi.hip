@@ -8,10 +8,9 @@
 // by one host thread per device; the only collective is the one-time replication of the two key images, an RCCL
 // broadcast over xGMI when the devices are distinct (librccl is loaded on demand), device-to-device copies otherwise.
 //
-// Host-buffer traffic of one device: persistent device buffers and pinned staging owned by the slot (no hipMalloc /
-// hipFree per call), the block cut into chunks that alternate between two streams and the engine's two workspace sets, so
-// that the copies of one chunk run under the kernels of the other.  Caller buffers from eoc_host_alloc (pinned) are
-// DMA sources / targets directly; pageable caller buffers go through the runtime's staged copies.
+// Host-buffer traffic of one device: persistent device buffers owned by the slot (no hipMalloc / hipFree per call).
+// Caller buffers from eoc_host_alloc (pinned, device-mapped) are read in place by the linear-stage kernel and receive
+// the result by one asynchronous copy; pageable caller buffers go through the runtime's staged copies.
 #include "common.h"
 #include "../../include/eoc_tfhe_gpu.h"
 
@@ -42,12 +41,20 @@ extern "C" int eoc_gate_batch_device_ws(eoc_engine *e, int ws_index, int op, con
         }                                                                                   \
     } while (0)
 
+// result rows -> caller's pinned, device-mapped buffer (a kernel writes over PCIe at twice the rate of the copy
+// engine's 2 MB transfer and needs no separate queue hand-off)
+__global__ __launch_bounds__(256) void k_copy_words(const int32_t *__restrict__ src, int32_t *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 namespace {
 
 struct Slot {
     int device = 0;
     eoc_engine *e = nullptr;
-    hipStream_t st[2] = {nullptr, nullptr};
+    hipStream_t st[3] = {nullptr, nullptr, nullptr}; // [0] kernels, [1] H2D copies, [2] D2H copies
+    std::vector<hipEvent_t> ev;                       // chunk hand-offs between the three (grown on demand, re-used)
     // persistent buffers of the gate-batch path: 3 inputs + 1 output, `cap_rows` rows each
     int32_t *d_io[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap_rows = 0;
@@ -104,7 +111,13 @@ int slot_reserve_rows(Slot &s, size_t rows, size_t stride_ints)
     return EOC_OK;
 }
 
-// one device's block of a gate batch: chunks alternate between the slot's two streams / the engine's two workspaces
+// one device's block of a gate batch.  Pinned caller buffers (eoc_host_alloc) are mapped into the device's address
+// space: the linear stage (k_prepare / k_free_gates) reads the operands straight from host memory over PCIe, so no
+// H2D copy and no staging exist on that path; the result is produced in a persistent device buffer (the key switch
+// accumulates with atomics) and a small kernel writes it into the caller's mapped buffer.  Pageable buffers take the
+// runtime's staged copies into the persistent device buffers.  (Cutting a 1024-gate batch into chunks on two streams
+// was measured and dropped: kernels of two streams do not run concurrently here, 2 x 512 gates take 4.65 ms against
+// 3.29 ms for 1 x 1024; chunking is used from 8192 gates on, where every chunk fills the device by itself.)
 int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,
                     int32_t *out, size_t count, size_t stride_ints)
 {
@@ -113,31 +126,92 @@ int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, con
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s.device));
     const int32_t *h[3] = {in0, in1, in2};
-    const bool pinned = is_pinned(in0) && is_pinned(in1) && is_pinned(in2) && is_pinned(out);
-    // chunking pays only when the copies are true DMA (pinned) and every chunk still fills the device reasonably
-    size_t nchunks = 1;
-    if (pinned && count >= 512) nchunks = count >= 4096 ? 4 : 2;
-    if (const char *c = getenv("EOC_TFHE_HOST_CHUNKS")) nchunks = std::max(1, atoi(c));
-    nchunks = std::min(nchunks, count);
-    const size_t row_bytes = stride_ints * 4;
-    for (size_t c = 0; c < nchunks; c++) {
-        size_t lo, hi;
-        shard_range(count, (int)c, (int)nchunks, &lo, &hi);
-        const size_t cnt = hi - lo;
-        if (!cnt) continue;
-        hipStream_t st = s.st[c & 1];
-        for (int k = 0; k < 3; k++)
-            if (h[k])
-                HIP_TRY(hipMemcpyAsync(s.d_io[k] + lo * stride_ints, h[k] + lo * stride_ints, cnt * row_bytes,
-                                       hipMemcpyHostToDevice, st));
-        rc = eoc_gate_batch_device_ws(s.e, (int)(c & 1), op, ops ? ops + lo : nullptr, in0 ? s.d_io[0] + lo * stride_ints : nullptr,
-                                      in1 ? s.d_io[1] + lo * stride_ints : nullptr, in2 ? s.d_io[2] + lo * stride_ints : nullptr,
-                                      s.d_io[3] + lo * stride_ints, cnt, st);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out + lo * stride_ints, s.d_io[3] + lo * stride_ints, cnt * row_bytes, hipMemcpyDeviceToHost, st));
+    const bool zero_copy = !getenv("EOC_TFHE_NO_ZERO_COPY");
+    bool pin[3] = {false, false, false};
+    const int32_t *dmap[3] = {nullptr, nullptr, nullptr};
+    bool all_pinned = true;
+    for (int k = 0; k < 3; k++) {
+        if (!h[k]) continue;
+        pin[k] = is_pinned(h[k]);
+        if (pin[k]) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, const_cast<int32_t *>(h[k]), 0) == hipSuccess && dp) dmap[k] = static_cast<const int32_t *>(dp);
+            else (void)hipGetLastError();
+        }
+        all_pinned &= pin[k];
     }
-    HIP_TRY(hipStreamSynchronize(s.st[0]));
-    if (nchunks > 1) HIP_TRY(hipStreamSynchronize(s.st[1]));
+    int32_t *out_map = nullptr;
+    if (is_pinned(out)) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp) out_map = static_cast<int32_t *>(dp);
+        else (void)hipGetLastError();
+    }
+    all_pinned &= out_map != nullptr;
+    // Batches wider than one resident set, from pinned buffers: chunks of 1024 gates (one single-round blind-rotate
+    // launch each).  ALL kernels stay on one stream (kernels of different streams do not overlap on this device and
+    // would only interleave their launches); the copy engines run beside them on two copy streams: every chunk's
+    // operands are DMA'd ahead, and a chunk's result leaves while the next chunk computes.  Exposed: the first chunk's
+    // H2D and the last chunk's D2H, 6 MB in all, whatever the batch size.
+    size_t nchunks = 1;
+    if (all_pinned && count > 1024) nchunks = (count + 1023) / 1024;
+    if (const char *c = getenv("EOC_TFHE_HOST_CHUNKS")) nchunks = std::min<size_t>(std::max(1, atoi(c)), count);
+    if (nchunks > 1) {
+        const size_t row_bytes = stride_ints * 4;
+        while (s.ev.size() < 2 * nchunks) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            s.ev.push_back(e);
+        }
+        for (size_t c = 0; c < nchunks; c++) { // operands of every chunk, queued back to back on the H2D stream
+            size_t lo, hi;
+            shard_range(count, (int)c, (int)nchunks, &lo, &hi);
+            for (int k = 0; k < 3; k++)
+                if (h[k])
+                    HIP_TRY(hipMemcpyAsync(s.d_io[k] + lo * stride_ints, h[k] + lo * stride_ints, (hi - lo) * row_bytes,
+                                           hipMemcpyHostToDevice, s.st[1]));
+            HIP_TRY(hipEventRecord(s.ev[2 * c], s.st[1]));
+        }
+        for (size_t c = 0; c < nchunks; c++) {
+            size_t lo, hi;
+            shard_range(count, (int)c, (int)nchunks, &lo, &hi);
+            const size_t cnt = hi - lo;
+            HIP_TRY(hipStreamWaitEvent(s.st[0], s.ev[2 * c], 0));
+            rc = eoc_gate_batch_device_ws(s.e, 0, op, ops ? ops + lo : nullptr, h[0] ? s.d_io[0] + lo * stride_ints : nullptr,
+                                          h[1] ? s.d_io[1] + lo * stride_ints : nullptr,
+                                          h[2] ? s.d_io[2] + lo * stride_ints : nullptr, s.d_io[3] + lo * stride_ints, cnt, s.st[0]);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(s.ev[2 * c + 1], s.st[0]));
+            HIP_TRY(hipStreamWaitEvent(s.st[2], s.ev[2 * c + 1], 0));
+            HIP_TRY(hipMemcpyAsync(out + lo * stride_ints, s.d_io[3] + lo * stride_ints, cnt * row_bytes,
+                                   hipMemcpyDeviceToHost, s.st[2]));
+        }
+        HIP_TRY(hipStreamSynchronize(s.st[2]));
+        HIP_TRY(hipStreamSynchronize(s.st[0]));
+        return EOC_OK;
+    }
+    hipStream_t st = s.st[0];
+    const size_t bytes = count * stride_ints * 4;
+    const int32_t *d[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++) {
+        if (!h[k]) continue;
+        if (zero_copy && dmap[k]) {
+            d[k] = dmap[k]; // read in place over PCIe by k_prepare / k_free_gates
+            continue;
+        }
+        HIP_TRY(hipMemcpyAsync(s.d_io[k], h[k], bytes, hipMemcpyHostToDevice, st));
+        d[k] = s.d_io[k];
+    }
+    rc = eoc_gate_batch_device_ws(s.e, 0, op, ops, d[0], d[1], d[2], s.d_io[3], count, st);
+    if (rc) return rc;
+    if (zero_copy && out_map) {
+        const size_t n = count * stride_ints;
+        hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st,
+                           s.d_io[3], out_map, n);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(out, s.d_io[3], bytes, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
     return EOC_OK;
 }
 
@@ -177,8 +251,9 @@ void destroy_slots_locked()
         hipDeviceSynchronize();
         for (int k = 0; k < 4; k++) hipFree(s.d_io[k]);
         hipFree(s.d_wires);
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < 3; k++)
             if (s.st[k]) hipStreamDestroy(s.st[k]);
+        for (auto e : s.ev) hipEventDestroy(e);
         eoc_engine_destroy(s.e);
     }
     G.slots.clear();
@@ -327,7 +402,8 @@ extern "C" int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_p
         int rc = eoc_engine_create(devices[i], p, &s.e);
         if (rc == EOC_OK) {
             if (hipSetDevice(s.device) != hipSuccess || hipStreamCreateWithFlags(&s.st[0], hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&s.st[1], hipStreamNonBlocking) != hipSuccess) {
+                hipStreamCreateWithFlags(&s.st[1], hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&s.st[2], hipStreamNonBlocking) != hipSuccess) {
                 eoc_set_error("eoc_gpu_init_multi: stream creation failed on device %d", s.device);
                 rc = EOC_ERR_HIP;
             }

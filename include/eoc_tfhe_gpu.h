@@ -221,8 +221,8 @@ int eoc_engine_stats(eoc_engine *e, uint64_t out[3]);
  *   eoc_gate_batch / eoc_circuit_run  cut their instances into contiguous blocks (eoc_shard_range: blocks differ by at
  *                        most one, the same blocks as eoc_tfhe_amd.distributed.shard), one block per engine, one host
  *                        thread per engine; a whole circuit instance stays on one device; no data-path collective.
- *                        Per device: persistent device buffers, the block cut into chunks on two streams so that
- *                        copies run under kernels; buffers from eoc_host_alloc (pinned) are DMA'd directly.
+ *                        Per device: persistent device buffers; operands in buffers from eoc_host_alloc (pinned,
+ *                        device-mapped) are read in place by the first kernel, pageable ones are copied.
  * ---------------------------------------------------------------------------------------------- */
 int eoc_gpu_init(int device, const eoc_params *p);
 int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_params *p);

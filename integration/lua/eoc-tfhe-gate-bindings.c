@@ -1,6 +1,11 @@
-/* eoc-tfhe-gate-bindings.c -- text to merge into ao-tfhe/eoc-tfhe-bindings.c (pattern of l_addCiphertexts, :12-24).
- * NOT compiled in this repository: the build image has no Lua 5.3 SDK (lua.h).  The equivalent Node binding,
- * integration/node/eoc_tfhe_node.c, is built and tested.  Needs <lua.h>, <lauxlib.h>, <stdlib.h>. */
+/* eoc-tfhe-gate-bindings.c -- text to merge into ao-tfhe/eoc-tfhe-bindings.c (pattern of l_addCiphertexts, :12-24:
+ * read the arguments, call the extern "C" function, lua_pushstring the heap result, free() it, return 1).
+ * NOT compiled in this repository: the build image has no Lua 5.3 SDK (lua.h); it is written against the Lua 5.3 C API
+ * the reference uses.  The equivalent Node binding, integration/node/eoc_tfhe_node.c, is built and GPU-tested and has
+ * the same entry points.  Needs <lua.h>, <lauxlib.h>, <stdlib.h>, <string.h>.
+ *
+ * Raw-buffer calls take and return Lua strings holding binary data (lua_pushlstring / luaL_checklstring): LWE samples
+ * are int32 little-endian [count][n+1], bit arrays one byte per bit, netlists int32 [5 per gate: op, in0, in1, in2, out]. */
 #include "eoc_tfhe_gpu.h"
 
 static int l_generateGateKey(lua_State *L) {          /* like l_generateSecretKey, :38-48 */
@@ -11,11 +16,18 @@ static int l_generateGateKey(lua_State *L) {          /* like l_generateSecretKe
   free((void *)r);
   return 1;
 }
+static int l_resetGateKey(lua_State *L) { (void)L; resetGateKey(); return 0; }
 static int l_encryptBit(lua_State *L) {               /* like l_encryptInteger, :59-67 */
   int bit = (int)luaL_checkinteger(L, 1);
   const char *key = luaL_optstring(L, 2, "");
   (void)key;                                          /* ignored, as :63 passes NULL */
   const char *r = encryptBit(bit, NULL);
+  lua_pushstring(L, r);
+  free((void *)r);
+  return 1;
+}
+static int l_constantBit(lua_State *L) {              /* bootsCONSTANT: noiseless trivial sample, no key involved */
+  const char *r = constantBit((int)luaL_checkinteger(L, 1));
   lua_pushstring(L, r);
   free((void *)r);
   return 1;
@@ -45,8 +57,101 @@ static int l_gateMUX(lua_State *L) {
                           luaL_optstring(L, 4, ""));
   lua_pushstring(L, r); free((void *)r); return 1;
 }
+static int l_exportSecretKey(lua_State *L) {
+  const char *r = exportSecretKey();
+  lua_pushstring(L, r); free((void *)r); return 1;
+}
+static int l_importSecretKey(lua_State *L) {
+  lua_pushinteger(L, importSecretKey(luaL_checkstring(L, 1)));
+  return 1;
+}
+
+/* ---- raw-buffer batch calls on the global key ---- */
+static int l_sampleInts(lua_State *L) {               /* n + 1 of the global key, or -1 */
+  eoc_params p;
+  lua_pushinteger(L, eoc_global_params(&p) == EOC_OK ? p.n + 1 : -1);
+  return 1;
+}
+static int l_encryptBits(lua_State *L) {              /* (bits: string, one byte per bit) -> samples */
+  size_t count;
+  const char *bits = luaL_checklstring(L, 1, &count);
+  eoc_params p;
+  if (eoc_global_params(&p) != EOC_OK) { lua_pushnil(L); return 1; }
+  size_t bytes = count * (size_t)(p.n + 1) * 4;
+  int32_t *cts = malloc(bytes ? bytes : 1);
+  if (cts && eoc_global_encrypt_bits((const uint8_t *)bits, count, cts) == EOC_OK) lua_pushlstring(L, (const char *)cts, bytes);
+  else lua_pushnil(L);
+  free(cts);
+  return 1;
+}
+static int l_decryptBits(lua_State *L) {              /* (samples) -> bits: string, one byte per bit */
+  size_t bytes;
+  const char *cts = luaL_checklstring(L, 1, &bytes);
+  eoc_params p;
+  if (eoc_global_params(&p) != EOC_OK || bytes % ((size_t)(p.n + 1) * 4)) { lua_pushnil(L); return 1; }
+  size_t count = bytes / ((size_t)(p.n + 1) * 4);
+  uint8_t *bits = malloc(count ? count : 1);
+  if (bits && eoc_global_decrypt_bits((const int32_t *)cts, count, bits) == EOC_OK) lua_pushlstring(L, (const char *)bits, count);
+  else lua_pushnil(L);
+  free(bits);
+  return 1;
+}
+static int l_gateBatch(lua_State *L) {                /* (op, in0, in1 | nil, in2 | nil, ops | nil) -> samples or nil */
+  int op = (int)luaL_checkinteger(L, 1);
+  size_t bytes[3] = {0, 0, 0}, nops = 0;
+  const char *in[3] = {NULL, NULL, NULL}, *ops = NULL;
+  for (int k = 0; k < 3; k++)
+    if (!lua_isnoneornil(L, 2 + k)) in[k] = luaL_checklstring(L, 2 + k, &bytes[k]);
+  if (!lua_isnoneornil(L, 5)) ops = luaL_checklstring(L, 5, &nops);
+  eoc_params p;
+  if (!in[0] || eoc_global_params(&p) != EOC_OK) { lua_pushnil(L); return 1; }
+  const size_t row = (size_t)(p.n + 1) * 4, count = bytes[0] / row;
+  if (bytes[0] % row || (in[1] && bytes[1] != bytes[0]) || (in[2] && bytes[2] != bytes[0]) || (ops && nops != count)) {
+    lua_pushnil(L);                                   /* every supplied operand has in0's length */
+    return 1;
+  }
+  int32_t *out = malloc(bytes[0] ? bytes[0] : 1);
+  if (out && eoc_global_gate_batch(op, (const uint8_t *)ops, (const int32_t *)in[0], (const int32_t *)in[1],
+                                   (const int32_t *)in[2], out, count) == EOC_OK)
+    lua_pushlstring(L, (const char *)out, bytes[0]);
+  else lua_pushnil(L);
+  free(out);
+  return 1;
+}
+static int l_circuitRun(lua_State *L) {               /* (gates, wires, nWires, instances) -> wires after evaluation, or nil */
+  size_t gbytes, wbytes;
+  const char *g = luaL_checklstring(L, 1, &gbytes), *w = luaL_checklstring(L, 2, &wbytes);
+  size_t n_wires = (size_t)luaL_checkinteger(L, 3), inst = (size_t)luaL_checkinteger(L, 4);
+  eoc_params p;
+  if (gbytes % sizeof(eoc_gate) || eoc_global_params(&p) != EOC_OK || wbytes != n_wires * inst * (size_t)(p.n + 1) * 4) {
+    lua_pushnil(L);
+    return 1;
+  }
+  int32_t *wires = malloc(wbytes ? wbytes : 1);       /* Lua strings are immutable: evaluate on a copy */
+  if (wires) memcpy(wires, w, wbytes);
+  if (wires && eoc_global_circuit_run((const eoc_gate *)g, gbytes / sizeof(eoc_gate), wires, n_wires, inst) == EOC_OK)
+    lua_pushlstring(L, (const char *)wires, wbytes);
+  else lua_pushnil(L);
+  free(wires);
+  return 1;
+}
+static int l_netlistOptimize(lua_State *L) {          /* (gates, outputs: int32 wire ids) -> gates or nil */
+  size_t gbytes, obytes;
+  const char *g = luaL_checklstring(L, 1, &gbytes), *o = luaL_checklstring(L, 2, &obytes);
+  if (gbytes % sizeof(eoc_gate) || obytes % 4) { lua_pushnil(L); return 1; }
+  eoc_gate *tmp = malloc(gbytes + sizeof(eoc_gate));
+  int64_t n = tmp ? eoc_netlist_optimize((const eoc_gate *)g, gbytes / sizeof(eoc_gate), (const int32_t *)o, obytes / 4, tmp) : -1;
+  if (n >= 0) lua_pushlstring(L, (const char *)tmp, (size_t)n * sizeof(eoc_gate));
+  else lua_pushnil(L);
+  free(tmp);
+  return 1;
+}
 
 /* appended to the luaL_Reg table of luaopen_tfhe (ao-tfhe/eoc-tfhe-bindings.c:130-144) */
-  {"generateGateKey", l_generateGateKey}, {"encryptBit", l_encryptBit}, {"decryptBit", l_decryptBit},
+  {"generateGateKey", l_generateGateKey}, {"resetGateKey", l_resetGateKey}, {"encryptBit", l_encryptBit},
+  {"constantBit", l_constantBit}, {"decryptBit", l_decryptBit},
   {"gateNAND", l_gateNAND}, {"gateAND", l_gateAND}, {"gateOR", l_gateOR}, {"gateNOR", l_gateNOR},
   {"gateXOR", l_gateXOR}, {"gateXNOR", l_gateXNOR}, {"gateNOT", l_gateNOT}, {"gateMUX", l_gateMUX},
+  {"exportSecretKey", l_exportSecretKey}, {"importSecretKey", l_importSecretKey},
+  {"sampleInts", l_sampleInts}, {"encryptBits", l_encryptBits}, {"decryptBits", l_decryptBits},
+  {"gateBatch", l_gateBatch}, {"circuitRun", l_circuitRun}, {"netlistOptimize", l_netlistOptimize},

@@ -1,24 +1,123 @@
--- tfhe_gates.lua -- text to append to ao-tfhe/tfhe.lua (same pass-through style as :4-53).
--- Not executed in this repository (no Lua interpreter in the image); integration/node/tfhe.js is its tested twin.
+-- tfhe_gates.lua -- text to append to ao-tfhe/tfhe.lua (same pass-through style as :4-53; needs Lua 5.3 string.pack).
+-- Not executed in this repository (no Lua interpreter in the image); integration/node/tfhe.js is its tested twin and has
+-- the same functions with the same netlists.
 function Tfhe.generateGateKey(lambda, seed) return Tfhe.backend.generateGateKey(lambda, seed) end
+function Tfhe.resetGateKey()                return Tfhe.backend.resetGateKey() end
 function Tfhe.encryptBit(bit, key)          return Tfhe.backend.encryptBit(bit, key) end
+function Tfhe.constantBit(bit)              return Tfhe.backend.constantBit(bit) end
 function Tfhe.decryptBit(ct, key)           return Tfhe.backend.decryptBit(ct, key) end
 function Tfhe.nand(a, b, pk)                return Tfhe.backend.gateNAND(a, b, pk) end
+function Tfhe.band(a, b, pk)                return Tfhe.backend.gateAND(a, b, pk) end   -- `and`, `or`, `not` are Lua keywords
+function Tfhe.bor(a, b, pk)                 return Tfhe.backend.gateOR(a, b, pk) end
+function Tfhe.nor(a, b, pk)                 return Tfhe.backend.gateNOR(a, b, pk) end
 function Tfhe.xor(a, b, pk)                 return Tfhe.backend.gateXOR(a, b, pk) end
+function Tfhe.xnor(a, b, pk)                return Tfhe.backend.gateXNOR(a, b, pk) end
+function Tfhe.bnot(a, pk)                   return Tfhe.backend.gateNOT(a, pk) end
 function Tfhe.mux(a, b, c, pk)              return Tfhe.backend.gateMUX(a, b, c, pk) end
--- … and/or/nor/xnor/not likewise
+function Tfhe.exportSecretKey()             return Tfhe.backend.exportSecretKey() end
+function Tfhe.importSecretKey(k)            return Tfhe.backend.importSecretKey(k) end
 
--- 8-bit ripple-carry adder over bit-sliced ciphertext tables (LSB first): 2 XOR + 2 AND + 1 OR per bit
-function Tfhe.addBits(A, B, pk)
-  local S, c = {}, nil
-  for i = 1, #A do
-    local p = Tfhe.xor(A[i], B[i], pk)
-    local g = Tfhe.backend.gateAND(A[i], B[i], pk)
-    if c then
-      S[i] = Tfhe.xor(p, c, pk)
-      c = Tfhe.backend.gateOR(g, Tfhe.backend.gateAND(p, c, pk), pk)
-    else S[i], c = p, g end
+-- ---- circuit layer: netlists evaluated by ONE backend call (circuitRun), batched over instances ----
+-- wires travel as one binary string [nWires][instances][n+1] of int32 samples; a netlist is packed as 5 int32 per gate
+Tfhe.OP = { NAND = 0, AND = 1, OR = 2, NOR = 3, XOR = 4, XNOR = 5, ANDNY = 6, ANDYN = 7, ORNY = 8, ORYN = 9, MUX = 10,
+            NOT = 11, COPY = 12, CONST0 = 13, CONST1 = 14 }
+local OP = Tfhe.OP
+local function newNetlist()
+  local nl = { gates = {}, nWires = 0 }
+  function nl.wire(n) local w = nl.nWires; nl.nWires = nl.nWires + (n or 1); return w end
+  function nl.gate(op, in0, in1, in2)
+    local out = nl.wire()
+    nl.gates[#nl.gates + 1] = string.pack("<i4i4i4i4i4", op, in0, in1 or -1, in2 or -1, out)
+    return out
   end
-  S[#A + 1] = c
-  return S
+  function nl.packed() return table.concat(nl.gates) end
+  return nl
+end
+-- ripple-carry adder, LSB first: half adder at bit 0, then 2 XOR + 2 AND + 1 OR per bit
+function Tfhe.adderNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, sum, c = nl.wire(nbits), nl.wire(nbits), {}, nil
+  for i = 0, nbits - 1 do
+    local p, g = nl.gate(OP.XOR, a + i, b + i), nl.gate(OP.AND, a + i, b + i)
+    if c then
+      sum[#sum + 1] = nl.gate(OP.XOR, p, c)
+      c = nl.gate(OP.OR, g, nl.gate(OP.AND, p, c))
+    else sum[1], c = p, g end
+  end
+  sum[#sum + 1] = c
+  return nl, a, b, sum
+end
+-- equality of two nbits-wide values: XOR per bit, OR tree, NOT (free)
+function Tfhe.equalNetlist(nbits)
+  local nl = newNetlist()
+  local x, y, level = nl.wire(nbits), nl.wire(nbits), {}
+  for i = 0, nbits - 1 do level[#level + 1] = nl.gate(OP.XOR, x + i, y + i) end
+  while #level > 1 do
+    local nxt = {}
+    for i = 1, #level - 1, 2 do nxt[#nxt + 1] = nl.gate(OP.OR, level[i], level[i + 1]) end
+    if #level % 2 == 1 then nxt[#nxt + 1] = level[#level] end
+    level = nxt
+  end
+  return nl, x, y, nl.gate(OP.NOT, level[1])
+end
+-- unsigned a < b (LSB first) and min / max: lt_0 = ANDNY(a_0, b_0); lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i)
+function Tfhe.minMaxNetlist(nbits)
+  local nl = newNetlist()
+  local a, b = nl.wire(nbits), nl.wire(nbits)
+  local lt = nl.gate(OP.ANDNY, a, b)
+  for i = 1, nbits - 1 do lt = nl.gate(OP.MUX, nl.gate(OP.XNOR, a + i, b + i), lt, b + i) end
+  local mn, mx = {}, {}
+  for i = 0, nbits - 1 do
+    mn[#mn + 1] = nl.gate(OP.MUX, lt, a + i, b + i)
+    mx[#mx + 1] = nl.gate(OP.MUX, lt, b + i, a + i)
+  end
+  return nl, a, b, lt, mn, mx
+end
+-- run a netlist over `instances` instances; inputs = { [firstWire] = samples [k][instances][n+1] }
+function Tfhe.runNetlist(nl, inputs, instances)
+  local plane = instances * Tfhe.backend.sampleInts() * 4
+  local parts, w = {}, 0
+  while w < nl.nWires do                                  -- assemble the wire array plane by plane
+    local buf = inputs[w]
+    if buf then parts[#parts + 1] = buf; w = w + #buf // plane
+    else parts[#parts + 1] = string.rep("\0", plane); w = w + 1 end
+  end
+  return Tfhe.backend.circuitRun(nl.packed(), table.concat(parts), nl.nWires, instances)
+end
+local function planes(wires, first, count, instances)
+  local plane = instances * Tfhe.backend.sampleInts() * 4
+  return wires:sub(first * plane + 1, (first + count) * plane)
+end
+-- raw-buffer circuits over many instances: operands are samples [nbits][instances][n+1]
+function Tfhe.addBitsBatch(A, B, nbits, instances)
+  local nl, a, b, sum = Tfhe.adderNetlist(nbits)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  if not wires then return nil end
+  local out = {}
+  for i = 1, #sum do out[i] = planes(wires, sum[i], 1, instances) end
+  return table.concat(out)                                -- [nbits + 1][instances][n+1]
+end
+function Tfhe.equalBits(X, Y)                             -- X, Y: samples [nbits][n+1]; one ciphertext: 1 iff equal
+  local nbits = #X // (Tfhe.backend.sampleInts() * 4)
+  local nl, x, y, out = Tfhe.equalNetlist(nbits)
+  local wires = Tfhe.runNetlist(nl, { [x] = X, [y] = Y }, 1)
+  return wires and planes(wires, out, 1, 1)
+end
+-- a string travels as 8 bit-ciphertexts per byte, LSB first
+function Tfhe.encryptStringBits(str)
+  local bits = {}
+  for i = 1, #str do
+    local c = str:byte(i)
+    for k = 0, 7 do bits[#bits + 1] = string.char((c >> k) & 1) end
+  end
+  return Tfhe.backend.encryptBits(table.concat(bits))
+end
+function Tfhe.equalStrings(X, Y) return Tfhe.equalBits(X, Y) end
+function Tfhe.minMaxBitsBatch(A, B, nbits, instances)
+  local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlist(nbits)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  if not wires then return nil end
+  local lo, hi = {}, {}
+  for i = 1, nbits do lo[i] = planes(wires, mn[i], 1, instances); hi[i] = planes(wires, mx[i], 1, instances) end
+  return table.concat(lo), table.concat(hi), planes(wires, lt, 1, instances)
 end

@@ -7,6 +7,7 @@
  * tests/tfhe.test.js:52,74.  Build: see integration/node/build.sh (gcc, headers from /usr/include/node).
  */
 #include <node_api.h>
+#include <stdbool.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -207,28 +208,111 @@ static napi_value n_decryptBits(napi_env env, napi_callback_info info)
     if (eoc_global_decrypt_bits((const int32_t *)cts, count, (uint8_t *)bits) != EOC_OK) napi_get_null(env, &out);
     return out;
 }
-static napi_value n_gateBatch(napi_env env, napi_callback_info info)
-{ /* (op, Buffer in0, Buffer in1 | null, Buffer in2 | null) -> Buffer out, or null on error (no GPU, ...) */
-    ARGS(4);
-    int op = arg_int(env, argv[0]);
-    void *in[3] = {NULL, NULL, NULL};
-    size_t bytes[3] = {0, 0, 0};
-    for (int k = 0; k < 3; k++) {
-        bool isbuf = false;
-        if (argv[1 + k] && napi_is_buffer(env, argv[1 + k], &isbuf) == napi_ok && isbuf)
-            NAPI_OK(napi_get_buffer_info(env, argv[1 + k], &in[k], &bytes[k]));
-    }
-    eoc_params p;
+static napi_value ret_null(napi_env env)
+{
     napi_value out;
-    if (!in[0] || eoc_global_params(&p) != EOC_OK) { napi_get_null(env, &out); return out; }
-    size_t count = bytes[0] / ((size_t)(p.n + 1) * 4);
-    void *o;
-    NAPI_OK(napi_create_buffer(env, bytes[0], &o, &out));
-    if (eoc_global_gate_batch(op, NULL, (const int32_t *)in[0], (const int32_t *)in[1], (const int32_t *)in[2],
-                              (int32_t *)o, count) != EOC_OK)
-        napi_get_null(env, &out);
+    napi_get_null(env, &out);
     return out;
 }
+static int get_buffer(napi_env env, napi_value v, void **p, size_t *bytes)
+{ /* 1 if v is a Buffer (pointer and length returned), 0 otherwise */
+    bool isbuf = false;
+    *p = NULL;
+    *bytes = 0;
+    if (!v || napi_is_buffer(env, v, &isbuf) != napi_ok || !isbuf) return 0;
+    return napi_get_buffer_info(env, v, p, bytes) == napi_ok;
+}
+static int get_i32_array(napi_env env, napi_value v, int32_t **p, size_t *len)
+{ /* 1 if v is an Int32Array */
+    bool ista = false;
+    *p = NULL;
+    *len = 0;
+    if (!v || napi_is_typedarray(env, v, &ista) != napi_ok || !ista) return 0;
+    napi_typedarray_type t;
+    void *data;
+    napi_value ab;
+    size_t off;
+    if (napi_get_typedarray_info(env, v, &t, len, &data, &ab, &off) != napi_ok || t != napi_int32_array) return 0;
+    *p = (int32_t *)data;
+    return 1;
+}
+static napi_value n_gateBatch(napi_env env, napi_callback_info info)
+{ /* (op, Buffer in0 | null, Buffer in1 | null, Buffer in2 | null, Buffer ops | null, count?) -> Buffer out, or null on
+   * error (no GPU, a supplied operand shorter than in0, length not a multiple of a sample, ...).  `ops` = one opcode
+   * byte per gate (mixed batch).  bootsCONSTANT (op 13 / 14) takes no operand: pass null and the gate count. */
+    ARGS(6);
+    int op = arg_int(env, argv[0]);
+    void *in[3] = {NULL, NULL, NULL}, *ops = NULL;
+    size_t bytes[3] = {0, 0, 0}, nops = 0;
+    for (int k = 0; k < 3; k++) get_buffer(env, argv[1 + k], &in[k], &bytes[k]);
+    get_buffer(env, argv[4], &ops, &nops);
+    eoc_params p;
+    if (eoc_global_params(&p) != EOC_OK) return ret_null(env);
+    const size_t row = (size_t)(p.n + 1) * 4;
+    size_t count;
+    if (in[0]) {
+        if (bytes[0] % row) return ret_null(env);
+        count = bytes[0] / row;
+    } else {
+        if (ops || (op != EOC_CONST0 && op != EOC_CONST1)) return ret_null(env);
+        count = (size_t)arg_int(env, argv[5]);
+    }
+    for (int k = 1; k < 3; k++)
+        if (in[k] && bytes[k] != count * row) return ret_null(env); /* every supplied operand has in0's length */
+    if (ops && nops != count) return ret_null(env);
+    void *o;
+    napi_value out;
+    NAPI_OK(napi_create_buffer(env, count * row, &o, &out));
+    if (eoc_global_gate_batch(op, (const uint8_t *)ops, (const int32_t *)in[0], (const int32_t *)in[1],
+                              (const int32_t *)in[2], (int32_t *)o, count) != EOC_OK)
+        return ret_null(env);
+    return out;
+}
+static napi_value n_circuitRun(napi_env env, napi_callback_info info)
+{ /* (Int32Array gates [5 per gate: op, in0, in1, in2, out], Buffer wires [nWires][instances][n+1], nWires, instances)
+   * -> the same Buffer, evaluated in place (eoc_global_circuit_run), or null on error */
+    ARGS(4);
+    int32_t *g;
+    size_t glen, wbytes;
+    void *w;
+    eoc_params p;
+    if (!get_i32_array(env, argv[0], &g, &glen) || glen % 5 || !get_buffer(env, argv[1], &w, &wbytes) ||
+        eoc_global_params(&p) != EOC_OK)
+        return ret_null(env);
+    const size_t n_wires = (size_t)arg_int(env, argv[2]), inst = (size_t)arg_int(env, argv[3]);
+    if (wbytes != n_wires * inst * (size_t)(p.n + 1) * 4) return ret_null(env);
+    if (eoc_global_circuit_run((const eoc_gate *)g, glen / 5, (int32_t *)w, n_wires, inst) != EOC_OK) return ret_null(env);
+    return argv[1];
+}
+static napi_value n_netlistOptimize(napi_env env, napi_callback_info info)
+{ /* (Int32Array gates, Int32Array outputs) -> Int32Array gates (NOT folding, MUX fusion, dead gates dropped) or null */
+    ARGS(2);
+    int32_t *g, *outs;
+    size_t glen, nout;
+    if (!get_i32_array(env, argv[0], &g, &glen) || glen % 5 || !get_i32_array(env, argv[1], &outs, &nout)) return ret_null(env);
+    eoc_gate *tmp = malloc((glen / 5 + 1) * sizeof(eoc_gate));
+    int64_t n = eoc_netlist_optimize((const eoc_gate *)g, glen / 5, outs, nout, tmp);
+    if (n < 0) {
+        free(tmp);
+        return ret_null(env);
+    }
+    napi_value ab, ta;
+    void *data;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)n * sizeof(eoc_gate), &data, &ab));
+    memcpy(data, tmp, (size_t)n * sizeof(eoc_gate));
+    free(tmp);
+    NAPI_OK(napi_create_typedarray(env, napi_int32_array, (size_t)n * 5, ab, 0, &ta));
+    return ta;
+}
+static napi_value n_circuitBootstraps(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    int32_t *g;
+    size_t glen;
+    if (!get_i32_array(env, argv[0], &g, &glen) || glen % 5) return ret_int(env, -1);
+    return ret_int(env, (int)eoc_circuit_bootstraps((const eoc_gate *)g, glen / 5));
+}
+static napi_value n_engineCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_gpu_engine_count()); }
 static napi_value n_deviceCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_device_count()); }
 
 static napi_value init(napi_env env, napi_value exports)
@@ -244,7 +328,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"gateNOR", n_gateNOR}, {"gateXOR", n_gateXOR}, {"gateXNOR", n_gateXNOR}, {"gateNOT", n_gateNOT},
         {"gateMUX", n_gateMUX}, {"exportSecretKey", n_exportSecretKey}, {"importSecretKey", n_importSecretKey},
         {"sampleInts", n_sampleInts}, {"encryptBits", n_encryptBits}, {"decryptBits", n_decryptBits},
-        {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount},
+        {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount}, {"circuitRun", n_circuitRun},
+        {"netlistOptimize", n_netlistOptimize}, {"circuitBootstraps", n_circuitBootstraps}, {"engineCount", n_engineCount},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++) {
         napi_value fn;

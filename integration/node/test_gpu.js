@@ -36,5 +36,32 @@ assert.strictEqual(eq('sixteen byte str', 'sixteen byte str'), 1);
 assert.strictEqual(eq('sixteen byte str', 'sixteen byte stR'), 0);
 assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptStringBits('abc'), tfhe.encryptStringBits('abc')))[0], 1);
 assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptStringBits('abc'), tfhe.encryptStringBits('abd')))[0], 0);
+// 8-bit adder over 4096 input pairs through ONE circuitRun call (BASELINE configs[2] through the Node host)
+{
+  const S = 4096, nb = 8, B = tfhe.backend;
+  const A = [...Array(S).keys()].map(i => (i * 37 + 11) & 255), Bv = [...Array(S).keys()].map(i => (i * 101 + 7) & 255);
+  const planeBits = (vals, k) => Buffer.from(vals.map(v => (v >> k) & 1));
+  const enc = vals => Buffer.concat([...Array(nb).keys()].map(k => B.encryptBits(planeBits(vals, k))));
+  const t0 = Date.now();
+  const sums = tfhe.addBitsBatch(enc(A), enc(Bv), nb, S);
+  const dt = (Date.now() - t0) / 1000;
+  assert.ok(sums, 'circuitRun failed');
+  const w = B.sampleInts() * 4, plane = S * w;
+  const tot = new Array(S).fill(0);
+  for (let k = 0; k <= nb; k++) {
+    const bits = B.decryptBits(sums.slice(k * plane, (k + 1) * plane));
+    for (let i = 0; i < S; i++) tot[i] |= bits[i] << k;
+  }
+  for (let i = 0; i < S; i++) assert.strictEqual(tot[i], A[i] + Bv[i]);
+  const boots = B.circuitBootstraps(tfhe.adderNetlist(nb).nl.packed()) * S;
+  console.log(`node adder8 x ${S}: ${boots} bootstraps in ${dt.toFixed(2)} s (${Math.round(boots / dt)} /s incl. host copies)`);
+  // netlistOptimize: NOT(x) feeding an AND becomes one ANDNY
+  const opt = B.netlistOptimize(Int32Array.from([11, 0, -1, -1, 2, 1, 2, 1, -1, 3]), Int32Array.from([3]));
+  assert.deepStrictEqual(Array.from(opt), [6, 0, 1, -1, 3]);
+  // operand checks: a short second operand is refused instead of being read out of bounds
+  const one = B.encryptBits(Buffer.from([1, 0]));
+  assert.strictEqual(B.gateBatch(0, one, one.slice(0, w), null), null);
+  assert.strictEqual(B.decryptBits(B.gateBatch(14, null, null, null, null, 3)).join(''), '111');   // bootsCONSTANT
+}
 tfhe.backend.resetGateKey();
 console.log('node gpu tests OK');

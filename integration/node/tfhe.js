@@ -35,44 +35,100 @@ Tfhe.xnor = (a, b, pk) => B.gateXNOR(a, b, pk);
 Tfhe.not = (a, pk) => B.gateNOT(a, pk);
 Tfhe.mux = (a, b, c, pk) => B.gateMUX(a, b, c, pk);
 
-// ripple-carry adder over bit-sliced ciphertext arrays (LSB first): 2 XOR + 2 AND + 1 OR per bit
-Tfhe.addBits = (A, Bs, pk) => {
-  const S = [];
-  let c = null;
-  for (let i = 0; i < A.length; i++) {
-    const p = Tfhe.xor(A[i], Bs[i], pk), g = Tfhe.and(A[i], Bs[i], pk);
-    if (c === null) { S.push(p); c = g; } else { S.push(Tfhe.xor(p, c, pk)); c = Tfhe.or(g, Tfhe.and(p, c, pk), pk); }
+// ---- circuit layer: netlists evaluated by ONE backend call (eoc_global_circuit_run), batched over instances --------
+// A netlist is a list of gates {op, in0, in1, in2, out} over numbered wires; wires travel as one Buffer
+// [nWires][instances][n+1] of int32 samples.  The builders mirror eoc_tfhe_amd/circuits.py.
+const OP = { NAND: 0, AND: 1, OR: 2, NOR: 3, XOR: 4, XNOR: 5, ANDNY: 6, ANDYN: 7, ORNY: 8, ORYN: 9, MUX: 10, NOT: 11, COPY: 12,
+             CONST0: 13, CONST1: 14 };
+Tfhe.OP = OP;
+class Netlist {
+  constructor() { this.gates = []; this.nWires = 0; }
+  wire(n = 1) { const w = this.nWires; this.nWires += n; return w; }
+  gate(op, in0, in1 = -1, in2 = -1) { const out = this.wire(); this.gates.push([op, in0, in1, in2, out]); return out; }
+  packed() { return Int32Array.from(this.gates.flat()); }
+}
+Tfhe.Netlist = Netlist;
+// ripple-carry adder, LSB first: half adder at bit 0, then 2 XOR + 2 AND + 1 OR per bit (5 nbits - 3 bootstraps)
+Tfhe.adderNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), sum = [];
+  let c = -1;
+  for (let i = 0; i < nbits; i++) {
+    const p = nl.gate(OP.XOR, a + i, b + i), g = nl.gate(OP.AND, a + i, b + i);
+    if (c < 0) { sum.push(p); c = g; } else { sum.push(nl.gate(OP.XOR, p, c)); c = nl.gate(OP.OR, g, nl.gate(OP.AND, p, c)); }
   }
-  S.push(c);
-  return S;
+  sum.push(c);
+  return { nl, a, b, sum };
 };
-// ASCII string equality: XOR per bit, OR tree, NOT -- batched over the bits with the raw-buffer API
-Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1]
-  const w = B.sampleInts() * 4;
-  let level = B.gateBatch(4 /* XOR */, X, Y, null);
-  let n = level.length / w;
-  while (n > 1) {
-    const half = n >> 1;
-    const a = level.slice(0, half * w), b = level.slice(half * w, 2 * half * w);
-    const next = B.gateBatch(2 /* OR */, Buffer.from(a), Buffer.from(b), null);
-    level = (n & 1) ? Buffer.concat([next, level.slice(2 * half * w)]) : next;
-    n = level.length / w;
+// equality of two nbits-wide values: XOR per bit, OR tree, NOT (free)
+Tfhe.equalNetlist = nbits => {
+  const nl = new Netlist(), x = nl.wire(nbits), y = nl.wire(nbits);
+  let level = [...Array(nbits).keys()].map(i => nl.gate(OP.XOR, x + i, y + i));
+  while (level.length > 1) {
+    const next = [];
+    for (let i = 0; i + 1 < level.length; i += 2) next.push(nl.gate(OP.OR, level[i], level[i + 1]));
+    if (level.length & 1) next.push(level[level.length - 1]);
+    level = next;
   }
-  return B.gateBatch(11 /* NOT */, level, null, null);
+  return { nl, x, y, out: nl.gate(OP.NOT, level[0]) };
+};
+// unsigned a < b, LSB first: lt_0 = ANDNY(a_0, b_0); lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i); min / max by MUX
+Tfhe.minMaxNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  let lt = nl.gate(OP.ANDNY, a, b);
+  for (let i = 1; i < nbits; i++) lt = nl.gate(OP.MUX, nl.gate(OP.XNOR, a + i, b + i), lt, b + i);
+  const min = [], max = [];
+  for (let i = 0; i < nbits; i++) { min.push(nl.gate(OP.MUX, lt, a + i, b + i)); max.push(nl.gate(OP.MUX, lt, b + i, a + i)); }
+  return { nl, a, b, lt, min, max };
+};
+// run a netlist over `instances` instances: inputs = {firstWire: Buffer [k][instances][n+1]}; returns the wire Buffer
+Tfhe.runNetlist = (nl, inputs, instances, outputs) => {
+  const w = B.sampleInts() * 4, plane = instances * w;
+  const wires = Buffer.alloc(nl.nWires * plane);
+  for (const [first, buf] of Object.entries(inputs)) buf.copy(wires, Number(first) * plane);
+  let gates = nl.packed();
+  if (outputs) gates = B.netlistOptimize(gates, Int32Array.from(outputs)) || gates;  // NOT folding, MUX fusion
+  return B.circuitRun(gates, wires, nl.nWires, instances) ? wires : null;
+};
+const planes = (wires, first, count, instances) => {
+  const plane = instances * B.sampleInts() * 4;
+  return wires.slice(first * plane, (first + count) * plane);
+};
+// base64 ciphertext strings <-> raw samples (wire format of export_lweSample_toStream: a[n] | b | f64 variance)
+const strToSample = s => Buffer.from(s, 'base64').slice(0, B.sampleInts() * 4);
+const sampleToStr = buf => Buffer.concat([buf, Buffer.alloc(8)]).toString('base64');
+const stack = arr => Buffer.concat(arr.map(strToSample));
+const unstack = (buf, k) => { const w = B.sampleInts() * 4; return [...Array(k).keys()].map(i => sampleToStr(buf.slice(i * w, (i + 1) * w))); };
+
+// string-API circuits: arrays of base64 bit ciphertexts in, arrays out -- ONE backend call per circuit
+Tfhe.addBits = (A, Bs) => {
+  const { nl, a, b, sum } = Tfhe.adderNetlist(A.length);
+  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1);
+  return wires && sum.map(wi => unstack(planes(wires, wi, 1, 1), 1)[0]);
+};
+Tfhe.lessThanBits = (A, Bs) => {
+  const { nl, a, b, lt } = Tfhe.minMaxNetlist(A.length);
+  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1, [lt]);
+  return wires && unstack(planes(wires, lt, 1, 1), 1)[0];
+};
+Tfhe.minMaxBits = (A, Bs) => {
+  const { nl, a, b, min, max } = Tfhe.minMaxNetlist(A.length);
+  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1);
+  const pick = ws => ws.map(wi => unstack(planes(wires, wi, 1, 1), 1)[0]);
+  return wires && { min: pick(min), max: pick(max) };
+};
+// raw-buffer circuits over many instances: operands are Buffers [nbits][instances][n+1]
+Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {
+  const { nl, a, b, sum } = Tfhe.adderNetlist(nbits);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  return wires && Buffer.concat(sum.map(wi => planes(wires, wi, 1, instances)));   // [nbits + 1][instances][n+1]
+};
+Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1] (one instance)
+  const nbits = X.length / (B.sampleInts() * 4);
+  const { nl, x, y, out } = Tfhe.equalNetlist(nbits);
+  const wires = Tfhe.runNetlist(nl, { [x]: X, [y]: Y }, 1);
+  return wires && planes(wires, out, 1, 1);
 };
 // string helpers of the gate path: a string travels as 8 bit-ciphertexts per byte, LSB first (raw Buffer of samples)
 Tfhe.encryptStringBits = str => B.encryptBits(Buffer.from([...Buffer.from(str)].flatMap(c => [...Array(8).keys()].map(k => (c >> k) & 1))));
 Tfhe.equalStrings = (X, Y) => Tfhe.equalBits(X, Y);   // one ciphertext: 1 iff the two encrypted strings are equal
-// unsigned comparison and min/max over bit-sliced ciphertext arrays (LSB first), string API:
-// lt_0 = (not a_0) and b_0 -- written NOT + AND here; the batch/circuit layer uses bootsANDNY directly --
-// lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i)
-Tfhe.lessThanBits = (A, Bs, pk) => {
-  let lt = Tfhe.and(Tfhe.not(A[0], pk), Bs[0], pk);
-  for (let i = 1; i < A.length; i++) lt = Tfhe.mux(Tfhe.xnor(A[i], Bs[i], pk), lt, Bs[i], pk);
-  return lt;
-};
-Tfhe.minMaxBits = (A, Bs, pk) => {
-  const lt = Tfhe.lessThanBits(A, Bs, pk);
-  return { min: A.map((a, i) => Tfhe.mux(lt, a, Bs[i], pk)), max: A.map((a, i) => Tfhe.mux(lt, Bs[i], a, pk)) };
-};
 module.exports = Tfhe;
