@@ -82,6 +82,11 @@ def lib():
         "eoc_default_params": (C.c_int, [C.c_int, PP]),
         "eoc_params_for_lambda": (C.c_int, [C.c_int, PP]),
         "eoc_keygen": (C.c_int, [PP, u64, C.c_int, C.POINTER(vp)]),
+        "eoc_keygen_secure": (C.c_int, [PP, C.c_int, C.POINTER(vp)]),
+        "eoc_keygen_from_master": (C.c_int, [PP, vp, C.c_int, C.POINTER(vp)]),
+        "eoc_sk_is_secure": (C.c_int, [vp]),
+        "eoc_encrypt_bits_keyed": (C.c_int, [vp, vp, u64, vp, sz, vp]),
+        "eoc_dbg_chacha20_block": (None, [vp, C.c_uint32, vp, vp]),
         "eoc_secret_key_free": (None, [vp]),
         "eoc_sk_params": (PP, [vp]),
         "eoc_sk_lwe_key": (vp, [vp]),
@@ -239,11 +244,21 @@ def _np_view(ptr, count, dtype):
 class SecretKey:
     """TFheGateBootstrappingSecretKeySet: LWE key, TLWE key and (optionally) the cloud key."""
 
-    def __init__(self, params, seed, with_cloud_key=True):
+    def __init__(self, params, seed, with_cloud_key=True, master=None):
+        """seed: int -> reproducible test mode (PRNG v1, shared with the oracle; NOT secure);
+        seed None -> secure mode (getrandom + ChaCha20), or from a 32-byte `master` key"""
         self.L = lib()
         self.h = C.c_void_p()
         self.params = params.copy()
-        _check(self.L.eoc_keygen(C.byref(self.params), seed, int(with_cloud_key), C.byref(self.h)), "eoc_keygen")
+        if master is not None:
+            m = np.frombuffer(bytes(master), np.uint8)
+            assert m.size == 32
+            _check(self.L.eoc_keygen_from_master(C.byref(self.params), m.ctypes.data, int(with_cloud_key), C.byref(self.h)),
+                   "eoc_keygen_from_master")
+        elif seed is None:
+            _check(self.L.eoc_keygen_secure(C.byref(self.params), int(with_cloud_key), C.byref(self.h)), "eoc_keygen_secure")
+        else:
+            _check(self.L.eoc_keygen(C.byref(self.params), seed, int(with_cloud_key), C.byref(self.h)), "eoc_keygen")
         self.n = params.n
         self.seed = seed
 

@@ -99,13 +99,74 @@ static int usable_threads()
 extern "C" int eoc_host_threads(void) { return usable_threads(); }
 
 // ------------------------------------------------------------------------------------------------
-// sampler: counter-based splitmix64 streams (DESIGN.md "PRNG")
+// samplers (DESIGN.md "PRNG").  Two sources behind one counter-stream interface u64(ctr):
+//   v1  splitmix64 finaliser in counter mode, keyed by a 64-bit seed.  REPRODUCIBLE / TEST mode: the oracle has the
+//       same generator, so keys and ciphertexts can be compared bit for bit.  NOT a cryptographic generator: the
+//       finaliser is invertible and the seed has 64 bits, so public masks reveal the stream key.  Never use a seeded
+//       key for data that matters.
+//   v2  ChaCha20 (RFC 8439 block function, 20 rounds): a 256-bit master key from getrandom(2); every stream
+//       (tag, idx) has its own 256-bit sub-key = first half of the block ChaCha20(master, counter 0, nonce (tag, idx)),
+//       its data are the blocks ChaCha20(sub-key, counter = ctr / 8, nonce 0).  Secure mode: eoc_keygen_secure,
+//       generateGateKey(lambda, 0), generateSecretKey, and all encryption on the global context.
 // ------------------------------------------------------------------------------------------------
+#include <sys/random.h>
+namespace eoc_host {
+bool os_random(void *buf, size_t len)
+{
+    unsigned char *p = static_cast<unsigned char *>(buf);
+    size_t got = 0;
+    while (got < len) {
+        ssize_t r = getrandom(p + got, len - got, 0);
+        if (r <= 0) break;
+        got += size_t(r);
+    }
+    if (got == len) return true;
+    if (FILE *f = fopen("/dev/urandom", "rb")) {
+        size_t r = fread(p, 1, len, f);
+        fclose(f);
+        return r == len;
+    }
+    return false;
+}
+} // namespace eoc_host
+
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+static void chacha20_block(const uint32_t key[8], uint64_t counter, const uint32_t nonce[2], uint32_t out[16])
+{ // original ChaCha layout: constants | key | 64-bit block counter | 64-bit nonce
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], uint32_t(counter), uint32_t(counter >> 32), nonce[0], nonce[1]};
+    uint32_t x[16];
+    memcpy(x, s, sizeof x);
+#define EOC_QR(a, b, c, d)                                                   \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7)
+    for (int r = 0; r < 10; r++) {
+        EOC_QR(0, 4, 8, 12); EOC_QR(1, 5, 9, 13); EOC_QR(2, 6, 10, 14); EOC_QR(3, 7, 11, 15);
+        EOC_QR(0, 5, 10, 15); EOC_QR(1, 6, 11, 12); EOC_QR(2, 7, 8, 13); EOC_QR(3, 4, 9, 14);
+    }
+#undef EOC_QR
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+// RFC 8439 layout (32-bit counter, 96-bit nonce) of the same block function, for the known-answer test
+extern "C" void eoc_dbg_chacha20_block(const uint8_t key[32], uint32_t counter, const uint8_t nonce[12], uint8_t out[64])
+{
+    uint32_t k[8], n[3], o[16];
+    memcpy(k, key, 32);
+    memcpy(n, nonce, 12);
+    const uint32_t n2[2] = {n[1], n[2]};
+    chacha20_block(k, uint64_t(counter) | (uint64_t(n[0]) << 32), n2, o);
+    memcpy(out, o, 64);
+}
+
 namespace {
 
 struct Stream {
     enum Tag : uint32_t { LweKey = 1, TlweKey = 2, Bk = 3, Ksk = 4, Enc = 5 };
-    uint64_t key;
+    bool secure = false;
+    uint64_t key = 0;           // v1
+    uint32_t sub[8];            // v2: this stream's ChaCha20 key
+    mutable uint64_t blk = ~uint64_t(0);
+    mutable uint32_t buf[16];
     static uint64_t fin(uint64_t z)
     {
         z ^= z >> 30;
@@ -120,7 +181,31 @@ struct Stream {
         uint64_t a = fin(seed + 0x9E3779B97F4A7C15ull * (uint64_t(tag) + 1));
         key = fin(a ^ (idx * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
     }
-    uint64_t u64(uint64_t ctr) const { return fin(key + 0x9E3779B97F4A7C15ull * (ctr + 1)); }
+    Stream(const uint8_t master[32], Tag tag, uint64_t idx) : secure(true)
+    {
+        uint32_t mk[8], o[16];
+        memcpy(mk, master, 32);
+        const uint32_t nonce[2] = {uint32_t(idx), uint32_t(idx >> 32)};
+        chacha20_block(mk, uint64_t(tag) << 32, nonce, o); // the tag sits in the high counter word: distinct per tag
+        memcpy(sub, o, 32);
+    }
+    // the source a key was made with
+    Stream(const eoc_secret_key &k, Tag tag, uint64_t idx) : Stream(k.seed, tag, idx)
+    {
+        if (k.secure) *this = Stream(k.master, tag, idx);
+    }
+    uint64_t u64(uint64_t ctr) const
+    {
+        if (!secure) return fin(key + 0x9E3779B97F4A7C15ull * (ctr + 1));
+        const uint64_t b = ctr >> 3;
+        if (b != blk) {
+            const uint32_t zero[2] = {0, 0};
+            chacha20_block(sub, b, zero, buf);
+            blk = b;
+        }
+        const int w = int(ctr & 7) * 2;
+        return uint64_t(buf[w]) | (uint64_t(buf[w + 1]) << 32);
+    }
     uint32_t torus(uint64_t ctr) const { return uint32_t(u64(ctr) >> 32); }
     uint32_t bit(uint64_t ctr) const { return uint32_t(u64(ctr) >> 63); }
     // mu + dtot32(N(0, sigma)); Box-Muller cosine branch on counters ctr, ctr+1
@@ -176,7 +261,7 @@ static void make_ksk(eoc_secret_key &k)
         const int d = int(r % nd) + 1, j = int((r / nd) % t), i = int(r / (size_t(nd) * t));
         // message s'_i * d / base^(j+1)   
         uint32_t msg = k.tlwe[i] ? uint32_t(d) << (32 - (j + 1) * bb) : 0u;
-        lwe_encrypt(n, k.lwe.data(), Stream(k.seed, Stream::Ksk, r), msg, p.ks_stdev, &k.ksk[r * (n + 1)]);
+        lwe_encrypt(n, k.lwe.data(), Stream(k, Stream::Ksk, r), msg, p.ks_stdev, &k.ksk[r * (n + 1)]);
     }
 }
 
@@ -191,7 +276,7 @@ static void make_bk(eoc_secret_key &k)
         if (k.tlwe[m]) ones.push_back(m);
 #pragma omp parallel for schedule(dynamic, 8) num_threads(usable_threads())
     for (int ir = 0; ir < p.n * kpl; ir++) {
-        Stream st(k.seed, Stream::Bk, uint64_t(ir));
+        Stream st(k, Stream::Bk, uint64_t(ir));
         uint32_t *a = reinterpret_cast<uint32_t *>(&k.bk[(size_t(ir) * 2) * EOC_N]);
         uint32_t *b = a + EOC_N;
         for (int j = 0; j < EOC_N; j++) {
@@ -212,7 +297,7 @@ static void make_bk(eoc_secret_key &k)
     }
 }
 
-extern "C" int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key, eoc_secret_key **out)
+static int keygen_common(const eoc_params *p, uint64_t seed, const uint8_t *master, int with_cloud_key, eoc_secret_key **out)
 {
     if (!p || !out || p->n < 1 || p->n > 1023 || p->l < 1 || p->l * p->Bgbit > 32 ||
         p->ks_t * p->ks_basebit > 31) {
@@ -223,9 +308,13 @@ extern "C" int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key
     if (!k) return EOC_ERR_ALLOC;
     k->p = *p;
     k->seed = seed;
+    if (master) {
+        k->secure = true;
+        memcpy(k->master, master, 32);
+    }
     k->lwe.resize(p->n);
     k->tlwe.resize(EOC_N);
-    Stream s1(seed, Stream::LweKey, 0), s2(seed, Stream::TlweKey, 0);
+    Stream s1(*k, Stream::LweKey, 0), s2(*k, Stream::TlweKey, 0);
     for (int i = 0; i < p->n; i++) k->lwe[i] = int32_t(s1.bit(uint64_t(i)));
     for (int j = 0; j < EOC_N; j++) k->tlwe[j] = int32_t(s2.bit(uint64_t(j)));
     if (with_cloud_key) {
@@ -235,6 +324,31 @@ extern "C" int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key
     *out = k.release();
     return EOC_OK;
 }
+// REPRODUCIBLE / TEST mode: every key bit, mask and noise sample is a function of the 64-bit seed (PRNG v1, shared
+// with the oracle).  Not secure: see the sampler comment above.
+extern "C" int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key, eoc_secret_key **out)
+{
+    return keygen_common(p, seed, nullptr, with_cloud_key, out);
+}
+// secure mode: 256-bit master key from getrandom(2), ChaCha20 streams (PRNG v2)
+extern "C" int eoc_keygen_secure(const eoc_params *p, int with_cloud_key, eoc_secret_key **out)
+{
+    uint8_t master[32];
+    if (!eoc_host::os_random(master, sizeof master)) {
+        eoc_set_error("eoc_keygen_secure: no entropy source (getrandom and /dev/urandom both failed)");
+        return EOC_ERR_STATE;
+    }
+    int rc = keygen_common(p, 0, master, with_cloud_key, out);
+    memset(master, 0, sizeof master);
+    return rc;
+}
+// the same from a caller-supplied 256-bit master key (key import; known-answer tests)
+extern "C" int eoc_keygen_from_master(const eoc_params *p, const uint8_t master[32], int with_cloud_key, eoc_secret_key **out)
+{
+    if (!master) return EOC_ERR_ARG;
+    return keygen_common(p, 0, master, with_cloud_key, out);
+}
+extern "C" int eoc_sk_is_secure(const eoc_secret_key *sk) { return sk && sk->secure ? 1 : 0; }
 extern "C" void eoc_secret_key_free(eoc_secret_key *sk) { delete sk; }
 extern "C" const eoc_params *eoc_sk_params(const eoc_secret_key *sk) { return sk ? &sk->p : nullptr; }
 extern "C" const int32_t *eoc_sk_lwe_key(const eoc_secret_key *sk) { return sk ? sk->lwe.data() : nullptr; }
@@ -247,6 +361,31 @@ extern "C" int eoc_lwe_encrypt(const eoc_secret_key *sk, uint64_t enc_seed, uint
 {
     if (!sk || !ct) return EOC_ERR_ARG;
     lwe_encrypt(sk->p.n, sk->lwe.data(), Stream(enc_seed, Stream::Enc, idx), uint32_t(mu), sigma, ct);
+    return EOC_OK;
+}
+namespace eoc_host {
+void lwe_encrypt_secure(const eoc_secret_key *sk, const uint8_t enc_key[32], uint64_t idx, int32_t mu, double sigma, int32_t *ct)
+{
+    lwe_encrypt(sk->p.n, sk->lwe.data(), Stream(enc_key, Stream::Enc, idx), uint32_t(mu), sigma, ct);
+}
+void arm_secure_encryption_locked()
+{
+    GlobalCtx &c = ctx();
+    c.enc_secure = os_random(c.enc_key, sizeof c.enc_key);
+    if (!c.enc_secure) fprintf(stderr, "eoc-tfhe: WARNING: no entropy source, encryption falls back to seeded test streams\n");
+    c.enc_counter = 0;
+}
+} // namespace eoc_host
+// bootsSymEncrypt with ChaCha20 randomness under a caller-held 256-bit key: sample s uses stream (enc_key, first_idx + s)
+extern "C" int eoc_encrypt_bits_keyed(const eoc_secret_key *sk, const uint8_t enc_key[32], uint64_t first_idx,
+                                      const uint8_t *bits, size_t count, int32_t *cts)
+{
+    if (!sk || !enc_key || !bits || !cts) return EOC_ERR_ARG;
+    const size_t st = size_t(sk->p.n) + 1;
+    const int32_t one8 = eoc_modswitch_to_torus32(1, 8);
+#pragma omp parallel for schedule(static) num_threads(usable_threads()) if (count >= 64)
+    for (size_t i = 0; i < count; i++)
+        eoc_host::lwe_encrypt_secure(sk, enc_key, first_idx + i, bits[i] ? one8 : -one8, sk->p.ks_stdev, cts + i * st);
     return EOC_OK;
 }
 extern "C" int32_t eoc_lwe_phase(const eoc_secret_key *sk, const int32_t *ct)
@@ -395,10 +534,14 @@ extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
     eoc_params p;
     if (eoc_params_for_lambda(minimum_lambda, &p)) return nullptr;
     eoc_secret_key *sk = nullptr;
-    if (eoc_keygen(&p, seed, 1, &sk)) return nullptr;
+    // seed = 0: secure mode (getrandom + ChaCha20, fresh encryption randomness per process); any other seed: the
+    // reproducible test mode (keys and ciphertexts are functions of the seed -- NOT secure, see the sampler comment)
+    if (seed == 0 ? eoc_keygen_secure(&p, 1, &sk) : eoc_keygen(&p, seed, 1, &sk)) return nullptr;
     c.sk = sk;
     c.enc_seed = mix64(seed ^ 0xA5A5A5A5DEADBEEFull);
     c.enc_counter = 0;
+    c.enc_secure = false;
+    if (seed == 0) arm_secure_encryption_locked();
     c.engine_ready = false;
     if (ensure_engine_locked()) { // the gate key is useless without the engine: fail loudly
         eoc_secret_key_free(sk);
@@ -430,7 +573,8 @@ extern "C" const char *encryptBit(int bit, const char *)
     }
     std::vector<int32_t> ct(c.sk->p.n + 1);
     uint8_t b = bit ? 1 : 0;
-    eoc_encrypt_bits(c.sk, c.enc_seed, c.enc_counter++, &b, 1, ct.data());
+    if (c.enc_secure) eoc_encrypt_bits_keyed(c.sk, c.enc_key, c.enc_counter++, &b, 1, ct.data());
+    else eoc_encrypt_bits(c.sk, c.enc_seed, c.enc_counter++, &b, 1, ct.data());
     return sample_to_b64(ct.data(), c.sk->p.n, c.sk->p.ks_stdev * c.sk->p.ks_stdev);
 }
 
@@ -511,7 +655,8 @@ extern "C" int eoc_global_encrypt_bits(const uint8_t *bits, size_t count, int32_
         fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
         return EOC_ERR_NO_KEY;
     }
-    int rc = eoc_encrypt_bits(c.sk, c.enc_seed, c.enc_counter, bits, count, cts);
+    int rc = c.enc_secure ? eoc_encrypt_bits_keyed(c.sk, c.enc_key, c.enc_counter, bits, count, cts)
+                          : eoc_encrypt_bits(c.sk, c.enc_seed, c.enc_counter, bits, count, cts);
     c.enc_counter += count;
     return rc;
 }

@@ -11,7 +11,9 @@
 // TFheGateBootstrappingSecretKeySet (built at ao-tfhe/eoc-tfhe-run.cpp:231)
 struct eoc_secret_key {
     eoc_params p;
-    uint64_t seed;
+    uint64_t seed;              // reproducible mode (PRNG v1, splitmix64 counter streams): everything derives from it
+    bool secure = false;        // secure mode (PRNG v2): everything derives from `master` through ChaCha20
+    uint8_t master[32] = {0};   // 256 bits from getrandom(2)
     std::vector<int32_t> lwe, tlwe, bk, ksk;
 };
 
@@ -31,9 +33,15 @@ struct GlobalCtx {
     std::mutex mu;
     eoc_secret_key *sk = nullptr;
     uint64_t enc_seed = 0, enc_counter = 0;
+    bool enc_secure = false;    // encryption randomness from ChaCha20 keyed by enc_key (fresh per process, from
+    uint8_t enc_key[32] = {0};  // getrandom(2), independent of the key material) instead of the seeded test streams
     bool engine_ready = false;
 };
 GlobalCtx &ctx();
+bool os_random(void *buf, size_t len);  // getrandom(2), /dev/urandom as a fallback; false if neither works
+// one LWE sample with ChaCha20 randomness: stream (enc_key, idx)
+void lwe_encrypt_secure(const eoc_secret_key *sk, const uint8_t enc_key[32], uint64_t idx, int32_t mu, double sigma, int32_t *ct);
+void arm_secure_encryption_locked();    // draws ctx().enc_key, resets the counter (caller holds ctx().mu)
 int ensure_engine_locked(); // caller holds ctx().mu
 
 } // namespace eoc_host

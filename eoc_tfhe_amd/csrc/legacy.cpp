@@ -82,7 +82,9 @@ const char *no_secret_key()
 // one wide-message sample of the global key: lweSymEncrypt(ct, modSwitchToTorus32(v, Msize), alpha, key)
 void encrypt_wide(GlobalCtx &c, int32_t value, int32_t *ct)
 {
-    eoc_lwe_encrypt(c.sk, c.enc_seed, c.enc_counter++, eoc_modswitch_to_torus32(value, kMsize), kAlpha, ct);
+    const int32_t mu = eoc_modswitch_to_torus32(value, kMsize);
+    if (c.enc_secure) lwe_encrypt_secure(c.sk, c.enc_key, c.enc_counter++, mu, kAlpha, ct);
+    else eoc_lwe_encrypt(c.sk, c.enc_seed, c.enc_counter++, mu, kAlpha, ct);
 }
 
 const char *linear_op(const char *b64a, const char *b64b, int sign)
@@ -107,9 +109,11 @@ const char *linear_op(const char *b64a, const char *b64b, int sign)
 
 // ---- f2: versioned flat key formats --------------------------------------------------------------
 // secret key blob: "EOCSK1\0\0" | n,l,Bgbit,ks_t,ks_basebit (5 x i32) | ks_stdev, bk_stdev (2 x f64) |
-//                  seed u64 | lwe bits (n bytes) | tlwe bits (1024 bytes)
+//                  seed u64 | lwe bits (n bytes) | tlwe bits (1024 bytes)            (reproducible keys, PRNG v1)
+//                  "EOCSK2\0\0" | same params | master key (32 bytes) | lwe bits | tlwe bits  (secure keys, PRNG v2)
 // cloud key blob : "EOCCK1\0\0" | same params | bk int32[eoc_bk_len] | ksk int32[eoc_ksk_len]
 const char kMagicSK[8] = {'E', 'O', 'C', 'S', 'K', '1', 0, 0};
+const char kMagicSK2[8] = {'E', 'O', 'C', 'S', 'K', '2', 0, 0};
 const char kMagicCK[8] = {'E', 'O', 'C', 'C', 'K', '1', 0, 0};
 const size_t kParamBytes = 5 * 4 + 2 * 8;
 
@@ -139,13 +143,15 @@ bool get_params(const unsigned char *o, eoc_params &p)
 extern "C" size_t eoc_secret_key_export(const eoc_secret_key *sk, void *buf, size_t cap)
 {
     if (!sk) return 0;
-    const size_t need = 8 + kParamBytes + 8 + size_t(sk->p.n) + EOC_N;
+    const size_t idlen = sk->secure ? 32 : 8;
+    const size_t need = 8 + kParamBytes + idlen + size_t(sk->p.n) + EOC_N;
     if (!buf || cap < need) return need;
     unsigned char *o = static_cast<unsigned char *>(buf);
-    memcpy(o, kMagicSK, 8);
+    memcpy(o, sk->secure ? kMagicSK2 : kMagicSK, 8);
     put_params(sk->p, o + 8);
-    memcpy(o + 8 + kParamBytes, &sk->seed, 8);
-    unsigned char *bits = o + 8 + kParamBytes + 8;
+    if (sk->secure) memcpy(o + 8 + kParamBytes, sk->master, 32);
+    else memcpy(o + 8 + kParamBytes, &sk->seed, 8);
+    unsigned char *bits = o + 8 + kParamBytes + idlen;
     for (int i = 0; i < sk->p.n; i++) bits[i] = (unsigned char)sk->lwe[i];
     for (int j = 0; j < EOC_N; j++) bits[sk->p.n + j] = (unsigned char)sk->tlwe[j];
     return need;
@@ -159,22 +165,30 @@ extern "C" int eoc_secret_key_import(const void *buf, size_t len, int with_cloud
     }
     const unsigned char *o = static_cast<const unsigned char *>(buf);
     eoc_params p;
-    if (memcmp(o, kMagicSK, 8) != 0 || !get_params(o + 8, p) || len != 8 + kParamBytes + 8 + size_t(p.n) + EOC_N) {
-        eoc_set_error("eoc_secret_key_import: not an EOCSK1 blob");
+    const bool v2 = memcmp(o, kMagicSK2, 8) == 0;
+    const size_t idlen = v2 ? 32 : 8;
+    if ((!v2 && memcmp(o, kMagicSK, 8) != 0) || !get_params(o + 8, p) ||
+        len != 8 + kParamBytes + idlen + size_t(p.n) + EOC_N) {
+        eoc_set_error("eoc_secret_key_import: not an EOCSK1 / EOCSK2 blob");
         return EOC_ERR_ARG;
     }
-    uint64_t seed;
-    memcpy(&seed, o + 8 + kParamBytes, 8);
     eoc_secret_key *sk = nullptr;
-    int rc = eoc_keygen(&p, seed, with_cloud_key, &sk); // keys are a deterministic function of (params, seed)
+    int rc;
+    if (v2) {
+        rc = eoc_keygen_from_master(&p, o + 8 + kParamBytes, with_cloud_key, &sk);
+    } else {
+        uint64_t seed;
+        memcpy(&seed, o + 8 + kParamBytes, 8);
+        rc = eoc_keygen(&p, seed, with_cloud_key, &sk); // keys are a deterministic function of (params, seed)
+    }
     if (rc) return rc;
-    const unsigned char *bits = o + 8 + kParamBytes + 8;
+    const unsigned char *bits = o + 8 + kParamBytes + idlen;
     bool same = true;
     for (int i = 0; i < p.n && same; i++) same = bits[i] == (unsigned char)sk->lwe[i];
     for (int j = 0; j < EOC_N && same; j++) same = bits[p.n + j] == (unsigned char)sk->tlwe[j];
     if (!same) { // a blob written by another PRNG version: refuse rather than hand out a different key
         eoc_secret_key_free(sk);
-        eoc_set_error("eoc_secret_key_import: key bits do not match the seed (PRNG version mismatch)");
+        eoc_set_error("eoc_secret_key_import: key bits do not match the seed / master key (PRNG version mismatch)");
         return EOC_ERR_ARG;
     }
     *out = sk;
@@ -257,7 +271,11 @@ extern "C" int importSecretKey(const char *base64Key)
     if (eoc_secret_key_import(raw.data(), raw.size(), 1, &sk)) return -1;
     c.sk = sk;
     c.enc_seed = mix64(sk->seed ^ 0xA5A5A5A5DEADBEEFull);
-    c.enc_counter = uint64_t(1) << 40; // never reuse the exporter's streams
+    c.enc_counter = uint64_t(1) << 40; // reproducible keys: never reuse the exporter's streams
+    c.enc_secure = false;
+    // a secure (EOCSK2) key encrypts with fresh per-process randomness, independent of the key material; a seeded
+    // (EOCSK1, test-mode) key keeps its seeded streams so that test vectors stay reproducible
+    if (sk->secure) arm_secure_encryption_locked();
     c.engine_ready = false;
     return 0;
 }
@@ -309,14 +327,20 @@ extern "C" const char *generateSecretKey(const char *jwtToken, const char *jwksB
         return nullptr;
     }
     std::cout << "Generating secret key started..." << std::endl;
-    uint32_t seed = uint32_t(lrand48()); // the reference's seeding, unseeded lrand48 and all (:226-228)
+    // The reference seeds libtfhe from an UNSEEDED lrand48() (:226-228): every cold start makes the same key.  That is
+    // not reproduced: the key comes from getrandom(2) through ChaCha20 (eoc_keygen_secure), and so does the encryption
+    // randomness, fresh per process.  EOC_TFHE_LEGACY_SEED=<n> in the environment selects the reproducible test mode.
     eoc_params p;
     if (eoc_params_for_lambda(kMinimumLambda, &p)) return nullptr;
     eoc_secret_key *sk = nullptr;
-    if (eoc_keygen(&p, seed, 1, &sk)) return nullptr;
+    const char *test_seed = getenv("EOC_TFHE_LEGACY_SEED");
+    uint64_t seed = test_seed ? strtoull(test_seed, nullptr, 10) : 0;
+    if (test_seed ? eoc_keygen(&p, seed, 1, &sk) : eoc_keygen_secure(&p, 1, &sk)) return nullptr;
     c.sk = sk;
-    c.enc_seed = mix64(uint64_t(seed) ^ 0xA5A5A5A5DEADBEEFull);
+    c.enc_seed = mix64(seed ^ 0xA5A5A5A5DEADBEEFull);
     c.enc_counter = 0;
+    c.enc_secure = false;
+    if (!test_seed) arm_secure_encryption_locked();
     c.engine_ready = false; // the GPU engine comes up on the first gate call, if there ever is one
     std::vector<unsigned char> blob(eoc_secret_key_export(sk, nullptr, 0));
     eoc_secret_key_export(sk, blob.data(), blob.size());

@@ -76,7 +76,23 @@ int eoc_params_for_lambda(int minimum_lambda, eoc_params *out);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct eoc_secret_key eoc_secret_key; /* TFheGateBootstrappingSecretKeySet */
 
+/* Randomness.  Two modes:
+ *   eoc_keygen(seed)    REPRODUCIBLE / TEST mode (PRNG v1): counter streams of the splitmix64 finaliser keyed by the
+ *                       64-bit seed, the generator the oracle shares, so keys and ciphertexts compare bit for bit.
+ *                       NOT secure: the finaliser is invertible and the seed is short; public masks reveal the
+ *                       stream key.  The same holds for eoc_encrypt_bits / eoc_lwe_encrypt with an explicit enc_seed.
+ *   eoc_keygen_secure   PRNG v2: a 256-bit master key from getrandom(2); every stream is ChaCha20 under its own
+ *                       sub-key.  eoc_encrypt_bits_keyed is the matching encryption under a caller-held 256-bit key.
+ * The string / global API (generateGateKey with seed 0, generateSecretKey, encryptBit, eoc_global_encrypt_bits, ...)
+ * uses the secure mode with encryption randomness drawn fresh per process, independent of the key material. */
 int eoc_keygen(const eoc_params *p, uint64_t seed, int with_cloud_key, eoc_secret_key **out);
+int eoc_keygen_secure(const eoc_params *p, int with_cloud_key, eoc_secret_key **out);
+int eoc_keygen_from_master(const eoc_params *p, const uint8_t master[32], int with_cloud_key, eoc_secret_key **out);
+int eoc_sk_is_secure(const eoc_secret_key *sk);
+int eoc_encrypt_bits_keyed(const eoc_secret_key *sk, const uint8_t enc_key[32], uint64_t first_idx,
+                           const uint8_t *bits, size_t count, int32_t *cts);
+/* RFC 8439 block function (known-answer test of the generator behind the secure mode) */
+void eoc_dbg_chacha20_block(const uint8_t key[32], uint32_t counter, const uint8_t nonce[12], uint8_t out[64]);
 void eoc_secret_key_free(eoc_secret_key *sk);
 const eoc_params *eoc_sk_params(const eoc_secret_key *sk);
 const int32_t *eoc_sk_lwe_key(const eoc_secret_key *sk);  /* [n]   bits */
@@ -251,9 +267,9 @@ int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_
  * string API (reference style; global key context)
  * ---------------------------------------------------------------------------------------------- */
 /* like generateSecretKey (eoc-tfhe-run.cpp:214-250) but for the Boolean path: creates the global
- * secret + cloud key from `seed`, brings up the GPU engine and uploads the cloud key.  Returns a
- * short base64 token describing the key (params + seed), NULL if a key already exists
- * (eoc-tfhe-run.cpp:245-249) or on error. */
+ * secret + cloud key, brings up the GPU engine and uploads the cloud key.  seed = 0: secure mode (getrandom +
+ * ChaCha20); any other seed: the reproducible test mode (NOT secure).  Returns a short base64 token describing
+ * the key (params + seed), NULL if a key already exists (eoc-tfhe-run.cpp:245-249) or on error. */
 const char *generateGateKey(int minimum_lambda, uint64_t seed);
 void resetGateKey(void);
 /* bootsSymEncrypt / bootsSymDecrypt on base64(export_lweSample_toStream bytes):
@@ -296,8 +312,9 @@ void testJWT();
 /* ------------------------------------------------------------------------------------------------
  * f2: key export / import (the reference exports at eoc-tfhe-run.cpp:235-243 but has no import
  * path).  Versioned flat little-endian formats:
- *   secret key "EOCSK1": params | seed | lwe bits | tlwe bits  (the cloud key is regenerated from
- *                        the seed; import verifies the key bits)
+ *   secret key "EOCSK1": params | seed | lwe bits | tlwe bits  (reproducible keys; the cloud key is regenerated
+ *                        from the seed; import verifies the key bits)
+ *              "EOCSK2": params | 256-bit master key | lwe bits | tlwe bits  (secure keys, same idea)
  *   cloud key  "EOCCK1": params | bk int32[] | ksk int32[]      (what a server needs; no secrets)
  * ---------------------------------------------------------------------------------------------- */
 size_t eoc_secret_key_export(const eoc_secret_key *sk, void *buf, size_t cap); /* returns bytes needed */

@@ -126,3 +126,52 @@ def test_shard_partition():
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_chacha20_block_rfc8439_known_answer(built_lib):
+    """the block function behind the secure sampler (PRNG v2) against RFC 8439 section 2.3.2"""
+    key = np.arange(32, dtype=np.uint8)
+    nonce = np.frombuffer(bytes.fromhex("000000090000004a00000000"), np.uint8).copy()
+    out = np.zeros(64, np.uint8)
+    built_lib.eoc_dbg_chacha20_block(key.ctypes.data, 1, nonce.ctypes.data, out.ctypes.data)
+    assert bytes(out) == bytes.fromhex(
+        "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+        "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+
+
+def test_secure_mode_keys_and_encryption(built_lib):
+    """eoc_keygen_secure: keys from getrandom + ChaCha20 (two calls differ, a fixed master key reproduces), a valid
+    TGSW/LWE structure (bits decrypt), export/import through the EOCSK2 blob, keyed encryption decrypts and never
+    repeats a mask across indices"""
+    import eoc_tfhe_amd as eoc
+    import ctypes as C
+    p = eoc.default_params(0)
+    p.n = 48
+    a, b = eoc.SecretKey(p, None, with_cloud_key=False), eoc.SecretKey(p, None, with_cloud_key=False)
+    assert built_lib.eoc_sk_is_secure(a.h) == 1 and not np.array_equal(a.tlwe_key, b.tlwe_key)
+    assert 300 < a.tlwe_key.sum() < 724                      # about half of 1024 key bits set
+    m = bytes(range(7, 39))
+    k1, k2 = eoc.SecretKey(p, None, master=m), eoc.SecretKey(p, None, master=m)
+    assert np.array_equal(k1.bk, k2.bk) and np.array_equal(k1.ksk, k2.ksk)
+    det = eoc.SecretKey(p, 5)                                 # the reproducible mode is a different generator
+    assert built_lib.eoc_sk_is_secure(det.h) == 0 and not np.array_equal(det.tlwe_key, k1.tlwe_key)
+    # keyed encryption
+    bits = np.random.default_rng(1).integers(0, 2, 200).astype(np.uint8)
+    enc_key = np.frombuffer(os.urandom(32), np.uint8).copy()
+    cts = np.zeros((200, p.n + 1), np.int32)
+    assert built_lib.eoc_encrypt_bits_keyed(k1.h, enc_key.ctypes.data, 0, bits.ctypes.data, 200, cts.ctypes.data) == 0
+    assert np.array_equal(k1.decrypt_bits(cts), bits)
+    assert len({row[:-1].tobytes() for row in cts}) == 200    # no mask is ever repeated
+    # EOCSK2 round trip
+    need = built_lib.eoc_secret_key_export(k1.h, None, 0)
+    blob = np.zeros(need, np.uint8)
+    built_lib.eoc_secret_key_export(k1.h, blob.ctypes.data, need)
+    assert bytes(blob[:6]) == b"EOCSK2" and need == 8 + 36 + 32 + p.n + 1024
+    h = C.c_void_p()
+    assert built_lib.eoc_secret_key_import(blob.ctypes.data, need, 1, C.byref(h)) == 0
+    n_bk = built_lib.eoc_bk_len(C.byref(p))
+    got = np.ctypeslib.as_array(C.cast(built_lib.eoc_sk_bk(h), C.POINTER(C.c_int32)), (n_bk,))
+    assert np.array_equal(got, k1.bk.ravel())
+    built_lib.eoc_secret_key_free(h)
+    blob[50] ^= 1                                             # a damaged master key no longer matches the key bits
+    assert built_lib.eoc_secret_key_import(blob.ctypes.data, need, 0, C.byref(h)) != 0
