@@ -52,6 +52,11 @@ struct eoc_engine {
         size_t ws_jobs = 0;
         GateDesc *d_descs = nullptr, *h_descs = nullptr; // device ring + pinned host ring, same capacity
         size_t ws_descs = 0, desc_pos = 0;
+        // descriptors sent while the stream is being captured into a hipGraph live in blocks that are never re-used:
+        // the captured copy node reads its pinned source again at every replay
+        // (allocated with the ring -- nothing may be allocated while a stream captures -- four times its size)
+        GateDesc *d_persist = nullptr, *h_persist = nullptr;
+        size_t persist_cap = 0, persist_pos = 0;
         int32_t *d_mixed = nullptr; // gather/scatter space of mixed batches: 4 row arrays + perm
         uint32_t *h_perm = nullptr; // pinned
         hipEvent_t perm_ev = nullptr; // the last copy out of h_perm (awaited before h_perm is rewritten)
@@ -241,6 +246,8 @@ static void free_ws(eoc_engine::Workspace &W)
     if (W.h_descs) hipHostFree(W.h_descs);
     if (W.h_perm) hipHostFree(W.h_perm);
     if (W.perm_ev) hipEventDestroy(W.perm_ev);
+    hipFree(W.d_persist);
+    if (W.h_persist) hipHostFree(W.h_persist);
     W = eoc_engine::Workspace();
 }
 
@@ -294,6 +301,15 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         HIP_TRY(hipMalloc(&W.d_descs, cap * sizeof(GateDesc)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&W.h_descs), cap * sizeof(GateDesc), hipHostMallocDefault));
         W.ws_descs = cap;
+        if (W.persist_pos == 0) { // no captured graph refers to the arena yet: it may grow with the ring
+            hipFree(W.d_persist);
+            if (W.h_persist) hipHostFree(W.h_persist);
+            W.d_persist = W.h_persist = nullptr;
+            W.persist_cap = 0;
+            HIP_TRY(hipMalloc(&W.d_persist, 4 * cap * sizeof(GateDesc)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&W.h_persist), 4 * cap * sizeof(GateDesc), hipHostMallocDefault));
+            W.persist_cap = 4 * cap;
+        }
         e->ws_grows++;
     }
     if (mixed > W.ws_mixed) {
@@ -594,6 +610,20 @@ constexpr size_t kMaxGatesPerLaunch = 32768;
 // copy that reads it may still be in flight (sized by ensure_ws for everything a call sends, the wrap is rare).
 static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, GateDesc **d_out)
 {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+        if (W.persist_pos + count > W.persist_cap) {
+            eoc_set_error("graph capture: descriptor arena exhausted (%zu of %zu used, %zu wanted); "
+                          "eoc_engine_reserve a larger max_descs before capturing", W.persist_pos, W.persist_cap, count);
+            return EOC_ERR_STATE;
+        }
+        memcpy(W.h_persist + W.persist_pos, src, count * sizeof(GateDesc));
+        HIP_TRY(hipMemcpyAsync(W.d_persist + W.persist_pos, W.h_persist + W.persist_pos, count * sizeof(GateDesc),
+                               hipMemcpyHostToDevice, st));
+        *d_out = W.d_persist + W.persist_pos;
+        W.persist_pos += count;
+        return EOC_OK;
+    }
     if (count > W.ws_descs) {
         eoc_set_error("internal: descriptor ring too small (%zu > %zu)", count, W.ws_descs);
         return EOC_ERR_STATE;

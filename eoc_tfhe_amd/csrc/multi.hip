@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -83,16 +84,26 @@ void shard_range(size_t total, int rank, int world, size_t *lo, size_t *hi)
     *hi = l + base + ((size_t)rank < rem ? 1 : 0);
 }
 
-bool is_pinned(const void *p)
+// Registry of the pinned buffers handed out by eoc_host_alloc: base -> (size, device-side address).  The batch calls
+// look caller pointers up here instead of asking the runtime (hipPointerGetAttributes costs tens of microseconds per
+// call); anything not found is treated as pageable memory.
+struct PinnedBlock { size_t size; char *dev; };
+std::mutex g_pin_mu;
+std::map<uintptr_t, PinnedBlock> g_pinned;
+
+// device-side address of a caller pointer inside an eoc_host_alloc block, or nullptr
+void *mapped_address(const void *p)
 {
-    if (!p) return true;
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError(); // pageable memory is reported as an error: clear it
-        return false;
-    }
-    return a.type == hipMemoryTypeHost;
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    auto it = g_pinned.upper_bound(a);
+    if (it == g_pinned.begin()) return nullptr;
+    --it;
+    if (a >= it->first + it->second.size) return nullptr;
+    return it->second.dev + (a - it->first);
 }
+bool is_pinned(const void *p) { return !p || mapped_address(p) != nullptr; }
 
 int slot_reserve_rows(Slot &s, size_t rows, size_t stride_ints)
 {
@@ -132,20 +143,11 @@ int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, con
     bool all_pinned = true;
     for (int k = 0; k < 3; k++) {
         if (!h[k]) continue;
-        pin[k] = is_pinned(h[k]);
-        if (pin[k]) {
-            void *dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, const_cast<int32_t *>(h[k]), 0) == hipSuccess && dp) dmap[k] = static_cast<const int32_t *>(dp);
-            else (void)hipGetLastError();
-        }
+        dmap[k] = static_cast<const int32_t *>(mapped_address(h[k]));
+        pin[k] = dmap[k] != nullptr;
         all_pinned &= pin[k];
     }
-    int32_t *out_map = nullptr;
-    if (is_pinned(out)) {
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, out, 0) == hipSuccess && dp) out_map = static_cast<int32_t *>(dp);
-        else (void)hipGetLastError();
-    }
+    int32_t *out_map = static_cast<int32_t *>(mapped_address(out));
     all_pinned &= out_map != nullptr;
     // Batches wider than one resident set, from pinned buffers: chunks of 1024 gates (one single-round blind-rotate
     // launch each).  ALL kernels stay on one stream (kernels of different streams do not overlap on this device and
@@ -556,16 +558,27 @@ extern "C" int eoc_upload_cloud_key(const eoc_secret_key *sk)
 
 extern "C" void *eoc_host_alloc(size_t bytes)
 {
-    void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    void *p = nullptr, *dp = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
         eoc_set_error("eoc_host_alloc: hipHostMalloc(%zu) failed", bytes);
         return nullptr;
     }
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) {
+        (void)hipGetLastError();
+        dp = p; // unified addressing: the host address is valid on the device
+    }
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    g_pinned[reinterpret_cast<uintptr_t>(p)] = PinnedBlock{bytes ? bytes : 1, static_cast<char *>(dp)};
     return p;
 }
 extern "C" void eoc_host_free(void *p)
 {
-    if (p) hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        g_pinned.erase(reinterpret_cast<uintptr_t>(p));
+    }
+    hipHostFree(p);
 }
 
 extern "C" int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,

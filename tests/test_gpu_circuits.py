@@ -277,3 +277,61 @@ def test_min_max_4bit_bit_exact_and_optimised_select(eoc):
     for g in (g1, g2):
         v = sum(sk.decrypt_bits(g[w]).astype(np.int64) << i for i, w in enumerate(outs))
         assert np.array_equal(v, np.minimum(A, B))
+
+
+def test_reserved_engine_is_graph_capturable(eoc):
+    """launch-path hygiene: after eoc_engine_reserve a gate batch and a netlist are captured into a hipGraph (no
+    allocation, no synchronisation, descriptors from engine-owned pinned memory) and replayed on new operand values"""
+    torch = torch_cuda()
+    from eoc_tfhe_amd import circuits
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 21)
+    orc = ol.Oracle(0, 21, n_override=40)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    L = eoc.lib()
+    S = 48
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(3)
+    assert L.eoc_engine_reserve(eng.h, 4 * S, 256, 0) == 0
+    rng = np.random.default_rng(2)
+
+    def enc(bits, seed):
+        return to_dev(sk.encrypt_bits(bits.astype(np.uint8), seed, 0))
+
+    b0, b1 = rng.integers(0, 2, S), rng.integers(0, 2, S)
+    d0, d1 = enc(b0, 1), enc(b1, 2)
+    out = torch.empty_like(d0)
+    wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):   # warm-up outside the capture (first launches load code objects)
+        eng.gate_batch_device(eoc.OPS["XOR"], d0.data_ptr(), d1.data_ptr(), None, out.data_ptr(), S, stream=st.cuda_stream)
+        eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S, stream=st.cuda_stream)
+    st.synchronize()
+    grows = L.eoc_engine_workspace_grows(eng.h)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        eng.gate_batch_device(eoc.OPS["XOR"], d0.data_ptr(), d1.data_ptr(), None, out.data_ptr(), S, stream=st.cuda_stream)
+        eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S, stream=st.cuda_stream)
+    assert L.eoc_engine_workspace_grows(eng.h) == grows
+    for rnd in range(2):          # replay on fresh operand values written into the captured buffers
+        b0, b1 = rng.integers(0, 2, S), rng.integers(0, 2, S)
+        A, B = rng.integers(0, 8, S), rng.integers(0, 8, S)
+        d0.copy_(enc(b0, 10 + rnd))
+        d1.copy_(enc(b1, 20 + rnd))
+        for i in range(3):
+            wires[aw[0] + i].copy_(enc((A >> i) & 1, 100 + 10 * rnd + i))
+            wires[bw[0] + i].copy_(enc((B >> i) & 1, 200 + 10 * rnd + i))
+        # a few other calls in between re-use the engine's descriptor ring: the captured graph must not care
+        tmp = torch.empty_like(d0)
+        for _ in range(3):
+            eng.gate_batch_device(eoc.OPS["AND"], d0.data_ptr(), d1.data_ptr(), None, tmp.data_ptr(), S)
+        sync()
+        g.replay()
+        sync()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, orc.gate_batch(ol.OPS["XOR"], d0.cpu().numpy(), d1.cpu().numpy()))
+        tot = sum(sk.decrypt_bits(wires[sw[0] + i].cpu().numpy()).astype(np.int64) << i for i in range(4))
+        assert np.array_equal(tot, A + B)
+    eng.close()

@@ -7,7 +7,7 @@ TAG=${1:-final}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 mkdir -p "$O"
-python3 bench.py --pcie > "$O/bench_A.json" 2> "$O/bench_A.err"
+python3 bench.py > "$O/bench_A.json" 2> "$O/bench_A.err"
 echo "bench A done"
 python3 bench.py --pset B --no-cpu-baseline --no-secondary > "$O/bench_B.json" 2> "$O/bench_B.err"
 echo "bench B done"

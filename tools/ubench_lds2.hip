@@ -1,0 +1,91 @@
+// Micro-benchmark (diagnostic): CU-wide cost of the LDS store/load forms a transpose could use, 8 waves per CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double d2 __attribute__((ext_vector_type(2)));
+// MODE 0: 8 x ds_write_b128 + 8 x ds_read_b128   1: 16 x ds_write_b64 + 8 x ds_read_b128   2: 8 x w128 + 16 x ds_read_b64
+// 3: writes only (8 x b128)   4: reads only (8 x b128)   5: 16 x ds_write_b64 only   6: 8 x ds_write2_b64 only
+template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int iters)
+{
+    __shared__ d2 scr_all[2][568];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    d2 *scr = scr_all[w];
+    double *scd = reinterpret_cast<double *>(scr);
+    d2 x[8];
+    for (int r = 0; r < 8; r++) x[r] = d2{lane * 0.5 + r, r * 0.25};
+    for (int i = lane; i < 568; i += 64) scr[i] = d2{1.0 * i, 2.0};
+    __syncthreads();
+    for (int it = 0; it < iters; it++) {
+        if (MODE == 0 || MODE == 2 || MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) scr[72 * r + lane] = x[r];
+        }
+        if (MODE == 1 || MODE == 5) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                asm volatile("ds_write_b64 %0, %1" ::"v"((72 * r + lane) * 16 + (int)(w * 568 * 16)), "v"(x[r].x) : "memory");
+                asm volatile("ds_write_b64 %0, %1 offset:8" ::"v"((72 * r + lane) * 16 + (int)(w * 568 * 16)), "v"(x[r].y) : "memory");
+            }
+        }
+        if (MODE == 6) {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" ::"v"((72 * r + lane) * 16 + (int)(w * 568 * 16)), "v"(x[r].x), "v"(x[r].y) : "memory");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (MODE == 0 || MODE == 1 || MODE == 4) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) x[r] = scr[72 * (lane >> 3) + 8 * r + (lane & 7)];
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                double a, b;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(a) : "v"((72 * (lane >> 3) + 8 * r + (lane & 7)) * 16 + (int)(w * 568 * 16)) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(b) : "v"((72 * (lane >> 3) + 8 * r + (lane & 7)) * 16 + (int)(w * 568 * 16)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                x[r] = d2{a, b};
+            }
+        }
+        if (MODE == 3 || MODE == 5 || MODE == 6) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) x[r].x += 1.0; // keep the stores live and distinct
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    double s = 0;
+    for (int r = 0; r < 8; r++) s += x[r].x + x[r].y;
+    out[blockIdx.x * 128 + threadIdx.x] = s + scd[lane];
+}
+template <int MODE> void run(const char *name)
+{
+    const int blocks = 1024;
+    double *out;
+    hipMalloc(&out, (size_t)blocks * 128 * 8);
+    const int iters = 20000;
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(128), 0, 0, out, 100);
+    hipDeviceSynchronize();
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(128), 0, 0, out, iters);
+    hipEventRecord(b);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("%-40s %.4f us per round (8 waves per CU)\n", name, ms * 1e3 / iters);
+    hipFree(out);
+}
+int main()
+{
+    run<0>("8 w128 + 8 r128");
+    run<1>("16 w64 + 8 r128");
+    run<2>("8 w128 + 16 r64");
+    run<3>("8 w128 only");
+    run<4>("8 r128 only");
+    run<5>("16 w64 only");
+    run<6>("8 write2_b64 only");
+    return 0;
+}
