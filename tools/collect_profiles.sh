@@ -16,6 +16,10 @@ echo "trace done"
 cp "$O"/trace/*/*kernel_stats.csv "$O/kernel_stats.csv"
 bash tools/pmc_passes.sh "$O/pmc" > "$O/pmc_passes.log" 2>&1
 cp "$O/pmc/summary.txt" "$O/pmc_summary.txt"
-echo "pmc done"
+echo "pmc A done"
+bash tools/pmc_passes.sh "$O/pmcB" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --pset B > "$O/pmcB_passes.log" 2>&1
+cp "$O/pmcB/summary.txt" "$O/pmc_summary_B.txt"
+echo "pmc B done"
+python3 tools/traffic_json.py "$O/pmc_summary.txt" "$O/pmc_summary_B.txt" > "$O/traffic.json"
 head -5 "$O/kernel_stats.csv"
 cat "$O/bench_A.json"

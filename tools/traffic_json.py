@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC summaries: measured fabric/HBM bytes per k_blind_rotate launch
+= (2 x FETCH_SIZE + WRITE_SIZE) x 1024  (rocprofv3 reports KiB-units of 1024 B; FETCH_SIZE is doubled on gfx950 for
+16-B-per-lane coalesced reads, MI355X_MICROARCH.md section HBM).  Usage: traffic_json.py summary_A.txt [summary_B.txt]"""
+import json
+import re
+import sys
+
+
+def parse(path, kernel):
+    vals, cur = {}, None
+    for line in open(path):
+        m = re.match(r"== (.*)", line)
+        if m:
+            cur = m.group(1).strip()
+            continue
+        m = re.match(r"\s+(\w+)\s+n=\s*\d+\s+mean=([0-9.e+]+)", line)
+        if m and cur and cur.startswith(kernel):
+            vals[m.group(1)] = float(m.group(2))
+    return vals
+
+
+out = {"unit": "bytes per k_blind_rotate launch (1024 jobs)",
+       "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)"}
+for path, name, kern in zip(sys.argv[1:], ("A", "B"), ("eoc::k_blind_rotate<2, 10>", "eoc::k_blind_rotate<3, 7>")):
+    v = parse(path, kern)
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        out[f"blind_rotate_{name}_1024"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+        out[f"detail_{name}"] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
+                                 "TCC_HIT": v.get("TCC_HIT_sum"), "TCC_MISS": v.get("TCC_MISS_sum")}
+print(json.dumps(out, indent=1))
