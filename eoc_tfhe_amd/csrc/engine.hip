@@ -67,6 +67,7 @@ struct eoc_engine {
     int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
     int prio_multi = -1;                    // duty code of launches of several rounds (EOC_TFHE_PRIO_MULTI)
     int br_slice = 0;                       // jobs per blind-rotate launch: 0 = resident set, < 0 = unlimited (EOC_TFHE_BR_SLICE)
+    bool no_fold = false;                   // EOC_TFHE_NO_FOLD: keep k_ks_init as its own launch
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
     uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
@@ -222,6 +223,7 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (const char *s = getenv("EOC_TFHE_PRIO_DUTY")) e->prio_duty_override = atoi(s);
         if (const char *s = getenv("EOC_TFHE_PRIO_MULTI")) e->prio_multi = atoi(s);
         if (const char *s = getenv("EOC_TFHE_BR_SLICE")) e->br_slice = atoi(s);
+        if (getenv("EOC_TFHE_NO_FOLD")) e->no_fold = true;
     }
     // key-switch kernels use > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
 #define EOC_KS_ATTR(BB, TT, NWV, JBV, CWV)                                                                       \
@@ -511,7 +513,8 @@ typedef eoc_engine::Workspace WS;
 // which every workgroup is resident from the start runs with the wave-priority alternation and finishes all its
 // workgroups within half a per cent of each other (3.0 ms per 1024 jobs), while a launch of several rounds settles at
 // a 10 % lower rate (the arbiter's age bias), so wide levels are cut into back-to-back single-round launches.
-static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipStream_t st)
+static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipStream_t st,
+                               const GateDesc *fold_descs = nullptr, uint32_t fold_S = 0)
 {
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
     const uint32_t resident = 4u * (uint32_t)e->num_cus;
@@ -532,6 +535,12 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
         a.bara_stride = e->bara_stride;
         a.mu = (int32_t)(1u << 29);
         a.stamps = e->d_stamps;
+        a.ks_descs = fold_descs;
+        a.ubarT = W.d_ubarT;
+        a.ks_jstride = (uint32_t)W.ws_jobs + KS_GT;
+        a.ks_S = fold_S ? fold_S : 1;
+        a.ks_prec_offset = 1u << (32 - (1 + e->p.ks_basebit * e->p.ks_t));
+        a.job0 = off;
         // priority alternation pays only when every workgroup is resident from the start (four per CU)
         a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
                       : (njobs <= resident ? EOC_PRIO_DUTY : e->prio_multi);
@@ -553,7 +562,8 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
     return EOC_OK;
 }
 
-static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint32_t ngates, uint32_t S, hipStream_t st)
+static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint32_t ngates, uint32_t S, hipStream_t st,
+                            bool init_done = false)
 {
     KSArgs a;
     a.ksk = e->ksk;
@@ -567,8 +577,10 @@ static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint3
     a.jstride = (uint32_t)W.ws_jobs + KS_GT;
     a.mu = (int32_t)(1u << 29);
     SpanGuard span(e, st, KIND_KEYSWITCH);
-    hipLaunchKernelGGL(k_ks_init, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
-    HIP_TRY(hipGetLastError());
+    if (!init_done) { // levels with MUX (two extracted samples are summed) and the stand-alone key switch
+        hipLaunchKernelGGL(k_ks_init, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
+        HIP_TRY(hipGetLastError());
+    }
     const uint32_t ntiles = (S + KS_GT - 1) / KS_GT;
     const int nw = (int)(e->n1p / KS_CW);
     dim3 grid(ntiles * (kN / KS_IT), ngates);
@@ -684,9 +696,12 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
             hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, W.d_bara, e->bara_stride);
             HIP_TRY(hipGetLastError());
         }
-        rc = launch_blind_rotate(e, W, jobs, st);
+        // without MUX every gate has S jobs (job = gate * S + instance) and the blind rotate's epilogue sets the key
+        // switch up itself (k_ks_init folded away); EOC_TFHE_NO_FOLD=1 keeps the separate launch (diagnostics)
+        const bool fold = !any_mux && !e->no_fold;
+        rc = launch_blind_rotate(e, W, jobs, st, fold ? dd : nullptr, (uint32_t)S);
         if (rc) return rc;
-        rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st);
+        rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st, fold);
         if (rc) return rc;
         e->stats[0] += 1;
         e->stats[1] += jobs;

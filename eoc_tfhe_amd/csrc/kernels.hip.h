@@ -649,6 +649,11 @@ struct BRArgs {
     int32_t mu;
     unsigned long long *stamps; // diagnostic build only: [waves][16] cycle sums per segment
     int prio_duty;              // < 0: leave wave priorities alone; else see the loop (single-round launches)
+    // folded key-switch set-up (levels without MUX): the epilogue writes the key-switch operand and the output row
+    // itself, k_ks_init is not launched and the extracted sample never goes to memory
+    const GateDesc *ks_descs;   // non-null = fold; gate of job j is j / ks_S (jobs are [gate][instance])
+    uint32_t *ubarT;            // [N][ks_jstride]
+    uint32_t ks_jstride, ks_S, ks_prec_offset, job0; // job0: first job of this launch within the level
 };
 
 // LDS: the two tables + one 9 KB scratch per wave.  Between two steps the scratch holds the accumulator polynomial of
@@ -893,7 +898,21 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #endif
 
     // tLweExtractLweSample, index 0: u_0 = ACC_0[0], u_j = -ACC_0[N - j] = ext[2N - j]; b = ACC_1[0]
-    {
+    if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit) (transposed), out = (0, ..., 0, b)
+        const uint32_t gjob = A.job0 + job;
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int j = lane + 64 * r;
+                A.ubarT[(size_t)j * A.ks_jstride + gjob] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
+            }
+        } else {
+            const uint32_t g = gjob / A.ks_S, si = gjob - g * A.ks_S;
+            int32_t *o = A.ks_descs[g].out + (size_t)si * (A.n + 1);
+            for (int m = lane; m < A.n; m += 64) o[m] = 0;
+            if (lane == 0) o[A.n] = ext[0];
+        }
+    } else {
         int32_t *u = A.u + (size_t)job * (kN + 1);
         if (h == 0) {
 #pragma unroll

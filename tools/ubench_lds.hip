@@ -6,7 +6,7 @@
 #include <cstdio>
 typedef double d2 __attribute__((ext_vector_type(2)));
 #define NF 72
-template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int iters)
+template <int MODE> __global__ __launch_bounds__(128, 4) void k(double *out, int iters)
 {
     __shared__ d2 scr_all[2][568];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -59,7 +59,7 @@ template <int MODE> void run(const char *name, int blocks)
 }
 int main()
 {
-    for (int blocks : {256, 512, 1024}) {
+    for (int blocks : {1024, 1536, 2048}) {
         run<0>("transpose only (8 w128 + 8 r128)", blocks);
         run<1>("72 fma_f64 only", blocks);
         run<2>("transpose then fma (pinned)", blocks);
