@@ -49,6 +49,7 @@ struct eoc_engine {
         uint16_t *d_bara = nullptr;
         int32_t *d_u = nullptr;
         uint32_t *d_ubarT = nullptr; // [N][ws_jobs + 64] key-switch operand, transposed
+        int32_t *d_acc_state = nullptr; // [resident jobs][2][N]: accumulators between the parts of a cut blind rotation
         size_t ws_jobs = 0;
         GateDesc *d_descs = nullptr, *h_descs = nullptr; // device ring + pinned host ring, same capacity
         size_t ws_descs = 0, desc_pos = 0;
@@ -68,6 +69,7 @@ struct eoc_engine {
     int prio_multi = -1;                    // duty code of launches of several rounds (EOC_TFHE_PRIO_MULTI)
     int br_slice = 0;                       // jobs per blind-rotate launch: 0 = resident set, < 0 = unlimited (EOC_TFHE_BR_SLICE)
     bool no_fold = false;                   // EOC_TFHE_NO_FOLD: keep k_ks_init as its own launch
+    int br_parts = 0;                       // consecutive launches per blind rotation (EOC_TFHE_BR_PARTS); 0 = by key-row size
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
     uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
@@ -224,6 +226,7 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (const char *s = getenv("EOC_TFHE_PRIO_MULTI")) e->prio_multi = atoi(s);
         if (const char *s = getenv("EOC_TFHE_BR_SLICE")) e->br_slice = atoi(s);
         if (getenv("EOC_TFHE_NO_FOLD")) e->no_fold = true;
+        if (const char *s = getenv("EOC_TFHE_BR_PARTS")) e->br_parts = atoi(s);
     }
     // key-switch kernels use > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
 #define EOC_KS_ATTR(BB, TT, NWV, JBV, CWV)                                                                       \
@@ -243,6 +246,7 @@ static void free_ws(eoc_engine::Workspace &W)
     hipFree(W.d_bara);
     hipFree(W.d_u);
     hipFree(W.d_ubarT);
+    hipFree(W.d_acc_state);
     hipFree(W.d_descs);
     hipFree(W.d_mixed);
     if (W.h_descs) hipHostFree(W.h_descs);
@@ -289,6 +293,7 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         HIP_TRY(hipMalloc(&W.d_u, cap * (kN + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&W.d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
         HIP_TRY(hipMemset(W.d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        if (!W.d_acc_state) HIP_TRY(hipMalloc(&W.d_acc_state, (size_t)4 * e->num_cus * 2 * kN * sizeof(int32_t) * 4));
         W.ws_jobs = cap;
         e->ws_grows++;
     }
@@ -523,41 +528,54 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
         const uint32_t nsl = (njobs_total + slice - 1) / slice;
         slice = (njobs_total + nsl - 1) / nsl;
     }
+    // The n steps of a blind rotation may run as several consecutive launches (the accumulators travel through
+    // d_acc_state): every launch boundary brings all workgroups of an XCD back to the same step.  With 96 KB of key
+    // rows per step and ciphertext (gadget length 3) the 128 resident ciphertexts of an XCD drift far enough apart for
+    // their rows to overflow the 4 MB L2 share (rows re-fetched 3.6x, profiles/traffic.json): two parts -2.5 % on
+    // Set B; with 64 KB per step (Set A) the rows fit and every extra part costs 0.8 %.
+    const int auto_parts = e->kpl * 2 * kNH * 16 > 80 * 1024 ? 2 : 1;
+    const int parts = std::max(1, std::min(e->br_parts > 0 ? e->br_parts : auto_parts, e->p.n));
+    if (parts > 1 && slice > 16u * (uint32_t)e->num_cus) slice = 16u * (uint32_t)e->num_cus; // acc_state capacity
     for (uint32_t off = 0; off < njobs_total; off += slice) {
         const uint32_t njobs = std::min(slice, njobs_total - off);
-        BRArgs a;
-        a.bkfft = e->bkfft;
-        a.bara = W.d_bara + (size_t)off * e->bara_stride;
-        a.u = W.d_u + (size_t)off * (kN + 1);
-        a.njobs = njobs;
-        a.n = e->p.n;
-        a.Bgbit = e->p.Bgbit;
-        a.bara_stride = e->bara_stride;
-        a.mu = (int32_t)(1u << 29);
-        a.stamps = e->d_stamps;
-        a.ks_descs = fold_descs;
-        a.ubarT = W.d_ubarT;
-        a.ks_jstride = (uint32_t)W.ws_jobs + KS_GT;
-        a.ks_S = fold_S ? fold_S : 1;
-        a.ks_prec_offset = 1u << (32 - (1 + e->p.ks_basebit * e->p.ks_t));
-        a.job0 = off;
-        // priority alternation pays only when every workgroup is resident from the start (four per CU)
-        a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
-                      : (njobs <= resident ? EOC_PRIO_DUTY : e->prio_multi);
-        dim3 grid(njobs), block(128);
-        if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
-            hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
-        else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
-            hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
-        else
-            switch (e->p.l) {
-            case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-            case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-            case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-            case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-            default: return EOC_ERR_ARG;
-            }
-        HIP_TRY(hipGetLastError());
+        for (int part = 0; part < parts; part++) {
+            BRArgs a;
+            a.bkfft = e->bkfft;
+            a.bara = W.d_bara + (size_t)off * e->bara_stride;
+            a.u = W.d_u + (size_t)off * (kN + 1);
+            a.njobs = njobs;
+            a.n = e->p.n;
+            a.Bgbit = e->p.Bgbit;
+            a.bara_stride = e->bara_stride;
+            a.mu = (int32_t)(1u << 29);
+            a.stamps = e->d_stamps;
+            a.ks_descs = fold_descs;
+            a.ubarT = W.d_ubarT;
+            a.ks_jstride = (uint32_t)W.ws_jobs + KS_GT;
+            a.ks_S = fold_S ? fold_S : 1;
+            a.ks_prec_offset = 1u << (32 - (1 + e->p.ks_basebit * e->p.ks_t));
+            a.job0 = off;
+            a.step_begin = (int)((long long)e->p.n * part / parts);
+            a.step_end = (int)((long long)e->p.n * (part + 1) / parts);
+            a.acc_state = W.d_acc_state;
+            // priority alternation pays only when every workgroup is resident from the start (four per CU)
+            a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
+                          : (njobs <= resident ? EOC_PRIO_DUTY : e->prio_multi);
+            dim3 grid(njobs), block(128);
+            if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
+                hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+            else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
+                hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+            else
+                switch (e->p.l) {
+                case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+                case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+                case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+                case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+                default: return EOC_ERR_ARG;
+                }
+            HIP_TRY(hipGetLastError());
+        }
     }
     return EOC_OK;
 }

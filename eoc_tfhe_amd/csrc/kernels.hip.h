@@ -654,6 +654,10 @@ struct BRArgs {
     const GateDesc *ks_descs;   // non-null = fold; gate of job j is j / ks_S (jobs are [gate][instance])
     uint32_t *ubarT;            // [N][ks_jstride]
     uint32_t ks_jstride, ks_S, ks_prec_offset, job0; // job0: first job of this launch within the level
+    // step range of this launch: the n steps of a blind rotation may be cut into consecutive launches; every boundary
+    // brings all workgroups of the chip back to the same step (the accumulator travels through `acc_state`)
+    int step_begin, step_end;
+    int32_t *acc_state;         // [jobs][2][N], only used when the range is a proper part of [0, n)
 };
 
 // LDS: the two tables + one 9 KB scratch per wave.  Between two steps the scratch holds the accumulator polynomial of
@@ -688,12 +692,14 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     {
         const int barb = bara[A.n];
         const int rot = (2 * kN - barb) & (2 * kN - 1);
+        const int32_t *st = A.acc_state + ((size_t)job * 2 + h) * kN;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int j = lane + 64 * (r & 7) + (r >> 3) * kNH;
             int idx = (j - rot) & (2 * kN - 1);
             int32_t v = (idx & kN) ? -A.mu : A.mu;
             v = h ? v : 0;
+            if (A.step_begin > 0) v = st[j]; // continue a blind rotation started by an earlier launch
             racc[r] = (uint32_t)v;
             ext[j] = v;
             ext[j + kN] = -v;
@@ -722,8 +728,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 #endif
-    int abar_next = (int)bara[0];
-    for (int i = 0; i < A.n; i++) {
+    int abar_next = (int)bara[A.step_begin];
+    for (int i = A.step_begin; i < A.step_end; i++) {
         EOC_STAMP(15);
 #if EOC_PRIO_ALT
         // The two waves that share a SIMD belong to different workgroups, and the issue arbiter favours the older
@@ -897,6 +903,12 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * 2 + h) * 16 + k] = st_acc[k];
 #endif
 
+    if (A.step_end < A.n) { // not the last part: park the accumulator for the next launch
+        int32_t *st = A.acc_state + ((size_t)job * 2 + h) * kN;
+#pragma unroll
+        for (int r = 0; r < 16; r++) st[lane + 64 * (r & 7) + (r >> 3) * kNH] = (int32_t)racc[r];
+        return;
+    }
     // tLweExtractLweSample, index 0: u_0 = ACC_0[0], u_j = -ACC_0[N - j] = ext[2N - j]; b = ACC_1[0]
     if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit) (transposed), out = (0, ..., 0, b)
         const uint32_t gjob = A.job0 + job;
