@@ -255,8 +255,8 @@ __device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, 
 #define EOC_M_VALU 0x002
 #define EOC_M_DSR 0x100
 #define EOC_M_DSW 0x200
-template <class MakeB, class PreLast>
-__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, PreLast pre_last, const d2 *tw, d2 *scr, int lane)
+template <class MakeB>
+__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, const d2 *tw, d2 *scr, int lane)
 {
     d2 t1[4], t2[4];
     EOC_SB();
@@ -321,7 +321,6 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     EOC_SGB(EOC_M_VALU, 40);
 #endif
     EOC_SB();
-    pre_last(); // e.g. key-row requests that should be in flight under the last register pass
     fwd_pass12(xb, t2);
 }
 
@@ -595,14 +594,6 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 #ifndef EOC_PRIO_ALT
 #define EOC_PRIO_ALT 1
 #endif
-//   EOC_OWN_EARLY  (l = 2) the first own key row is requested before the last forward register pass (third row buffer)
-//   EOC_OWN_LATE   only one own key row is requested before the exchange (fewer live registers)
-#ifndef EOC_OWN_EARLY
-#define EOC_OWN_EARLY 0
-#endif
-#ifndef EOC_OWN_LATE
-#define EOC_OWN_LATE 0
-#endif
 #ifndef EOC_PRIO_DUTY
 #define EOC_PRIO_DUTY 11
 #endif
@@ -611,8 +602,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 #endif
 //   the step's rotation amount (bara[i]) is loaded one step ahead, so no load is waited for at the step top: -1 % (kept)
 //   measured and rejected in round 1: staggering the workgroups of a CU, feedback priorities, touching the next step's
-//   key rows early, sched_barriers that pin the skew order, a one-wave-per-ciphertext form (k_blind_rotate_t, removed
-//   in round 2: slower at every size).
+//   key rows early, a one-wave-per-ciphertext form (k_blind_rotate_t, removed in round 2: slower at every size).
+//   measured and rejected in round 2: both waves of a pair on one priority phase (+1 %), a phase taken from the shader
+//   clock for launches of several rounds (+-0), a 168-register three-waves-per-SIMD form for launches wider than the
+//   resident set (two ciphertexts per 256-thread workgroup, transforms one at a time, one key-row buffer: 40 spills,
+//   270 k against 320 k gates/s for the single-round slices of the two-wave form).
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -815,9 +809,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // forward transforms of the l digits (two at a time, skewed on the one scratch; an odd last one alone) and
         // the chain for the partner's output polynomial.  The spectra stay in registers for the own chain below.
         d2 xs[L][8], ra[8], rb[8], S[8];
-#if EOC_OWN_EARLY
-        d2 rc[8];
-#endif
 #pragma unroll
         for (int p0 = 0; p0 + 1 < L; p0 += 2) {
             load_row(p0 + 1, 1 - h, ra);
@@ -825,11 +816,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             make_x0(p0 + 1, xs[p0]);
             EOC_STAMP(1);
             fft_fwd_rest_x2(xs[p0], xs[p0 + 1], [&]() __attribute__((always_inline)) { make_x0(p0 + 2, xs[p0 + 1]); },
-                            [&]() __attribute__((always_inline)) {
-#if EOC_OWN_EARLY
-                                if (L == 2) load_row(1, h, rc); // first own row under the last register pass
-#endif
-                            },
                             s_tw, scr, lane);
             EOC_STAMP(2);
             mac(p0 == 0, xs[p0], ra, S);
@@ -845,17 +831,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             mac(L == 1, xs[L - 1], ra, S);
             EOC_STAMP(3);
         }
-        // own rows: the first two are requested before the exchange
-#if EOC_OWN_EARLY
-        if constexpr (L != 2) load_row(1, h, ra);
-        if constexpr (L == 2) load_row(2, h, rb);
-        else if constexpr (L >= 2) load_row(2, h, rb);
-#elif EOC_OWN_LATE
-        load_row(1, h, ra); // register-lean form: the second own row is requested after the exchange
-#else
+        // own rows: the first two are requested before the exchange (requesting the first one a register pass
+        // earlier into a third buffer, or the second one only after the exchange, changes nothing: measured)
         load_row(1, h, ra);
         if constexpr (L >= 2) load_row(2, h, rb);
-#endif
 #pragma unroll
         for (int r = 0; r < 8; r++) scr[r * 64 + lane] = S[r];
         EOC_STAMP(4);
@@ -863,15 +842,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 8; r++) S[r] = scr_partner[r * 64 + lane]; // the chain of the other input polynomial
-#if EOC_OWN_EARLY
-        if constexpr (L == 2) mac(false, xs[0], rc, S);
-        else mac(false, xs[0], ra, S);
-#else
-#if EOC_OWN_LATE
-        if constexpr (L >= 2) load_row(2, h, rb);
-#endif
         mac(false, xs[0], ra, S);
-#endif
         if constexpr (L >= 3) load_row(3, h, ra);
         if constexpr (L >= 2) mac(false, xs[1], rb, S);
         if constexpr (L >= 4) load_row(4, h, rb);
