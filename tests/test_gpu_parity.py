@@ -390,3 +390,22 @@ def test_deep_chain_bit_exact_set_a(eoc, rig_a):
         bits = {"NAND": 1 - (x & y), "XOR": x ^ y, "ORNY": (1 - x) | y, "XNOR": 1 - (x ^ y), "AND": x & y,
                 "NOR": 1 - (x | y)}[op]
         assert np.array_equal(r.sk.decrypt_bits(cur), bits), f"wrong plaintext at level {lv}"
+
+
+@pytest.mark.parametrize("env", [{"EOC_TFHE_BR_PARTS": "3"}, {"EOC_TFHE_BR_PARTS": "1", "EOC_TFHE_BR_SLICE": "5"},
+                                 {"EOC_TFHE_NO_FOLD": "1"}, {"EOC_TFHE_PRIO_DUTY": "-1", "EOC_TFHE_BR_SLICE": "-1"}])
+def test_launch_shapes_do_not_change_results(eoc, monkeypatch, env):
+    """the launch-shape knobs of the engine -- a blind rotation cut into consecutive launches (accumulators parked in
+    between), job slices, the separate k_ks_init launch, wave priorities off -- give the oracle's bits, all of them"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for pset in (0, 1):
+        r = Rig(eoc, pset, 11, n_override=33)
+        b0, c0 = _rand_cts(r, 13, 61, 0)
+        b1, c1 = _rand_cts(r, 13, 62, 0)
+        b2, c2 = _rand_cts(r, 13, 63, 0)
+        assert np.array_equal(r.gate(eoc.OPS["NAND"], c0, c1), r.orc.gate_batch(ol.OPS["NAND"], c0, c1))
+        assert np.array_equal(r.gate(eoc.OPS["MUX"], c0, c1, c2), r.orc.gate_batch(ol.OPS["MUX"], c0, c1, c2))
+        ops = np.array([0, 4, 10, 11, 10, 0, 2, 13, 4, 12, 10, 14, 0], np.uint8)
+        assert np.array_equal(r.gate(0, c0, c1, c2, ops=ops), r.orc.gate_batch(0, c0, c1, c2, ops=ops))
+        r.eng.close()
