@@ -133,6 +133,7 @@ def lib():
         "eoc_gpu_init": (C.c_int, [C.c_int, PP]),
         "eoc_gpu_init_multi": (C.c_int, [vp, C.c_int, PP]),
         "eoc_gpu_init_from_env": (C.c_int, [PP]),
+        "eoc_gpu_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
         "eoc_gpu_engine_count": (C.c_int, []),
         "eoc_global_engine_at": (vp, [C.c_int]),
         "eoc_upload_cloud_key_arrays": (C.c_int, [vp, vp]),

@@ -419,12 +419,34 @@ extern "C" int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_p
 }
 extern "C" int eoc_gpu_init(int device, const eoc_params *p) { return eoc_gpu_init_multi(&device, 1, p); }
 
-// EOC_TFHE_DEVICES = "all" | "0,1,2,..." | unset (device 0): what a Lua / Node host sets to put several GPUs behind
-// the reference-style global key without any change to its calls
+// The device list the string API brings up on its first key: eoc_gpu_set_devices (what a Lua / Node host calls) wins,
+// then EOC_TFHE_DEVICES = "all" | "0,1,2,..." (no change to the host's calls at all), then device 0.
+static std::mutex g_pref_mu;
+static std::vector<int> g_pref_devices;
+extern "C" int eoc_gpu_set_devices(const int *devices, int n_devices)
+{
+    if (n_devices < 0 || n_devices > 64 || (n_devices && !devices)) {
+        eoc_set_error("eoc_gpu_set_devices: bad arguments");
+        return EOC_ERR_ARG;
+    }
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0) {
+            eoc_set_error("eoc_gpu_set_devices: negative device index");
+            return EOC_ERR_ARG;
+        }
+    std::lock_guard<std::mutex> g(g_pref_mu);
+    g_pref_devices.assign(devices, devices + n_devices);
+    return EOC_OK;
+}
 extern "C" int eoc_gpu_init_from_env(const eoc_params *p)
 {
     const char *s = getenv("EOC_TFHE_DEVICES");
     std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> g(g_pref_mu);
+        devs = g_pref_devices;
+    }
+    if (!devs.empty()) return eoc_gpu_init_multi(devs.data(), (int)devs.size(), p);
     if (!s || !*s) devs.push_back(0);
     else if (!strcmp(s, "all")) {
         int c = eoc_device_count();

@@ -229,8 +229,10 @@ int eoc_engine_stats(eoc_engine *e, uint64_t out[3]);
  *   eoc_gpu_init_multi   one engine per listed device (a device may be listed more than once: several engines then
  *                        share it, which is how a one-GPU box rehearses the N-GPU path)
  *   eoc_gpu_init         = eoc_gpu_init_multi(&device, 1, p)
- *   eoc_gpu_init_from_env  devices from EOC_TFHE_DEVICES = "all" | "0,1,2,..." (unset: device 0); what the string API
- *                        uses on first gate call, so a Lua / Node host scales without changing its calls
+ *   eoc_gpu_init_from_env  devices from eoc_gpu_set_devices if that was called, else EOC_TFHE_DEVICES = "all" |
+ *                        "0,1,2,..." (unset: device 0); what the string API uses when a gate key arrives, so a Lua /
+ *                        Node host scales without changing its calls
+ *   eoc_gpu_set_devices  remembers a device list for that bring-up (n_devices 0 forgets it); no GPU is touched
  *   eoc_upload_cloud_key the two key images are built once on the first device and replicated: ncclBroadcast over
  *                        xGMI (librccl, loaded on demand) when the devices are distinct, device-to-device / peer copies
  *                        otherwise (EOC_TFHE_KEY_BCAST = rccl | copy forces one).  Keys are replicated, never sharded.
@@ -243,6 +245,7 @@ int eoc_engine_stats(eoc_engine *e, uint64_t out[3]);
 int eoc_gpu_init(int device, const eoc_params *p);
 int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_params *p);
 int eoc_gpu_init_from_env(const eoc_params *p);
+int eoc_gpu_set_devices(const int *devices, int n_devices);
 int eoc_gpu_engine_count(void);
 int eoc_upload_cloud_key(const eoc_secret_key *sk);    /* push sk's BK/KSK to every engine of the global context */
 int eoc_upload_cloud_key_arrays(const int32_t *bk, const int32_t *ksk); /* same from raw torus-form arrays */

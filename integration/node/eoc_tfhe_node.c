@@ -313,6 +313,15 @@ static napi_value n_circuitBootstraps(napi_env env, napi_callback_info info)
     return ret_int(env, (int)eoc_circuit_bootstraps((const eoc_gate *)g, glen / 5));
 }
 static napi_value n_engineCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_gpu_engine_count()); }
+static napi_value n_setDevices(napi_env env, napi_callback_info info)
+{ /* (Int32Array devices) -> 0 or a negative code: the devices the next generateGateKey / importPublicKey brings up, one
+   * engine each (a device may repeat; an empty array returns to EOC_TFHE_DEVICES / device 0) */
+    ARGS(1);
+    int32_t *d;
+    size_t n;
+    if (!get_i32_array(env, argv[0], &d, &n)) return ret_int(env, EOC_ERR_ARG);
+    return ret_int(env, eoc_gpu_set_devices((const int *)d, (int)n));
+}
 static napi_value n_deviceCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_device_count()); }
 
 static napi_value init(napi_env env, napi_value exports)
@@ -330,6 +339,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"sampleInts", n_sampleInts}, {"encryptBits", n_encryptBits}, {"decryptBits", n_decryptBits},
         {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount}, {"circuitRun", n_circuitRun},
         {"netlistOptimize", n_netlistOptimize}, {"circuitBootstraps", n_circuitBootstraps}, {"engineCount", n_engineCount},
+        {"setDevices", n_setDevices},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++) {
         napi_value fn;

@@ -3,7 +3,10 @@
 const assert = require('assert');
 const tfhe = require('./tfhe.js');
 assert.ok(tfhe.backend.deviceCount() >= 1, 'needs a GPU');
+// two engines behind the one global key (both on device 0 here: the one-GPU rehearsal of a multi-GPU host)
+assert.strictEqual(tfhe.backend.setDevices(Int32Array.from([0, 0])), 0);
 assert.ok(tfhe.generateGateKey(80, 3));
+assert.strictEqual(tfhe.backend.engineCount(), 2);
 const e = [tfhe.encryptBit(0, ''), tfhe.encryptBit(1, '')];
 for (const x of [0, 1]) for (const y of [0, 1]) {
   assert.strictEqual(tfhe.decryptBit(tfhe.nand(e[x], e[y], ''), ''), 1 - (x & y));
@@ -63,5 +66,6 @@ assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptString
   assert.strictEqual(B.gateBatch(0, one, one.slice(0, w), null), null);
   assert.strictEqual(B.decryptBits(B.gateBatch(14, null, null, null, null, 3)).join(''), '111');   // bootsCONSTANT
 }
+assert.strictEqual(tfhe.backend.engineCount(), 2);
 tfhe.backend.resetGateKey();
 console.log('node gpu tests OK');

@@ -4,6 +4,9 @@
 typedef double d2 __attribute__((ext_vector_type(2)));
 // MODE 0: 8 x ds_write_b128 + 8 x ds_read_b128   1: 16 x ds_write_b64 + 8 x ds_read_b128   2: 8 x w128 + 16 x ds_read_b64
 // 3: writes only (8 x b128)   4: reads only (8 x b128)   5: 16 x ds_write_b64 only   6: 8 x ds_write2_b64 only
+// Planar forms (real parts in one plane, imaginary parts 4608 bytes above, lanes 8 bytes apart):
+// 7: 16 x ds_write_b64   8: 8 x ds_write2st64_b64   9: 8 x ds_read2st64_b64   10: 16 x ds_read_b64
+// 11: 32 x ds_write_b32 over four planes   12: 8 x write2st64_b64 + 8 x read2st64_b64 (a whole planar transpose)
 template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int iters)
 {
     __shared__ d2 scr_all[2][568];
@@ -31,9 +34,50 @@ template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int
             for (int r = 0; r < 8; r++)
                 asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:1" ::"v"((72 * r + lane) * 16 + (int)(w * 568 * 16)), "v"(x[r].x), "v"(x[r].y) : "memory");
         }
+        if (MODE == 7) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                asm volatile("ds_write_b64 %0, %1" ::"v"((72 * r + lane) * 8 + (int)(w * 568 * 16)), "v"(x[r].x) : "memory");
+                asm volatile("ds_write_b64 %0, %1 offset:4608" ::"v"((72 * r + lane) * 8 + (int)(w * 568 * 16)), "v"(x[r].y) : "memory");
+            }
+        }
+        if (MODE == 8 || MODE == 12) {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:0 offset1:9" ::"v"((72 * r + lane) * 8 + (int)(w * 568 * 16)), "v"(x[r].x), "v"(x[r].y) : "memory");
+        }
+        if (MODE == 11) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int a = (72 * r + lane) * 4 + (int)(w * 568 * 16);
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(__double2loint(x[r].x)) : "memory");
+                asm volatile("ds_write_b32 %0, %1 offset:2304" ::"v"(a), "v"(__double2hiint(x[r].x)) : "memory");
+                asm volatile("ds_write_b32 %0, %1 offset:4608" ::"v"(a), "v"(__double2loint(x[r].y)) : "memory");
+                asm volatile("ds_write_b32 %0, %1 offset:6912" ::"v"(a), "v"(__double2hiint(x[r].y)) : "memory");
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (MODE == 9 || MODE == 12) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                d2 v;
+                asm volatile("ds_read2st64_b64 %0, %1 offset0:0 offset1:9" : "=v"(v) : "v"((72 * (lane >> 3) + 8 * r + (lane & 7)) * 8 + (int)(w * 568 * 16)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                x[r] = v;
+            }
+        }
+        if (MODE == 10) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                double a, b;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(a) : "v"((72 * (lane >> 3) + 8 * r + (lane & 7)) * 8 + (int)(w * 568 * 16)) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:4608" : "=v"(b) : "v"((72 * (lane >> 3) + 8 * r + (lane & 7)) * 8 + (int)(w * 568 * 16)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                x[r] = d2{a, b};
+            }
+        }
         if (MODE == 0 || MODE == 1 || MODE == 4) {
 #pragma unroll
             for (int r = 0; r < 8; r++) x[r] = scr[72 * (lane >> 3) + 8 * r + (lane & 7)];
@@ -48,7 +92,7 @@ template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int
                 x[r] = d2{a, b};
             }
         }
-        if (MODE == 3 || MODE == 5 || MODE == 6) {
+        if (MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7 || MODE == 8 || MODE == 11) {
 #pragma unroll
             for (int r = 0; r < 8; r++) x[r].x += 1.0; // keep the stores live and distinct
         }
@@ -87,5 +131,11 @@ int main()
     run<4>("8 r128 only");
     run<5>("16 w64 only");
     run<6>("8 write2_b64 only");
+    run<7>("planar 16 w64 only");
+    run<8>("planar 8 write2st64_b64 only");
+    run<9>("planar 8 read2st64_b64 only");
+    run<10>("planar 16 r64 only");
+    run<11>("planar 32 w32 only");
+    run<12>("planar 8 write2st64 + 8 read2st64");
     return 0;
 }
