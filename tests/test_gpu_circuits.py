@@ -161,6 +161,33 @@ def test_string_api_and_host_batch_api(eoc):
         T.resetGateKey()
 
 
+def test_string_api_on_a_device_list(eoc):
+    """eoc_gpu_set_devices: the reference-style global key in front of two engines (both on device 0 on this box);
+    the string calls and the host-buffer batch call shard over them and give the single-engine bits"""
+    import ctypes as C
+    T, L = eoc.Tfhe, eoc.lib()
+    devs = (C.c_int * 2)(0, 0)
+    assert L.eoc_gpu_set_devices(devs, 2) == 0
+    assert L.eoc_gpu_set_devices(devs, -1) < 0 and L.eoc_gpu_set_devices(None, 2) < 0
+    try:
+        assert T.generateGateKey(80, 12) is not None
+        assert eoc.gpu_engine_count() == 2
+        c0, c1 = T.encryptBit(0), T.encryptBit(1)
+        assert T.decryptBit(T.nand(c1, c1)) == 0 and T.decryptBit(T.mux(c0, c0, c1)) == 1
+        import base64
+        rows = np.stack([np.frombuffer(base64.b64decode(c)[: 4 * 501], np.int32) for c in (c0, c1, c1, c0, c1)])
+        two = eoc.gate_batch(eoc.OPS["XOR"], rows, rows[::-1].copy())
+        T.resetGateKey()
+        assert L.eoc_gpu_set_devices(None, 0) == 0                   # forget the list: one engine on device 0 again
+        assert T.generateGateKey(80, 12) is not None
+        assert eoc.gpu_engine_count() == 1
+        one = eoc.gate_batch(eoc.OPS["XOR"], rows, rows[::-1].copy())
+        assert np.array_equal(one, two)
+    finally:
+        L.eoc_gpu_set_devices(None, 0)
+        T.resetGateKey()
+
+
 def test_engine_from_cloud_key_blob(eoc):
     """f2: a server holding only the EOCCK1 blob evaluates gates bit-exactly"""
     p, sk, eng, orc = _setup(eoc, 1, 8, 14)
