@@ -39,6 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PSETS = {"A": 0, "B": 1}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # datasheet FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz)
+PREFLIGHT_STEPS = 16
 FP64_SUSTAINED_TFLOPS = 62.0  # pure v_fma_f64 loop, tools/fp64_issue_bench.hip: the clock drops under FP64 load
 
 
@@ -231,9 +232,11 @@ def main():
         dt = time.perf_counter() - t0
         sec[wname] = {"bootstraps_per_s": round(wboots / dt, 1), "bootstraps": wboots, "workload": wdesc}
 
-    # pre-flight (set-up, untimed, not one of the W warm-up steps): the key images just built/received are
-    # exercised twice so that a bad broadcast or key load fails here, before anything is measured
-    for _ in range(2):
+    # pre-flight (set-up, untimed, not one of the W warm-up steps; reported as `preflight_steps`): the key images just
+    # built/received are exercised so that a bad broadcast or key load fails here, before anything is measured -- and
+    # for long enough (16 batches, 50 ms) that a rank which had nothing to run before (N > 1: no secondary passes)
+    # starts its W + K steps at the same sustained clock as the N = 1 run does
+    for _ in range(PREFLIGHT_STEPS):
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -320,6 +323,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preflight_steps": PREFLIGHT_STEPS,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
