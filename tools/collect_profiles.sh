@@ -7,11 +7,11 @@ TAG=${1:-final}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 mkdir -p "$O"
-python3 bench.py > "$O/bench_A.json" 2> "$O/bench_A.err"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_A.json" 2> "$O/bench_A.err"
 echo "bench A done"
-python3 bench.py --pset B --no-cpu-baseline --no-secondary > "$O/bench_B.json" 2> "$O/bench_B.err"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --pset B --no-cpu-baseline --no-secondary > "$O/bench_B.json" 2> "$O/bench_B.err"
 echo "bench B done"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
 echo "trace done"
 cp "$O"/trace/*/*kernel_stats.csv "$O/kernel_stats.csv"
 bash tools/pmc_passes.sh "$O/pmc" > "$O/pmc_passes.log" 2>&1
