@@ -17,6 +17,13 @@ static int l_generateGateKey(lua_State *L) {          /* like l_generateSecretKe
   return 1;
 }
 static int l_resetGateKey(lua_State *L) { (void)L; resetGateKey(); return 0; }
+static int l_setDevices(lua_State *L) {               /* (dev, dev, ...) -> 0 or a negative code; no arguments = forget */
+  int devs[64], n = lua_gettop(L);                    /* the devices the next generateGateKey / importPublicKey brings up */
+  if (n > 64) n = 64;
+  for (int i = 0; i < n; i++) devs[i] = (int)luaL_checkinteger(L, i + 1);
+  lua_pushinteger(L, eoc_gpu_set_devices(devs, n));
+  return 1;
+}
 static int l_encryptBit(lua_State *L) {               /* like l_encryptInteger, :59-67 */
   int bit = (int)luaL_checkinteger(L, 1);
   const char *key = luaL_optstring(L, 2, "");
@@ -148,7 +155,8 @@ static int l_netlistOptimize(lua_State *L) {          /* (gates, outputs: int32 
 }
 
 /* appended to the luaL_Reg table of luaopen_tfhe (ao-tfhe/eoc-tfhe-bindings.c:130-144) */
-  {"generateGateKey", l_generateGateKey}, {"resetGateKey", l_resetGateKey}, {"encryptBit", l_encryptBit},
+  {"generateGateKey", l_generateGateKey}, {"resetGateKey", l_resetGateKey}, {"setDevices", l_setDevices},
+  {"encryptBit", l_encryptBit},
   {"constantBit", l_constantBit}, {"decryptBit", l_decryptBit},
   {"gateNAND", l_gateNAND}, {"gateAND", l_gateAND}, {"gateOR", l_gateOR}, {"gateNOR", l_gateNOR},
   {"gateXOR", l_gateXOR}, {"gateXNOR", l_gateXNOR}, {"gateNOT", l_gateNOT}, {"gateMUX", l_gateMUX},

@@ -3,6 +3,7 @@
 -- the same functions with the same netlists.
 function Tfhe.generateGateKey(lambda, seed) return Tfhe.backend.generateGateKey(lambda, seed) end
 function Tfhe.resetGateKey()                return Tfhe.backend.resetGateKey() end
+function Tfhe.setDevices(...)               return Tfhe.backend.setDevices(...) end   -- GPUs behind the next gate key
 function Tfhe.encryptBit(bit, key)          return Tfhe.backend.encryptBit(bit, key) end
 function Tfhe.constantBit(bit)              return Tfhe.backend.constantBit(bit) end
 function Tfhe.decryptBit(ct, key)           return Tfhe.backend.decryptBit(ct, key) end
