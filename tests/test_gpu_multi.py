@@ -127,3 +127,47 @@ def test_operand_shape_checks(eoc, ctx3):
         eoc.gate_batch(eoc.OPS["NAND"], c[:, :-1], c[:, :-1])  # wrong row length
     with pytest.raises(eoc.EocError):
         eoc.gate_batch(0, c, c, ops=np.zeros(3, np.uint8))    # one opcode per row
+
+
+def test_concurrent_host_threads_are_serialised(eoc, ctx3):
+    """SURVEY 8b state/threading: one global context, calls serialised by a mutex -- four host threads issue batch and
+    circuit calls at once (ctypes releases the GIL during the call) and every result equals the oracle's"""
+    import threading
+    from eoc_tfhe_amd import circuits
+    p, sk, orc = ctx3
+    rng = np.random.default_rng(5)
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(2)
+    jobs, results, errors = [], {}, []
+    for t in range(4):
+        total = 6 + 3 * t
+        b0, b1 = rng.integers(0, 2, total).astype(np.uint8), rng.integers(0, 2, total).astype(np.uint8)
+        jobs.append((t, sk.encrypt_bits(b0, 20 + t, 0), sk.encrypt_bits(b1, 30 + t, 0)))
+
+    def work(t, c0, c1):
+        try:
+            outs = []
+            for op in ("NAND", "XOR", "OR"):
+                outs.append(eoc.gate_batch(eoc.OPS[op], c0, c1))
+            S = 3
+            wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+            wires[aw[0]: aw[0] + 2] = c0[: 2 * S].reshape(2, S, -1)
+            wires[bw[0]: bw[0] + 2] = c1[: 2 * S].reshape(2, S, -1)
+            eoc.circuit_run(gates, wires, S)
+            results[t] = (outs, wires[sw[0]: sw[0] + 3].copy())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t, c0, c1 in jobs:
+        outs, sums = results[t]
+        for got, op in zip(outs, ("NAND", "XOR", "OR")):
+            assert np.array_equal(got, orc.gate_batch(ol.OPS[op], c0, c1))
+        a = sk.decrypt_bits(c0[:6].reshape(2, 3, -1)[0]) + 2 * sk.decrypt_bits(c0[:6].reshape(2, 3, -1)[1])
+        b = sk.decrypt_bits(c1[:6].reshape(2, 3, -1)[0]) + 2 * sk.decrypt_bits(c1[:6].reshape(2, 3, -1)[1])
+        tot = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(3))
+        assert np.array_equal(tot, a.astype(np.int64) + b)
