@@ -7,6 +7,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // Planar forms (real parts in one plane, imaginary parts 4608 bytes above, lanes 8 bytes apart):
 // 7: 16 x ds_write_b64   8: 8 x ds_write2st64_b64   9: 8 x ds_read2st64_b64   10: 16 x ds_read_b64
 // 11: 32 x ds_write_b32 over four planes   12: 8 x write2st64_b64 + 8 x read2st64_b64 (a whole planar transpose)
+// Accumulator image round trip against a crossbar rotation:
+// 13: 16 x ds_write2st64_b32 + 16 x ds_read_b32 (rotated)   14: 16 x ds_bpermute_b32
 template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int iters)
 {
     __shared__ d2 scr_all[2][568];
@@ -55,6 +57,33 @@ template <int MODE> __global__ __launch_bounds__(128, 2) void k(double *out, int
                 asm volatile("ds_write_b32 %0, %1 offset:4608" ::"v"(a), "v"(__double2loint(x[r].y)) : "memory");
                 asm volatile("ds_write_b32 %0, %1 offset:6912" ::"v"(a), "v"(__double2hiint(x[r].y)) : "memory");
             }
+        }
+        if (MODE == 13 || MODE == 14) {
+            int v[16], u[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = __double2loint(x[r & 7].x) + r;
+            if (MODE == 13) {
+                int *img = reinterpret_cast<int *>(scr);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    img[lane + 64 * r] = v[r];
+                    img[lane + 64 * r + 1024] = -v[r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int k = (lane - (it * 37 + 5)) & 2047;
+#pragma unroll
+                for (int r = 0; r < 16; r++) u[r] = img[(k + 64 * r) & 2047];
+            } else {
+                const int src = ((lane - (it * 37 + 5)) & 63) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; r++) u[r] = __builtin_amdgcn_ds_bpermute(src, v[r]);
+            }
+            int acc = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc += u[r];
+            x[0].x += (double)(acc & 1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -137,5 +166,7 @@ int main()
     run<10>("planar 16 r64 only");
     run<11>("planar 32 w32 only");
     run<12>("planar 8 write2st64 + 8 read2st64");
+    run<13>("image: 16 write2st64_b32 + 16 r32");
+    run<14>("crossbar: 16 bpermute_b32");
     return 0;
 }
