@@ -658,6 +658,36 @@ struct BRArgs {
 // its wave as a signed 2N-periodic image ext[k] = ACC[k], ext[k + N] = -ACC[k] (8 KB), which turns the negacyclic
 // rotation of the next step into plain reads at (k - abar) mod 2N; the transposes of the step then overwrite it (one
 // wave's LDS operations execute in order, and only the owning wave ever touches the image).
+// EOC_ROT_XBAR: (X^abar - 1) * ACC without the accumulator image.  Coefficient lane + 64 r of ACC lives in racc[r];
+// entry k of the signed 2N-periodic extension, k = lane' + 64 r' (r' < 32), is +racc[r'] (r' < 16) or -racc[r' - 16] of
+// lane lane'.  Entry (lane + 64 r) - abar with abar = 64 Q + s is lane (lane - s) mod 64, register r - Q - (lane < s):
+// one ds_bpermute_b32 per register moves the lanes, the register shift Q is wave-uniform and selects one of 32
+// compile-time renamings of the block below.
+#ifndef EOC_ROT_XBAR
+#define EOC_ROT_XBAR 3
+#endif
+#ifndef EOC_BK_BUFFER
+#define EOC_BK_BUFFER 1
+#endif
+template <int Q>
+__device__ __forceinline__ void rot_digits(const uint32_t (&t)[16], const uint32_t (&racc)[16], bool borrow, uint32_t offset,
+                                           uint32_t (&d)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int k0 = (r - Q) & 31, k1 = (r - Q - 1) & 31;
+        const uint32_t a0 = t[k0 & 15], a1 = t[k1 & 15];
+        const uint32_t A = offset - racc[r];
+        const bool n0 = k0 >= 16, n1 = k1 >= 16;
+        if (n0 == n1) {
+            const uint32_t w = borrow ? a1 : a0;
+            d[r] = n0 ? A - w : A + w;
+        } else {
+            const uint32_t d0 = n0 ? A - a0 : A + a0, d1 = n1 ? A - a1 : A + a1;
+            d[r] = borrow ? d1 : d0;
+        }
+    }
+}
 constexpr int kBRLds = (kTwEntries + kNH + 2 * kScr) * 16; // 35 584 bytes: four workgroups per CU
 
 // BGBIT > 0: gadget base known at compile time (digit extraction becomes one bit-field extract); 0: run time
@@ -676,15 +706,25 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     d2 *scr_partner = s_scr_all + (h ^ 1) * kScr;
     int32_t *ext = reinterpret_cast<int32_t *>(scr); // [2N] signed periodic image of ACC_h (between steps)
 
+    // bit 0: gadget lengths 1 and 2, bit 1: length 3; length 4 (no default set uses it) keeps the accumulator image,
+    // its kernel is over the register budget either way
+    constexpr bool kXbar = L <= 3 && (EOC_ROT_XBAR & (L == 3 ? 2 : 1)) != 0;
+    constexpr bool kHoist = kXbar && (EOC_ROT_XBAR & 4) != 0;        // bit 2: first key rows requested ahead of the switch
     const uint32_t job = blockIdx.x; // grid = number of jobs
-    const uint16_t *bara = A.bara + (size_t)job * A.bara_stride;
+    // the rotation amounts of this job are wave-uniform and constant during the kernel: read as dwords through the
+    // constant address space (rows are 16-byte aligned: bara_stride is a multiple of 8), i.e. by scalar loads
+    typedef const __attribute__((address_space(4))) uint32_t *cu32p;
+    const cu32p bara32 = (cu32p)(uintptr_t)(A.bara + (size_t)job * A.bara_stride);
+    auto load_abar = [&](int idx) __attribute__((always_inline)) {
+        return (int)((bara32[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu);
+    };
 
     load_tables(s_tw, s_twist, g_tw, g_twist, tid, 128);
 
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
     uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8), lane + 64 r + 512 in racc[8 + r]
     {
-        const int barb = bara[A.n];
+        const int barb = load_abar(A.n);
         const int rot = (2 * kN - barb) & (2 * kN - 1);
         const int32_t *st = A.acc_state + ((size_t)job * 2 + h) * kN;
 #pragma unroll
@@ -708,6 +748,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
     constexpr int KPL = 2 * L;
     const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
+#if EOC_BK_BUFFER
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.bkfft), 0, (int)((size_t)A.n * KPL * 2 * kNH * 16), 0x00020000);
+#endif
     // digits arrive biased, u = digit + Bg/2 in [0, Bg); as_double(2^52 | u) - (2^52 + Bg/2) is the digit, exactly;
     // the stage-0 sums p - q and p + q are formed on the biased integers and converted the same way
     const double bias1 = 4503599627370496.0 + (double)halfBg, bias2 = 4503599627370496.0 + (double)Bg;
@@ -722,7 +766,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 #endif
-    int abar_next = (int)bara[A.step_begin];
+    int abar_next = load_abar(A.step_begin);
     for (int i = A.step_begin; i < A.step_end; i++) {
         EOC_STAMP(15);
 #if EOC_PRIO_ALT
@@ -751,11 +795,58 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         }
 #endif
         const int abar = __builtin_amdgcn_readfirstlane(abar_next);
-        abar_next = (int)bara[i + 1]; // one step ahead (entry n is barb: always in bounds); retires with the key rows
+        abar_next = load_abar(i + 1); // one step ahead (entry n is barb: always in bounds); retires with the key rows
         // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
         // zero update, which is what skipping the step (as libtfhe does) amounts to.
+        const d2 *rows_i = bk + ((size_t)i * KPL + h * L) * 2 * kNH; // rows (h, p), p = 1..L
+        auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
+            const d2 *src = rows_i + ((size_t)(p - 1) * 2 + c) * kNH;
+#if EOC_BK_BUFFER
+            // buffer loads: the row's byte offset is wave-uniform (SGPR), the lane part one loop-invariant VGPR
+            const uint32_t row_off = (uint32_t)((((size_t)i * KPL + h * L) * 2 + (size_t)(p - 1) * 2 + c) * kNH * 16);
+#endif
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+#ifdef EOC_ABL_NOBK
+                b[r] = s_twist[(r * 64 + lane) ^ c];
+                (void)src;
+#elif EOC_BK_BUFFER
+                (void)src;
+                b[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane * 16, (int)(row_off + r * 1024), 0));
+#else
+                b[r] = src[r * 64 + lane];
+#endif
+            }
+        };
+        d2 ra[8], rb[8];
+        if constexpr (kHoist) {
+            // the digit block below is a 32-way switch (basic-block boundaries): the first key rows are requested ahead of it
+            load_row(1, 1 - h, ra);
+            if constexpr (L >= 2) load_row(2, 1 - h, rb);
+        }
         uint32_t dlo[8], dhi[8];
-        {
+        if constexpr (kXbar) {
+            const int s = abar & 63;
+            const int src = ((lane - s) & 63) << 2;
+            uint32_t t[16], d[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)racc[r]);
+            const bool borrow = lane < s;
+#define EOC_RQ(q) case q: rot_digits<q>(t, racc, borrow, offset, d); break;
+            switch (abar >> 6) {
+                EOC_RQ(0) EOC_RQ(1) EOC_RQ(2) EOC_RQ(3) EOC_RQ(4) EOC_RQ(5) EOC_RQ(6) EOC_RQ(7)
+                EOC_RQ(8) EOC_RQ(9) EOC_RQ(10) EOC_RQ(11) EOC_RQ(12) EOC_RQ(13) EOC_RQ(14) EOC_RQ(15)
+                EOC_RQ(16) EOC_RQ(17) EOC_RQ(18) EOC_RQ(19) EOC_RQ(20) EOC_RQ(21) EOC_RQ(22) EOC_RQ(23)
+                EOC_RQ(24) EOC_RQ(25) EOC_RQ(26) EOC_RQ(27) EOC_RQ(28) EOC_RQ(29) EOC_RQ(30)
+                default: rot_digits<31>(t, racc, borrow, offset, d); break;
+            }
+#undef EOC_RQ
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                dlo[r] = d[r];
+                dhi[r] = d[8 + r];
+            }
+        } else {
             const int k = (lane - abar) & (2 * kN - 1);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -766,19 +857,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             }
         }
         EOC_STAMP(0);
-        const d2 *rows_i = bk + ((size_t)i * KPL + h * L) * 2 * kNH; // rows (h, p), p = 1..L
-        auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
-            const d2 *src = rows_i + ((size_t)(p - 1) * 2 + c) * kNH;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-#ifdef EOC_ABL_NOBK
-                b[r] = s_twist[(r * 64 + lane) ^ c];
-                (void)src;
-#else
-                b[r] = src[r * 64 + lane];
-#endif
-            }
-        };
         // digit p of the 16 coefficients of this lane, first pass of its forward transform (stages 0-2)
         auto make_x0 = [&](int p, d2 (&x)[8]) __attribute__((always_inline)) {
             const int shift = 32 - p * Bgbit;
@@ -808,11 +886,13 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         };
         // forward transforms of the l digits (two at a time, skewed on the one scratch; an odd last one alone) and
         // the chain for the partner's output polynomial.  The spectra stay in registers for the own chain below.
-        d2 xs[L][8], ra[8], rb[8], S[8];
+        d2 xs[L][8], S[8];
 #pragma unroll
         for (int p0 = 0; p0 + 1 < L; p0 += 2) {
-            load_row(p0 + 1, 1 - h, ra);
-            load_row(p0 + 2, 1 - h, rb);
+            if (!kHoist || p0 > 0) {
+                load_row(p0 + 1, 1 - h, ra);
+                load_row(p0 + 2, 1 - h, rb);
+            }
             make_x0(p0 + 1, xs[p0]);
             EOC_STAMP(1);
             fft_fwd_rest_x2(xs[p0], xs[p0 + 1], [&]() __attribute__((always_inline)) { make_x0(p0 + 2, xs[p0 + 1]); },
@@ -823,7 +903,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             EOC_STAMP(3);
         }
         if constexpr ((L & 1) != 0) {
-            load_row(L, 1 - h, ra);
+            if (!kHoist || L > 1) load_row(L, 1 - h, ra);
             make_x0(L, xs[L - 1]);
             EOC_STAMP(1);
             fft_fwd_rest(xs[L - 1], s_tw, scr, lane);
@@ -860,13 +940,24 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             d2 y = cmulc(S[r], ut[r]); // 1/512 is in the key image
             racc[r] += wrap_trunc(y.x);
             racc[8 + r] += wrap_trunc(y.y);
-            ext[j] = (int32_t)racc[r];
-            ext[j + kN] = (int32_t)(0u - racc[r]);
-            ext[j + kNH] = (int32_t)racc[8 + r];
-            ext[j + kNH + kN] = (int32_t)(0u - racc[8 + r]);
+            if constexpr (!kXbar) {
+                ext[j] = (int32_t)racc[r];
+                ext[j + kN] = (int32_t)(0u - racc[r]);
+                ext[j + kNH] = (int32_t)racc[8 + r];
+                ext[j + kNH + kN] = (int32_t)(0u - racc[8 + r]);
+            }
         }
         wave_lds_fence();
         EOC_STAMP(9);
+    }
+    if (kXbar && A.step_end >= A.n) { // the sample extraction below reads the image: written once, after the last step
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = lane + 64 * r;
+            ext[j] = (int32_t)racc[r];
+            ext[j + kN] = (int32_t)(0u - racc[r]);
+        }
+        wave_lds_fence();
     }
 #ifdef EOC_STAMPS
     st_acc[11] = __builtin_amdgcn_s_memtime(); // loop exit time
@@ -874,10 +965,13 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * 2 + h) * 16 + k] = st_acc[k];
 #endif
 
+    // the lane index again, from the hardware (not from threadIdx): nothing lane-derived then has to stay live across
+    // the step loop just for these stores
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (A.step_end < A.n) { // not the last part: park the accumulator for the next launch
         int32_t *st = A.acc_state + ((size_t)job * 2 + h) * kN;
 #pragma unroll
-        for (int r = 0; r < 16; r++) st[lane + 64 * (r & 7) + (r >> 3) * kNH] = (int32_t)racc[r];
+        for (int r = 0; r < 16; r++) st[lane_e + 64 * (r & 7) + (r >> 3) * kNH] = (int32_t)racc[r];
         return;
     }
     // tLweExtractLweSample, index 0: u_0 = ACC_0[0], u_j = -ACC_0[N - j] = ext[2N - j]; b = ACC_1[0]
