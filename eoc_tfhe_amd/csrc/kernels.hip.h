@@ -654,10 +654,11 @@ struct BRArgs {
     int32_t *acc_state;         // [jobs][2][N], only used when the range is a proper part of [0, n)
 };
 
-// LDS: the two tables + one 9 KB scratch per wave.  Between two steps the scratch holds the accumulator polynomial of
-// its wave as a signed 2N-periodic image ext[k] = ACC[k], ext[k + N] = -ACC[k] (8 KB), which turns the negacyclic
-// rotation of the next step into plain reads at (k - abar) mod 2N; the transposes of the step then overwrite it (one
-// wave's LDS operations execute in order, and only the owning wave ever touches the image).
+// LDS: the two tables + one 9 KB scratch per wave.  The accumulator lives in registers (racc[16]); the scratch holds it
+// as a signed 2N-periodic image ext[k] = ACC[k], ext[k + N] = -ACC[k] (8 KB) only where something reads it by index:
+// the sample extraction after the last step, and -- for gadget length 4, which keeps the older form -- the negacyclic
+// rotation of every step (plain reads at (k - abar) mod 2N; the transposes of the step then overwrite the image: one
+// wave's LDS operations execute in order, and only the owning wave ever touches it).
 // EOC_ROT_XBAR: (X^abar - 1) * ACC without the accumulator image.  Coefficient lane + 64 r of ACC lives in racc[r];
 // entry k of the signed 2N-periodic extension, k = lane' + 64 r' (r' < 32), is +racc[r'] (r' < 16) or -racc[r' - 16] of
 // lane lane'.  Entry (lane + 64 r) - abar with abar = 64 Q + s is lane (lane - s) mod 64, register r - Q - (lane < s):
