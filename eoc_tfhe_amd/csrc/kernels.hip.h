@@ -255,8 +255,10 @@ __device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, 
 #define EOC_M_VALU 0x002
 #define EOC_M_DSR 0x100
 #define EOC_M_DSW 0x200
+// T2 != nullptr: the last pass's four twiddles are resident in registers (loop-invariant, kept by the caller)
 template <class MakeB>
-__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, const d2 *tw, d2 *scr, int lane)
+__device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB make_b, const d2 *tw, d2 *scr, int lane,
+                                                const d2 (*T2)[4] = nullptr)
 {
     d2 t1[4], t2[4];
     EOC_SB();
@@ -280,7 +282,12 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     // region C: second pass of a; b's stores spread through its first half, then b's reads and the last twiddle set
     t01_write(xb, scr, lane);
     t01_read(xb, scr, lane);
-    tw_load(t2, tw + kTwF2 + lane, 64);
+    if (T2) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) t2[k] = (*T2)[k];
+    } else {
+        tw_load(t2, tw + kTwF2 + lane, 64);
+    }
     wave_lds_fence();
     fwd_pass12(xa, t1);
 #if EOC_ILV
@@ -289,7 +296,8 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
         EOC_SGB(EOC_M_DSW, 1);
         EOC_SGB(EOC_M_VALU, 4);
     }
-    EOC_SGB(EOC_M_DSR, 12);
+    if (T2) EOC_SGB(EOC_M_DSR, 8);
+    else EOC_SGB(EOC_M_DSR, 12);
     EOC_SGB(EOC_M_VALU, 40);
 #endif
     EOC_SB();
@@ -401,11 +409,17 @@ __device__ __forceinline__ void t10_read(d2 (&x)[8], const d2 *scr, int lane)
 #else
 #define EOC_SBI() do { } while (0)
 #endif
-__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *tw, const d2 *s_twist, d2 *scr, int lane)
+__device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *tw, const d2 *s_twist, d2 *scr, int lane,
+                                             const d2 (*T1)[4] = nullptr)
 {
     d2 t1[4], t0[4];
     EOC_SBI();
-    tw_load(t1, tw + kTwI1 + (lane & 7), 8);
+    if (T1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) t1[k] = (*T1)[k];
+    } else {
+        tw_load(t1, tw + kTwI1 + (lane & 7), 8);
+    }
     inv_pass2(x);
     t21_write(x, scr, lane);
     t21_read(x, scr, lane);
@@ -667,6 +681,12 @@ struct BRArgs {
 #ifndef EOC_ROT_XBAR
 #define EOC_ROT_XBAR 3
 #endif
+#ifndef EOC_RES_T1
+#define EOC_RES_T1 1
+#endif
+#ifndef EOC_RES_T2
+#define EOC_RES_T2 1
+#endif
 #ifndef EOC_BK_BUFFER
 #define EOC_BK_BUFFER 1
 #endif
@@ -767,6 +787,13 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 #endif
+    // gadget length 2 has registers to spare: the forward transform's last four twiddles stay resident
+    constexpr bool kResT2 = EOC_RES_T2 && L == 2;
+    d2 res_t2[4];
+    if constexpr (kResT2) tw_load(res_t2, s_tw + kTwF2 + lane, 64);
+    constexpr bool kResT1 = EOC_RES_T1 && L == 2; // ... and the inverse transform's first table pass
+    d2 res_t1[4];
+    if constexpr (kResT1) tw_load(res_t1, s_tw + kTwI1 + (lane & 7), 8);
     int abar_next = load_abar(A.step_begin);
     for (int i = A.step_begin; i < A.step_end; i++) {
         EOC_STAMP(15);
@@ -897,7 +924,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             make_x0(p0 + 1, xs[p0]);
             EOC_STAMP(1);
             fft_fwd_rest_x2(xs[p0], xs[p0 + 1], [&]() __attribute__((always_inline)) { make_x0(p0 + 2, xs[p0 + 1]); },
-                            s_tw, scr, lane);
+                            s_tw, scr, lane, kResT2 ? &res_t2 : nullptr);
             EOC_STAMP(2);
             mac(p0 == 0, xs[p0], ra, S);
             mac(false, xs[p0 + 1], rb, S);
@@ -933,7 +960,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         EOC_SYNC(); // the partner has read this wave's scratch before the inverse transform overwrites it
         EOC_STAMP(7);
         d2 ut[8];
-        fft_inv_wave(S, ut, s_tw, s_twist, scr, lane);
+        fft_inv_wave(S, ut, s_tw, s_twist, scr, lane, kResT1 ? &res_t1 : nullptr);
         EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
