@@ -409,6 +409,11 @@ __device__ __forceinline__ void t10_read(d2 (&x)[8], const d2 *scr, int lane)
 #else
 #define EOC_SBI() do { } while (0)
 #endif
+// EOC_INV_ILV: the eight stores of each transpose leave in the order the last stage of the register pass completes its
+// butterflies -- (0,4) (1,5) (2,6) (3,7) -- and are spread through that stage (sched_group_barrier), as the forward pair does
+#ifndef EOC_INV_ILV
+#define EOC_INV_ILV 1
+#endif
 __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *tw, const d2 *s_twist, d2 *scr, int lane,
                                              const d2 (*T1)[4] = nullptr)
 {
@@ -421,16 +426,50 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *
         tw_load(t1, tw + kTwI1 + (lane & 7), 8);
     }
     inv_pass2(x);
+#if EOC_INV_ILV
+    {
+        constexpr int ord[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+#pragma unroll
+        for (int q = 0; q < 8; q++) scr[f12(lane * 8 + ord[q])] = x[ord[q]];
+        wave_lds_fence();
+    }
+    t21_read(x, scr, lane);
+    EOC_SGB(EOC_M_VALU, 32);                                     // stages 8 and 7
+    EOC_SGB(EOC_M_VALU, 4);  EOC_SGB(EOC_M_DSW, 2);              // (0,4): w = 1
+    EOC_SGB(EOC_M_VALU, 6);  EOC_SGB(EOC_M_DSW, 2);              // (1,5)
+    EOC_SGB(EOC_M_VALU, 4);  EOC_SGB(EOC_M_DSW, 2);              // (2,6): w = conj(i)
+    EOC_SGB(EOC_M_VALU, 6);  EOC_SGB(EOC_M_DSW, 2);              // (3,7)
+    EOC_SGB(EOC_M_DSR, 8);
+#else
     t21_write(x, scr, lane);
     t21_read(x, scr, lane);
+#endif
     tw_load(t0, tw + kTwI0 + lane, 64);
 #pragma unroll
     for (int r = 0; r < 8; r++) ut[r] = s_twist[lane + 64 * r];
     wave_lds_fence();
     EOC_SBI();
     inv_pass10(x, t1);
+#if EOC_INV_ILV
+    {
+        constexpr int ord[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+        const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+        for (int q = 0; q < 8; q++) scr[72 * hi + 8 * ord[q] + lo] = x[ord[q]];
+        wave_lds_fence();
+    }
+    t10_read(x, scr, lane);
+    EOC_SGB(EOC_M_VALU, 48);                                     // first two stages of the pass
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        EOC_SGB(EOC_M_VALU, 6);
+        EOC_SGB(EOC_M_DSW, 2);
+    }
+    EOC_SGB(EOC_M_DSR, 8);
+#else
     t10_write(x, scr, lane);
     t10_read(x, scr, lane);
+#endif
     EOC_SBI();
     inv_pass10(x, t0);
 }
