@@ -560,7 +560,7 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
             a.acc_state = W.d_acc_state;
             // priority alternation pays only when every workgroup is resident from the start (four per CU)
             a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
-                          : (njobs <= resident ? EOC_PRIO_DUTY : e->prio_multi);
+                          : (njobs <= resident ? kPrioDuty : e->prio_multi);
             dim3 grid(njobs), block(128);
             if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
                 hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);

@@ -130,13 +130,6 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Ablation switches for diagnostic builds (tools/ablate.sh): wrong results, timing only.
-#ifdef EOC_ABL_NOBAR
-#define EOC_SYNC() do { } while (0)
-#else
-#define EOC_SYNC() __syncthreads()
-#endif
-
 // ---- forward transform, in pieces ---------------------------------------------------------------
 // stage 0 on exact integer-valued doubles: u = (a, b), v = (p, q), dm = p - q, dp = p + q
 __device__ __forceinline__ void fwd_stage0(d2 &lo, d2 &hi, double a, double b, double dm, double dp)
@@ -161,13 +154,8 @@ __device__ __forceinline__ void fwd_pass0_tail(d2 (&x)[8])
 // the four loaded twiddles of a table-driven pass; `stride` = 8 (pass 1, q = table + (lane >> 3)) or 64 (pass 2)
 __device__ __forceinline__ void tw_load(d2 (&t)[4], const d2 *q, int stride)
 {
-#ifdef EOC_ABL_NOTW
-    (void)q; (void)stride;
-    for (int k = 0; k < 4; k++) t[k] = d2{0.7 + 0.01 * k, 0.7 - 0.01 * k};
-#else
 #pragma unroll
     for (int k = 0; k < 4; k++) t[k] = q[k * stride];
-#endif
 }
 __device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[4])
 { // three radix-2 stages on the 8 register points: twiddles A | B0, i B0 | C0, i C0, C2, i C2
@@ -188,37 +176,29 @@ __device__ __forceinline__ void fwd_pass12(d2 (&x)[8], const d2 (&t)[4])
 // execute in issue order, so a later write to the same scratch cannot overtake an earlier read.
 __device__ __forceinline__ void t01_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[72 * r + lane] = x[r];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t01_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * hi + 8 * r + lo];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t12_write(const d2 (&x)[8], d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) scr[f12(hi * 64 + r * 8 + lo)] = x[r];
     wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t12_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(lane * 8 + r)];
     wave_lds_fence();
-#endif
 }
 
 // one forward transform after its first pass: x[] in L0 (stages 0-2 done) -> x[] in L2.  The second twiddle set is
@@ -235,22 +215,12 @@ __device__ __forceinline__ void fft_fwd_rest(d2 (&x)[8], const d2 *tw, d2 *scr, 
     t12_read(x, scr, lane);
     fwd_pass12(x, t2);
 }
-// EOC_PIN_SKEW: scheduling barriers that pin the phase order below (the machine scheduler otherwise sinks the early
-// twiddle reads under the transposes and waits for BOTH transposes before the first register pass)
-#ifndef EOC_PIN_SKEW
-#define EOC_PIN_SKEW 1
-#endif
-#if EOC_PIN_SKEW
-#define EOC_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define EOC_SB() do { } while (0)
-#endif
-// EOC_ILV: the stores of one transform's transpose are interleaved one by one with the other transform's register pass
+// EOC_SB: scheduling barriers that pin the phase order of the skewed pair below (the machine scheduler otherwise sinks
+// the early twiddle reads under the transposes and waits for BOTH transposes before the first register pass).
+// EOC_SGB: the stores of one transform's transpose are interleaved one by one with the other transform's register pass
 // (sched_group_barrier pipelines): a ds_write_b128 holds the CU's LDS store path for about 13 cycles, and a wave that
 // issues eight of them back to back is issue-blocked for all of them (SQ_WAIT_INST_LDS was 22 % of the wave cycles)
-#ifndef EOC_ILV
-#define EOC_ILV 1
-#endif
+#define EOC_SB() __builtin_amdgcn_sched_barrier(0)
 #define EOC_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #define EOC_M_VALU 0x002
 #define EOC_M_DSR 0x100
@@ -268,7 +238,6 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     t01_write(xa, scr, lane);
     make_b();
     t01_read(xa, scr, lane);
-#if EOC_ILV
     EOC_SGB(EOC_M_DSR, 4);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -277,7 +246,6 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     }
     EOC_SGB(EOC_M_VALU, 64);
     EOC_SGB(EOC_M_DSR, 8);
-#endif
     EOC_SB();
     // region C: second pass of a; b's stores spread through its first half, then b's reads and the last twiddle set
     t01_write(xb, scr, lane);
@@ -290,7 +258,6 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     }
     wave_lds_fence();
     fwd_pass12(xa, t1);
-#if EOC_ILV
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         EOC_SGB(EOC_M_DSW, 1);
@@ -299,13 +266,11 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     if (T2) EOC_SGB(EOC_M_DSR, 8);
     else EOC_SGB(EOC_M_DSR, 12);
     EOC_SGB(EOC_M_VALU, 40);
-#endif
     EOC_SB();
     // region D: second pass of b under a's second transpose
     t12_write(xa, scr, lane);
     t12_read(xa, scr, lane);
     fwd_pass12(xb, t1);
-#if EOC_ILV
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         EOC_SGB(EOC_M_DSW, 1);
@@ -313,13 +278,11 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     }
     EOC_SGB(EOC_M_DSR, 8);
     EOC_SGB(EOC_M_VALU, 40);
-#endif
     EOC_SB();
     // region E: third pass of a under b's second transpose
     t12_write(xb, scr, lane);
     t12_read(xb, scr, lane);
     fwd_pass12(xa, t2);
-#if EOC_ILV
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         EOC_SGB(EOC_M_DSW, 1);
@@ -327,7 +290,6 @@ __device__ __forceinline__ void fft_fwd_rest_x2(d2 (&xa)[8], d2 (&xb)[8], MakeB 
     }
     EOC_SGB(EOC_M_DSR, 8);
     EOC_SGB(EOC_M_VALU, 40);
-#endif
     EOC_SB();
     fwd_pass12(xb, t2);
 }
@@ -365,60 +327,28 @@ __device__ __forceinline__ void inv_pass10(d2 (&x)[8], const d2 (&t)[4])
     ct_iwc(x[2], x[6], t[2]);
     ct_iwc(x[3], x[7], t[3]);
 }
-__device__ __forceinline__ void t21_write(const d2 (&x)[8], d2 *scr, int lane)
-{
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
-#pragma unroll
-    for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = x[r];
-    wave_lds_fence();
-#endif
-}
 __device__ __forceinline__ void t21_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#if !defined(EOC_ABL_NOTRANSPOSE) && !defined(EOC_ABL_NOT12)
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[f12(hi * 64 + r * 8 + lo)];
     wave_lds_fence();
-#endif
-}
-__device__ __forceinline__ void t10_write(const d2 (&x)[8], d2 *scr, int lane)
-{
-#ifndef EOC_ABL_NOTRANSPOSE
-    const int hi = lane >> 3, lo = lane & 7;
-#pragma unroll
-    for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = x[r];
-    wave_lds_fence();
-#endif
 }
 __device__ __forceinline__ void t10_read(d2 (&x)[8], const d2 *scr, int lane)
 {
-#ifndef EOC_ABL_NOTRANSPOSE
 #pragma unroll
     for (int r = 0; r < 8; r++) x[r] = scr[72 * r + lane];
     wave_lds_fence();
-#endif
 }
 // inverse transform + un-twist factors: the twiddles of both table passes and the 8 un-twist factors are requested
-// under the first transpose, so that no table read sits between a transpose read and its use
-#ifndef EOC_PIN_INV
-#define EOC_PIN_INV 1
-#endif
-#if EOC_PIN_INV
-#define EOC_SBI() __builtin_amdgcn_sched_barrier(0)
-#else
-#define EOC_SBI() do { } while (0)
-#endif
-// EOC_INV_ILV: the eight stores of each transpose leave in the order the last stage of the register pass completes its
-// butterflies -- (0,4) (1,5) (2,6) (3,7) -- and are spread through that stage (sched_group_barrier), as the forward pair does
-#ifndef EOC_INV_ILV
-#define EOC_INV_ILV 1
-#endif
+// under the first transpose, so that no table read sits between a transpose read and its use.  The eight stores of each
+// transpose leave in the order the last stage of the register pass completes its butterflies -- (0,4) (1,5) (2,6) (3,7) --
+// and are spread through that stage (sched_group_barrier), as the forward pair does
 __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *tw, const d2 *s_twist, d2 *scr, int lane,
                                              const d2 (*T1)[4] = nullptr)
 {
     d2 t1[4], t0[4];
-    EOC_SBI();
+    EOC_SB();
     if (T1) {
 #pragma unroll
         for (int k = 0; k < 4; k++) t1[k] = (*T1)[k];
@@ -426,7 +356,6 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *
         tw_load(t1, tw + kTwI1 + (lane & 7), 8);
     }
     inv_pass2(x);
-#if EOC_INV_ILV
     {
         constexpr int ord[8] = {0, 4, 1, 5, 2, 6, 3, 7};
 #pragma unroll
@@ -440,17 +369,12 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *
     EOC_SGB(EOC_M_VALU, 4);  EOC_SGB(EOC_M_DSW, 2);              // (2,6): w = conj(i)
     EOC_SGB(EOC_M_VALU, 6);  EOC_SGB(EOC_M_DSW, 2);              // (3,7)
     EOC_SGB(EOC_M_DSR, 8);
-#else
-    t21_write(x, scr, lane);
-    t21_read(x, scr, lane);
-#endif
     tw_load(t0, tw + kTwI0 + lane, 64);
 #pragma unroll
     for (int r = 0; r < 8; r++) ut[r] = s_twist[lane + 64 * r];
     wave_lds_fence();
-    EOC_SBI();
+    EOC_SB();
     inv_pass10(x, t1);
-#if EOC_INV_ILV
     {
         constexpr int ord[8] = {0, 4, 1, 5, 2, 6, 3, 7};
         const int hi = lane >> 3, lo = lane & 7;
@@ -466,11 +390,7 @@ __device__ __forceinline__ void fft_inv_wave(d2 (&x)[8], d2 (&ut)[8], const d2 *
         EOC_SGB(EOC_M_DSW, 2);
     }
     EOC_SGB(EOC_M_DSR, 8);
-#else
-    t10_write(x, scr, lane);
-    t10_read(x, scr, lane);
-#endif
-    EOC_SBI();
+    EOC_SB();
     inv_pass10(x, t0);
 }
 
@@ -638,28 +558,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 }
 
 
-// Tuning notes kept from measured experiments (round 1: tools/ablate.sh, tools/variants.sh; 1024 gates, Set A):
-//   register copy of the accumulator next to the LDS copy the rotation reads: -1.7 %  (kept: racc[])
-//   EOC_PRIO_ALT  wave-priority alternation between the two waves sharing a SIMD (see the loop): steps per phase
-//                 (power of two; 0 compiles it out).  Single-round launches: -10 % (l = 2) / -13 % (l = 3) at
-//                 EOC_PRIO_DUTY = 11..12 sixteenths and 1 step per phase (8 steps: -8 %, 16: -6 %); level 1, 2, 3 alike.
-//                 The host enables it per launch (BRArgs::prio_duty); launches of several rounds lose 4 % with it.
-#ifndef EOC_PRIO_ALT
-#define EOC_PRIO_ALT 1
-#endif
-#ifndef EOC_PRIO_DUTY
-#define EOC_PRIO_DUTY 11
-#endif
-#ifndef EOC_PRIO_HI
-#define EOC_PRIO_HI 1
-#endif
-//   the step's rotation amount (bara[i]) is loaded one step ahead, so no load is waited for at the step top: -1 % (kept)
-//   measured and rejected in round 1: staggering the workgroups of a CU, feedback priorities, touching the next step's
-//   key rows early, a one-wave-per-ciphertext form (k_blind_rotate_t, removed in round 2: slower at every size).
-//   measured and rejected in round 2: both waves of a pair on one priority phase (+1 %), a phase taken from the shader
-//   clock for launches of several rounds (+-0), a 168-register three-waves-per-SIMD form for launches wider than the
-//   resident set (two ciphertexts per 256-thread workgroup, transforms one at a time, one key-row buffer: 40 spills,
-//   270 k against 320 k gates/s for the single-round slices of the two-wave form).
+// Wave-priority alternation between the two waves sharing a SIMD (see the step loop): one step per phase, the
+// later-placed wave holds the high priority kPrioDuty sixteenths of the steps.  The host enables it per launch
+// (BRArgs::prio_duty).  Everything that was measured and rejected on this kernel is recorded in DESIGN.md 5.1; the
+// timing-only ablations are patches under tools/patches/ (tools/variants.sh applies them to a scratch copy).
+constexpr int kPrioDuty = 11;
 
 // In-kernel stamps (diagnostic build only, -DEOC_STAMPS): per-wave cycle shares of the step's
 // segments.  Never enabled in the shipped library; the values leave through a buffer of their own.
@@ -708,27 +611,13 @@ struct BRArgs {
 };
 
 // LDS: the two tables + one 9 KB scratch per wave.  The accumulator lives in registers (racc[16]); the scratch holds it
-// as a signed 2N-periodic image ext[k] = ACC[k], ext[k + N] = -ACC[k] (8 KB) only where something reads it by index:
-// the sample extraction after the last step, and -- for gadget length 4, which keeps the older form -- the negacyclic
-// rotation of every step (plain reads at (k - abar) mod 2N; the transposes of the step then overwrite the image: one
-// wave's LDS operations execute in order, and only the owning wave ever touches it).
-// EOC_ROT_XBAR: (X^abar - 1) * ACC without the accumulator image.  Coefficient lane + 64 r of ACC lives in racc[r];
+// as a signed 2N-periodic image ext[k] = ACC[k], ext[k + N] = -ACC[k] (8 KB) only for the sample extraction after the
+// last step, which reads it by index.
+// (X^abar - 1) * ACC without an accumulator image: coefficient lane + 64 r of ACC lives in racc[r];
 // entry k of the signed 2N-periodic extension, k = lane' + 64 r' (r' < 32), is +racc[r'] (r' < 16) or -racc[r' - 16] of
 // lane lane'.  Entry (lane + 64 r) - abar with abar = 64 Q + s is lane (lane - s) mod 64, register r - Q - (lane < s):
 // one ds_bpermute_b32 per register moves the lanes, the register shift Q is wave-uniform and selects one of 32
 // compile-time renamings of the block below.
-#ifndef EOC_ROT_XBAR
-#define EOC_ROT_XBAR 3
-#endif
-#ifndef EOC_RES_T1
-#define EOC_RES_T1 1
-#endif
-#ifndef EOC_RES_T2
-#define EOC_RES_T2 1
-#endif
-#ifndef EOC_BK_BUFFER
-#define EOC_BK_BUFFER 1
-#endif
 template <int Q>
 __device__ __forceinline__ void rot_digits(const uint32_t (&t)[16], const uint32_t (&racc)[16], bool borrow, uint32_t offset,
                                            uint32_t (&d)[16])
@@ -750,7 +639,11 @@ __device__ __forceinline__ void rot_digits(const uint32_t (&t)[16], const uint32
 }
 constexpr int kBRLds = (kTwEntries + kNH + 2 * kScr) * 16; // 35 584 bytes: four workgroups per CU
 
-// BGBIT > 0: gadget base known at compile time (digit extraction becomes one bit-field extract); 0: run time
+// BGBIT > 0: gadget base known at compile time (digit extraction becomes one bit-field extract); 0: run time.
+// Register budget (hipcc 7.2, -Rpass-analysis=kernel-resource-usage): <2,10> 250 VGPRs, <3,7> 256, <1> 162, <2> 254, <3> 256,
+// none of them spills.  Gadget length 4 (no default parameter set uses it) is a SLOW CORRECTNESS PATH: four live spectra
+// exceed the 256 registers of a wave at two waves per SIMD, its kernel spills (324 VGPRs to scratch) and runs several
+// times slower per transform; it is bit-exact (tests/test_gpu_parity.py) and nothing else is claimed for it.
 template <int L, int BGBIT = 0>
 __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__restrict__ g_tw,
                                                          const d2 *__restrict__ g_twist)
@@ -766,10 +659,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     d2 *scr_partner = s_scr_all + (h ^ 1) * kScr;
     int32_t *ext = reinterpret_cast<int32_t *>(scr); // [2N] signed periodic image of ACC_h (between steps)
 
-    // bit 0: gadget lengths 1 and 2, bit 1: length 3; length 4 (no default set uses it) keeps the accumulator image,
-    // its kernel is over the register budget either way
-    constexpr bool kXbar = L <= 3 && (EOC_ROT_XBAR & (L == 3 ? 2 : 1)) != 0;
-    constexpr bool kHoist = kXbar && (EOC_ROT_XBAR & 4) != 0;        // bit 2: first key rows requested ahead of the switch
     const uint32_t job = blockIdx.x; // grid = number of jobs
     // the rotation amounts of this job are wave-uniform and constant during the kernel: read as dwords through the
     // constant address space (rows are 16-byte aligned: bara_stride is a multiple of 8), i.e. by scalar loads
@@ -795,8 +684,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             v = h ? v : 0;
             if (A.step_begin > 0) v = st[j]; // continue a blind rotation started by an earlier launch
             racc[r] = (uint32_t)v;
-            ext[j] = v;
-            ext[j + kN] = -v;
         }
     }
     __syncthreads();
@@ -807,11 +694,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #pragma unroll
     for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
     constexpr int KPL = 2 * L;
-    const d2 *bk = reinterpret_cast<const d2 *>(A.bkfft);
-#if EOC_BK_BUFFER
     const __amdgpu_buffer_rsrc_t bk_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.bkfft), 0, (int)((size_t)A.n * KPL * 2 * kNH * 16), 0x00020000);
-#endif
     // digits arrive biased, u = digit + Bg/2 in [0, Bg); as_double(2^52 | u) - (2^52 + Bg/2) is the digit, exactly;
     // the stage-0 sums p - q and p + q are formed on the biased integers and converted the same way
     const double bias1 = 4503599627370496.0 + (double)halfBg, bias2 = 4503599627370496.0 + (double)Bg;
@@ -823,20 +707,17 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     st_acc[14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID: CU / SE / SIMD / wave slot
     st_acc[13] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
 #endif
-#if EOC_PRIO_ALT
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
-#endif
     // gadget length 2 has registers to spare: the forward transform's last four twiddles stay resident
-    constexpr bool kResT2 = EOC_RES_T2 && L == 2;
+    constexpr bool kResT2 = L == 2;
     d2 res_t2[4];
     if constexpr (kResT2) tw_load(res_t2, s_tw + kTwF2 + lane, 64);
-    constexpr bool kResT1 = EOC_RES_T1 && L == 2; // ... and the inverse transform's first table pass
+    constexpr bool kResT1 = L == 2; // ... and the inverse transform's first table pass
     d2 res_t1[4];
     if constexpr (kResT1) tw_load(res_t1, s_tw + kTwI1 + (lane & 7), 8);
     int abar_next = load_abar(A.step_begin);
     for (int i = A.step_begin; i < A.step_end; i++) {
         EOC_STAMP(15);
-#if EOC_PRIO_ALT
         // The two waves that share a SIMD belong to different workgroups, and the issue arbiter favours the older
         // one: in a launch that exactly fills the chip (1024 gates = 512 workgroups) the first half of the grid
         // finishes at 0.82x and the second half at 1.19x of the mean, and the launch lasts as long as its slowest
@@ -845,10 +726,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         // rest.  12/16 makes both halves finish together (-10 % on the launch).  Launches of several rounds are
         // faster WITHOUT it (the arbiter's run-to-completion bias suits them: +4 %), so the host passes a
         // negative duty there.
-        if (A.prio_duty >= 0 && (i & (EOC_PRIO_ALT - 1)) == 0) {
-            const bool first_part = ((i / EOC_PRIO_ALT) & 15) < A.prio_duty;
+        if (A.prio_duty >= 0) {
+            const bool first_part = (i & 15) < A.prio_duty;
             if (first_part == ((prio_slot & 1) != 0))
-                __builtin_amdgcn_s_setprio(EOC_PRIO_HI);
+                __builtin_amdgcn_s_setprio(1);
             else
                 __builtin_amdgcn_s_setprio(0);
         } else if (A.prio_duty <= -2) {
@@ -856,43 +737,25 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             // from the shader clock both of them read (phase length 2^(-prio_duty) cycles), even shares
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             if ((int)((now >> (-A.prio_duty)) & 1) == (prio_slot & 1))
-                __builtin_amdgcn_s_setprio(EOC_PRIO_HI);
+                __builtin_amdgcn_s_setprio(1);
             else
                 __builtin_amdgcn_s_setprio(0);
         }
-#endif
         const int abar = __builtin_amdgcn_readfirstlane(abar_next);
         abar_next = load_abar(i + 1); // one step ahead (entry n is barb: always in bounds); retires with the key rows
         // (X^abar - 1) * ACC_h.  abar == 0 gives an all-zero polynomial, all-zero digits and an exact
         // zero update, which is what skipping the step (as libtfhe does) amounts to.
-        const d2 *rows_i = bk + ((size_t)i * KPL + h * L) * 2 * kNH; // rows (h, p), p = 1..L
+        // rows (h, p), p = 1..L, of BK_i by buffer loads: the row's byte offset is wave-uniform (SGPR), the lane part one
+        // loop-invariant VGPR
         auto load_row = [&](int p, int c, d2 (&b)[8]) __attribute__((always_inline)) {
-            const d2 *src = rows_i + ((size_t)(p - 1) * 2 + c) * kNH;
-#if EOC_BK_BUFFER
-            // buffer loads: the row's byte offset is wave-uniform (SGPR), the lane part one loop-invariant VGPR
             const uint32_t row_off = (uint32_t)((((size_t)i * KPL + h * L) * 2 + (size_t)(p - 1) * 2 + c) * kNH * 16);
-#endif
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-#ifdef EOC_ABL_NOBK
-                b[r] = s_twist[(r * 64 + lane) ^ c];
-                (void)src;
-#elif EOC_BK_BUFFER
-                (void)src;
+            for (int r = 0; r < 8; r++)
                 b[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane * 16, (int)(row_off + r * 1024), 0));
-#else
-                b[r] = src[r * 64 + lane];
-#endif
-            }
         };
         d2 ra[8], rb[8];
-        if constexpr (kHoist) {
-            // the digit block below is a 32-way switch (basic-block boundaries): the first key rows are requested ahead of it
-            load_row(1, 1 - h, ra);
-            if constexpr (L >= 2) load_row(2, 1 - h, rb);
-        }
         uint32_t dlo[8], dhi[8];
-        if constexpr (kXbar) {
+        {
             const int s = abar & 63;
             const int src = ((lane - s) & 63) << 2;
             uint32_t t[16], d[16];
@@ -912,15 +775,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             for (int r = 0; r < 8; r++) {
                 dlo[r] = d[r];
                 dhi[r] = d[8 + r];
-            }
-        } else {
-            const int k = (lane - abar) & (2 * kN - 1);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t v0 = (uint32_t)ext[(k + 64 * r) & (2 * kN - 1)];
-                const uint32_t v1 = (uint32_t)ext[(k + 64 * r + kNH) & (2 * kN - 1)];
-                dlo[r] = v0 - racc[r] + offset;
-                dhi[r] = v1 - racc[8 + r] + offset;
             }
         }
         EOC_STAMP(0);
@@ -956,10 +810,8 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         d2 xs[L][8], S[8];
 #pragma unroll
         for (int p0 = 0; p0 + 1 < L; p0 += 2) {
-            if (!kHoist || p0 > 0) {
-                load_row(p0 + 1, 1 - h, ra);
-                load_row(p0 + 2, 1 - h, rb);
-            }
+            load_row(p0 + 1, 1 - h, ra);
+            load_row(p0 + 2, 1 - h, rb);
             make_x0(p0 + 1, xs[p0]);
             EOC_STAMP(1);
             fft_fwd_rest_x2(xs[p0], xs[p0 + 1], [&]() __attribute__((always_inline)) { make_x0(p0 + 2, xs[p0 + 1]); },
@@ -970,7 +822,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             EOC_STAMP(3);
         }
         if constexpr ((L & 1) != 0) {
-            if (!kHoist || L > 1) load_row(L, 1 - h, ra);
+            load_row(L, 1 - h, ra);
             make_x0(L, xs[L - 1]);
             EOC_STAMP(1);
             fft_fwd_rest(xs[L - 1], s_tw, scr, lane);
@@ -985,7 +837,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 #pragma unroll
         for (int r = 0; r < 8; r++) scr[r * 64 + lane] = S[r];
         EOC_STAMP(4);
-        EOC_SYNC();
+        __syncthreads();
         EOC_STAMP(5);
 #pragma unroll
         for (int r = 0; r < 8; r++) S[r] = scr_partner[r * 64 + lane]; // the chain of the other input polynomial
@@ -996,28 +848,21 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         if constexpr (L >= 3) mac(false, xs[2], ra, S);
         if constexpr (L >= 4) mac(false, xs[3], rb, S);
         EOC_STAMP(6);
-        EOC_SYNC(); // the partner has read this wave's scratch before the inverse transform overwrites it
+        __syncthreads(); // the partner has read this wave's scratch before the inverse transform overwrites it
         EOC_STAMP(7);
         d2 ut[8];
         fft_inv_wave(S, ut, s_tw, s_twist, scr, lane, kResT1 ? &res_t1 : nullptr);
         EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            int j = lane + 64 * r;
             d2 y = cmulc(S[r], ut[r]); // 1/512 is in the key image
             racc[r] += wrap_trunc(y.x);
             racc[8 + r] += wrap_trunc(y.y);
-            if constexpr (!kXbar) {
-                ext[j] = (int32_t)racc[r];
-                ext[j + kN] = (int32_t)(0u - racc[r]);
-                ext[j + kNH] = (int32_t)racc[8 + r];
-                ext[j + kNH + kN] = (int32_t)(0u - racc[8 + r]);
-            }
         }
         wave_lds_fence();
         EOC_STAMP(9);
     }
-    if (kXbar && A.step_end >= A.n) { // the sample extraction below reads the image: written once, after the last step
+    if (A.step_end >= A.n) { // the sample extraction below reads the image: written once, after the last step
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int j = lane + 64 * r;
