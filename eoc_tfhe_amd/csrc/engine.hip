@@ -41,10 +41,10 @@ struct eoc_engine {
     bool own_keys = false;
     const double *bkfft = nullptr; // in use (owned or adopted)
     const int32_t *ksk = nullptr;
-    // workspaces: two independent sets, so that two chunks of one host-buffer call can be in flight on two streams
-    // (set 0 serves the device-pointer API).  Each set owns device buffers AND a pinned host ring for the gate
-    // descriptors / opcode permutations that every launch sends ahead of its kernels: nothing on the launch path reads
-    // pageable memory asynchronously, allocates or synchronises once the sets have their size (eoc_engine_reserve).
+    // workspace: device buffers AND a pinned host ring for the gate descriptors / opcode permutations that every launch
+    // sends ahead of its kernels: nothing on the launch path reads pageable memory asynchronously, allocates or
+    // synchronises once the workspace has its size (eoc_engine_reserve).  One set per engine: all kernels of an engine
+    // run on one stream at a time (the host-buffer path's chunks share the kernel stream, multi.hip).
     struct Workspace {
         uint16_t *d_bara = nullptr;
         int32_t *d_u = nullptr;
@@ -62,7 +62,7 @@ struct eoc_engine {
         uint32_t *h_perm = nullptr; // pinned
         hipEvent_t perm_ev = nullptr; // the last copy out of h_perm (awaited before h_perm is rewritten)
         size_t ws_mixed = 0;
-    } ws[2];
+    } ws;
     unsigned long long *d_stamps = nullptr; // diagnostic build (-DEOC_STAMPS) only
     int num_cus = 256;
     int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
@@ -268,8 +268,7 @@ extern "C" void eoc_engine_destroy(eoc_engine *e)
         hipFree(e->d_bkfft);
         hipFree(e->d_ksk);
     }
-    free_ws(e->ws[0]);
-    free_ws(e->ws[1]);
+    free_ws(e->ws);
     hipFree(e->d_stamps);
     delete e;
 }
@@ -277,10 +276,25 @@ extern "C" void eoc_engine_destroy(eoc_engine *e)
 // Grow a workspace set (outside the kernels: the device is synchronised and buffers are re-allocated; callers that
 // must not stall or want hipGraph capture size the sets once with eoc_engine_reserve).  jobs = blind rotations of the
 // widest level, descs = gate descriptors in flight between two wrap-arounds of the ring, mixed = rows of a mixed batch.
-static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_t descs, size_t mixed)
+static bool stream_is_capturing(hipStream_t st)
 {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+}
+
+static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_t descs, size_t mixed, hipStream_t st = nullptr)
+{
+    if (jobs <= W.ws_jobs && descs <= W.ws_descs && mixed <= W.ws_mixed) return EOC_OK;
+    // growing frees and re-allocates buffers that captured nodes may refer to, and nothing may be allocated while a
+    // stream captures: a capture needs eoc_engine_reserve first
+    if (stream_is_capturing(st)) {
+        eoc_set_error("graph capture: the workspace would have to grow (jobs %zu > %zu, descriptors %zu > %zu or mixed rows "
+                      "%zu > %zu); call eoc_engine_reserve with the sizes of the captured work before capturing",
+                      jobs, W.ws_jobs, descs, W.ws_descs, mixed, W.ws_mixed);
+        return EOC_ERR_STATE;
+    }
+    HIP_TRY(hipDeviceSynchronize()); // nothing in flight may still use the buffers that are about to be replaced
     if (jobs > W.ws_jobs) {
-        hipDeviceSynchronize();
         hipFree(W.d_bara);
         hipFree(W.d_u);
         hipFree(W.d_ubarT);
@@ -298,7 +312,6 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         e->ws_grows++;
     }
     if (descs > W.ws_descs) {
-        hipDeviceSynchronize();
         hipFree(W.d_descs);
         if (W.h_descs) hipHostFree(W.h_descs);
         W.d_descs = W.h_descs = nullptr;
@@ -320,7 +333,6 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         e->ws_grows++;
     }
     if (mixed > W.ws_mixed) {
-        hipDeviceSynchronize();
         hipFree(W.d_mixed);
         if (W.h_perm) hipHostFree(W.h_perm);
         W.d_mixed = nullptr;
@@ -341,10 +353,8 @@ extern "C" int eoc_engine_reserve(eoc_engine *e, size_t max_jobs, size_t max_des
     if (!e) return EOC_ERR_ARG;
     std::lock_guard<std::mutex> g(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    for (int k = 0; k < 2; k++) {
-        int rc = ensure_ws(e, e->ws[k], max_jobs, max_descs, k == 0 ? max_mixed_rows : 0);
-        if (rc) return rc;
-    }
+    int rc = ensure_ws(e, e->ws, max_jobs, max_descs, max_mixed_rows);
+    if (rc) return rc;
     e->ws_grows = 0;
     return EOC_OK;
 }
@@ -640,8 +650,7 @@ constexpr size_t kMaxGatesPerLaunch = 32768;
 // copy that reads it may still be in flight (sized by ensure_ws for everything a call sends, the wrap is rare).
 static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, GateDesc **d_out)
 {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (st && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+    if (stream_is_capturing(st)) {
         if (W.persist_pos + count > W.persist_cap) {
             eoc_set_error("graph capture: descriptor arena exhausted (%zu of %zu used, %zu wanted); "
                           "eoc_engine_reserve a larger max_descs before capturing", W.persist_pos, W.persist_cap, count);
@@ -742,7 +751,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         }
         GateDesc d{op, 0, d_in0, d_in1, d_in2, d_out};
         (op_free(op) ? freeg : boot).push_back(d);
-        int rc = ensure_ws(e, W, count * (op == OP_MUX ? 2 : 1), 64, 0);
+        int rc = ensure_ws(e, W, count * (op == OP_MUX ? 2 : 1), 64, 0, st);
         if (rc) return rc;
         return run_level(e, W, boot, freeg, count, st);
     }
@@ -777,13 +786,32 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         if (gather)
             for (int o = 0; o <= OP_CONST1; o++) max_jobs = std::max(max_jobs, cnt_op[o] * (o == OP_MUX ? 2 : 1));
     }
-    int rc = ensure_ws(e, W, max_jobs, 2 * (gather ? OP_CONST1 + 1 : runs) + 64, gather ? count : 0);
+    int rc = ensure_ws(e, W, max_jobs, 2 * (gather ? OP_CONST1 + 1 : runs) + 64, gather ? count : 0, st);
     if (rc) return rc;
+    uint32_t *d_perm = nullptr;
     if (gather) {
         // stable counting sort by opcode on the host (the opcode array is a host array); the permutation goes through
         // the workspace's pinned buffer, so nothing here waits for the device
         uint32_t *perm = W.h_perm;
-        HIP_TRY(hipEventSynchronize(W.perm_ev)); // the previous mixed batch's copy out of h_perm (long done, normally)
+        d_perm = reinterpret_cast<uint32_t *>(W.d_mixed + 4 * W.ws_mixed * stride);
+        const bool capturing = stream_is_capturing(st);
+        if (capturing) {
+            // A captured copy node reads its pinned source again at every replay, and h_perm is rewritten by the next
+            // mixed batch: the permutation of a captured batch lives in the never-re-used capture arena instead (host and
+            // device side), and perm_ev -- which would become a captured event -- is left alone.
+            const size_t slots = (count * sizeof(uint32_t) + sizeof(GateDesc) - 1) / sizeof(GateDesc);
+            if (W.persist_pos + slots > W.persist_cap) {
+                eoc_set_error("graph capture: descriptor arena exhausted by a mixed batch's permutation (%zu of %zu slots "
+                              "used, %zu wanted); eoc_engine_reserve a larger max_descs before capturing",
+                              W.persist_pos, W.persist_cap, slots);
+                return EOC_ERR_STATE;
+            }
+            perm = reinterpret_cast<uint32_t *>(W.h_persist + W.persist_pos);
+            d_perm = reinterpret_cast<uint32_t *>(W.d_persist + W.persist_pos);
+            W.persist_pos += slots;
+        } else {
+            HIP_TRY(hipEventSynchronize(W.perm_ev)); // the previous mixed batch's copy out of h_perm (long done, normally)
+        }
         size_t bucket[OP_CONST1 + 2] = {0};
         for (size_t k = 0; k < count; k++) bucket[ops[k] + 1]++;
         for (int o = 1; o < OP_CONST1 + 2; o++) bucket[o] += bucket[o - 1];
@@ -794,9 +822,8 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
             sorted_ops[pos] = ops[k];
         }
         int32_t *g0 = W.d_mixed, *g1 = g0 + count * stride, *g2 = g1 + count * stride, *go = g2 + count * stride;
-        uint32_t *d_perm = reinterpret_cast<uint32_t *>(W.d_mixed + 4 * W.ws_mixed * stride);
         HIP_TRY(hipMemcpyAsync(d_perm, perm, count * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipEventRecord(W.perm_ev, st));
+        if (!capturing) HIP_TRY(hipEventRecord(W.perm_ev, st));
         dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
         if (d_in0) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in0, g0, d_perm, (int)stride, 0);
         if (d_in1) hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, d_in1, g1, d_perm, (int)stride, 0);
@@ -823,7 +850,6 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         i = j;
     }
     if (gather) {
-        const uint32_t *d_perm = reinterpret_cast<const uint32_t *>(W.d_mixed + 4 * W.ws_mixed * stride);
         dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
         hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, out, d_out, d_perm, (int)stride, 1);
         HIP_TRY(hipGetLastError());
@@ -831,12 +857,11 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
     return EOC_OK;
 }
 
-// ws_index selects the workspace set (0: the public device API; 1: the second chunk stream of the host-buffer path)
-extern "C" int eoc_gate_batch_device_ws(eoc_engine *e, int ws_index, int op, const uint8_t *ops, const int32_t *d_in0,
-                                        const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
-                                        void *hip_stream)
+extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
+                                     const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
+                                     void *hip_stream)
 {
-    if (!e || !d_out || ws_index < 0 || ws_index > 1 || (!d_in0 && !ops && !op_const(op))) {
+    if (!e || !d_out || (!d_in0 && !ops && !op_const(op))) {
         eoc_set_error("eoc_gate_batch_device: null argument");
         return EOC_ERR_ARG;
     }
@@ -847,13 +872,7 @@ extern "C" int eoc_gate_batch_device_ws(eoc_engine *e, int ws_index, int op, con
         return EOC_ERR_NO_KEY;
     }
     HIP_TRY(hipSetDevice(e->device));
-    return gate_batch_ws(e, e->ws[ws_index], op, ops, d_in0, d_in1, d_in2, d_out, count, (hipStream_t)hip_stream);
-}
-extern "C" int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
-                                     const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
-                                     void *hip_stream)
-{
-    return eoc_gate_batch_device_ws(e, 0, op, ops, d_in0, d_in1, d_in2, d_out, count, hip_stream);
+    return gate_batch_ws(e, e->ws, op, ops, d_in0, d_in1, d_in2, d_out, count, (hipStream_t)hip_stream);
 }
 
 // ---- circuits -------------------------------------------------------------------------------
@@ -879,7 +898,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    WS &W = e->ws[0];
+    WS &W = e->ws;
     // levelise: RAW, WAR and WAW hazards on wires
     std::vector<int> wr_level(n_wires, 0), rd_level(n_wires, 0), level(n_gates, 0);
     int nlev = 0;
@@ -927,7 +946,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     // a level wider than the job cap is evaluated in slices (run_level), so the workspace is bounded: 2^20 blind
     // rotations in flight need 9.6 GB of extracted samples and rotation amounts; wider levels gain nothing
     const size_t job_cap = std::max<size_t>(max_gate_jobs, (size_t)1 << 20);
-    int rc = ensure_ws(e, W, std::min(max_jobs, job_cap), n_gates + 64, 0);
+    int rc = ensure_ws(e, W, std::min(max_jobs, job_cap), n_gates + 64, 0, st);
     if (rc) return rc;
     for (int lv = 1; lv <= nlev; lv++) {
         rc = run_level(e, W, boot[lv], freeg[lv], instances, st);
@@ -946,8 +965,8 @@ extern "C" int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_
     if (!e->bkfft) return EOC_ERR_NO_KEY;
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    WS &W = e->ws[0];
-    int rc = ensure_ws(e, W, count, 64, 0);
+    WS &W = e->ws;
+    int rc = ensure_ws(e, W, count, 64, 0, st);
     if (rc) return rc;
     GateDesc d{OP_RAW, 0, d_t, nullptr, nullptr, nullptr}, *dd = nullptr;
     rc = push_descs(W, &d, 1, st, &dd);
@@ -970,8 +989,8 @@ extern "C" int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *
     if (!e->ksk) return EOC_ERR_NO_KEY;
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
-    WS &W = e->ws[0];
-    int rc = ensure_ws(e, W, count, 64, 0);
+    WS &W = e->ws;
+    int rc = ensure_ws(e, W, count, 64, 0, st);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(W.d_u, d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
     GateDesc d{OP_RAW, 0, nullptr, nullptr, nullptr, d_out}, *dd = nullptr;

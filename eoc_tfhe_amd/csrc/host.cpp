@@ -339,7 +339,7 @@ extern "C" int eoc_keygen_secure(const eoc_params *p, int with_cloud_key, eoc_se
         return EOC_ERR_STATE;
     }
     int rc = keygen_common(p, 0, master, with_cloud_key, out);
-    memset(master, 0, sizeof master);
+    explicit_bzero(master, sizeof master);
     return rc;
 }
 // the same from a caller-supplied 256-bit master key (key import; known-answer tests)
@@ -349,7 +349,21 @@ extern "C" int eoc_keygen_from_master(const eoc_params *p, const uint8_t master[
     return keygen_common(p, 0, master, with_cloud_key, out);
 }
 extern "C" int eoc_sk_is_secure(const eoc_secret_key *sk) { return sk && sk->secure ? 1 : 0; }
-extern "C" void eoc_secret_key_free(eoc_secret_key *sk) { delete sk; }
+namespace eoc_host {
+void wipe_secret_key(eoc_secret_key *sk)
+{
+    if (!sk) return;
+    explicit_bzero(sk->master, sizeof sk->master);
+    explicit_bzero(&sk->seed, sizeof sk->seed);
+    if (!sk->lwe.empty()) explicit_bzero(sk->lwe.data(), sk->lwe.size() * sizeof(int32_t));
+    if (!sk->tlwe.empty()) explicit_bzero(sk->tlwe.data(), sk->tlwe.size() * sizeof(int32_t));
+}
+} // namespace eoc_host
+extern "C" void eoc_secret_key_free(eoc_secret_key *sk)
+{
+    eoc_host::wipe_secret_key(sk); // the secret bits do not outlive the object in freed heap memory
+    delete sk;
+}
 extern "C" const eoc_params *eoc_sk_params(const eoc_secret_key *sk) { return sk ? &sk->p : nullptr; }
 extern "C" const int32_t *eoc_sk_lwe_key(const eoc_secret_key *sk) { return sk ? sk->lwe.data() : nullptr; }
 extern "C" const int32_t *eoc_sk_tlwe_key(const eoc_secret_key *sk) { return sk ? sk->tlwe.data() : nullptr; }
@@ -368,12 +382,18 @@ void lwe_encrypt_secure(const eoc_secret_key *sk, const uint8_t enc_key[32], uin
 {
     lwe_encrypt(sk->p.n, sk->lwe.data(), Stream(enc_key, Stream::Enc, idx), uint32_t(mu), sigma, ct);
 }
-void arm_secure_encryption_locked()
+bool arm_secure_encryption_locked()
 {
     GlobalCtx &c = ctx();
-    c.enc_secure = os_random(c.enc_key, sizeof c.enc_key);
-    if (!c.enc_secure) fprintf(stderr, "eoc-tfhe: WARNING: no entropy source, encryption falls back to seeded test streams\n");
+    const char *deny = getenv("EOC_TFHE_TEST_NO_ENTROPY"); // fault injection for tests/test_host_cpu.py
+    c.enc_secure = !(deny && *deny == '1') && os_random(c.enc_key, sizeof c.enc_key);
     c.enc_counter = 0;
+    if (!c.enc_secure) {
+        explicit_bzero(c.enc_key, sizeof c.enc_key);
+        fprintf(stderr, "eoc-tfhe: no entropy source (getrandom and /dev/urandom both failed): refusing to install a "
+                        "secure key that would encrypt with predictable randomness\n");
+    }
+    return c.enc_secure;
 }
 } // namespace eoc_host
 // bootsSymEncrypt with ChaCha20 randomness under a caller-held 256-bit key: sample s uses stream (enc_key, first_idx + s)
@@ -541,9 +561,10 @@ extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
     c.enc_seed = mix64(seed ^ 0xA5A5A5A5DEADBEEFull);
     c.enc_counter = 0;
     c.enc_secure = false;
-    if (seed == 0) arm_secure_encryption_locked();
     c.engine_ready = false;
-    if (ensure_engine_locked()) { // the gate key is useless without the engine: fail loudly
+    // secure keys fail closed when the encryption randomness cannot be drawn; the gate key is useless without the
+    // engine: fail loudly there too
+    if ((seed == 0 && !arm_secure_encryption_locked()) || ensure_engine_locked()) {
         eoc_secret_key_free(sk);
         c.sk = nullptr;
         return nullptr;
@@ -559,6 +580,9 @@ extern "C" void resetGateKey(void)
     std::lock_guard<std::mutex> g(c.mu);
     eoc_secret_key_free(c.sk);
     c.sk = nullptr;
+    explicit_bzero(c.enc_key, sizeof c.enc_key);
+    c.enc_secure = false;
+    c.enc_seed = c.enc_counter = 0;
     c.engine_ready = false;
     eoc_gpu_shutdown();
 }

@@ -41,7 +41,11 @@ GlobalCtx &ctx();
 bool os_random(void *buf, size_t len);  // getrandom(2), /dev/urandom as a fallback; false if neither works
 // one LWE sample with ChaCha20 randomness: stream (enc_key, idx)
 void lwe_encrypt_secure(const eoc_secret_key *sk, const uint8_t enc_key[32], uint64_t idx, int32_t mu, double sigma, int32_t *ct);
-void arm_secure_encryption_locked();    // draws ctx().enc_key, resets the counter (caller holds ctx().mu)
+// draws ctx().enc_key from the OS and resets the counter (caller holds ctx().mu).  FAILS CLOSED: false means no entropy
+// source answered; the caller must then drop the key it was about to install -- a secure key never encrypts with the
+// seeded test streams
+bool arm_secure_encryption_locked();
+void wipe_secret_key(eoc_secret_key *sk); // explicit_bzero over the master key and the key bits
 int ensure_engine_locked(); // caller holds ctx().mu
 
 } // namespace eoc_host

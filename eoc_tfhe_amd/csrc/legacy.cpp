@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <array>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -31,35 +32,40 @@ const int kMinimumLambda = 128;                         // eoc-tfhe-run.cpp:34
 const int32_t kMsize = int32_t((1LL << 31) - 1);        // :35
 const double kAlpha = 1.0 / (10.0 * double(kMsize));    // :36
 
-// validateJWT (eoc-tfhe-run.cpp:94-133): non-empty, one dot not at either end, both sides made of
-// base64url characters.  (Everything after the FIRST dot is the "payload", so a real three-segment
-// JWT fails on its second dot -- the reference's own fixture has two segments, tests/tfhe.test.js:28-34.)
+// The reference's JWT check (eoc-tfhe-run.cpp:94-133) is a shape test, not a signature check: the token must be
+// `head.tail` with both parts non-empty and drawn from the base64url alphabet (plus '=').  Everything after the FIRST
+// dot counts as the tail, so a real three-segment JWT is rejected at its second dot -- the reference's own fixture has
+// two segments (tests/tfhe.test.js:28-34).  Same accept/reject set here, as one scan over the bytes.  Deliberate
+// difference: the reference prints the whole credential to stdout before checking it (eoc-tfhe-run.cpp:96); this
+// library logs only its length and the reason of a rejection (INTEGRATION.md, quirk list).
 bool validate_jwt(const char *token, const char *)
 {
     if (!token) return false;
-    std::string t(token);
-    std::cout << "Validating JWT token...:" << t << std::endl;
-    if (t.empty()) {
-        std::cout << "JWT validation failed: Empty token" << std::endl;
+    static const auto url_safe = [] {
+        std::array<bool, 256> ok{};
+        for (int c = 'A'; c <= 'Z'; c++) ok[c] = true;
+        for (int c = 'a'; c <= 'z'; c++) ok[c] = true;
+        for (int c = '0'; c <= '9'; c++) ok[c] = true;
+        ok[(unsigned char)'-'] = ok[(unsigned char)'_'] = ok[(unsigned char)'='] = true;
+        return ok;
+    }();
+    size_t len = 0, head = 0, tail = 0;
+    bool seen_dot = false;
+    const char *why = nullptr;
+    for (const unsigned char *q = reinterpret_cast<const unsigned char *>(token); *q && !why; q++, len++) {
+        if (*q == '.' && !seen_dot) seen_dot = true;
+        else if (!url_safe[*q]) why = seen_dot ? "second part is not base64url" : "first part is not base64url";
+        else (seen_dot ? tail : head)++;
+    }
+    if (!why) {
+        if (len == 0) why = "token is empty";
+        else if (!seen_dot || head == 0 || tail == 0) why = "expected two non-empty parts separated by a dot";
+    }
+    if (why) {
+        std::cout << "JWT shape check: rejected (" << why << ")" << std::endl;
         return false;
     }
-    size_t dot = t.find('.');
-    if (dot == std::string::npos || dot == 0 || dot == t.size() - 1) {
-        std::cout << "JWT validation failed: Missing or invalid dot separator" << std::endl;
-        return false;
-    }
-    auto b64url = [](const std::string &s) {
-        return !s.empty() &&
-               s.find_first_not_of("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_=") == std::string::npos;
-    };
-    if (!b64url(t.substr(0, dot))) {
-        std::cout << "JWT validation failed: Invalid header encoding" << std::endl;
-        return false;
-    }
-    if (!b64url(t.substr(dot + 1))) {
-        std::cout << "JWT validation failed: Invalid payload encoding" << std::endl;
-        return false;
-    }
+    std::cout << "JWT shape check: accepted (" << len << " bytes, content not logged)" << std::endl;
     return true;
 }
 
@@ -275,7 +281,11 @@ extern "C" int importSecretKey(const char *base64Key)
     c.enc_secure = false;
     // a secure (EOCSK2) key encrypts with fresh per-process randomness, independent of the key material; a seeded
     // (EOCSK1, test-mode) key keeps its seeded streams so that test vectors stay reproducible
-    if (sk->secure) arm_secure_encryption_locked();
+    if (sk->secure && !arm_secure_encryption_locked()) { // fail closed: never downgrade a secure key to the test streams
+        eoc_secret_key_free(sk);
+        c.sk = nullptr;
+        return -1;
+    }
     c.engine_ready = false;
     return 0;
 }
@@ -340,7 +350,11 @@ extern "C" const char *generateSecretKey(const char *jwtToken, const char *jwksB
     c.enc_seed = mix64(seed ^ 0xA5A5A5A5DEADBEEFull);
     c.enc_counter = 0;
     c.enc_secure = false;
-    if (!test_seed) arm_secure_encryption_locked();
+    if (!test_seed && !arm_secure_encryption_locked()) { // fail closed (see host_internal.h)
+        eoc_secret_key_free(sk);
+        c.sk = nullptr;
+        return nullptr;
+    }
     c.engine_ready = false; // the GPU engine comes up on the first gate call, if there ever is one
     std::vector<unsigned char> blob(eoc_secret_key_export(sk, nullptr, 0));
     eoc_secret_key_export(sk, blob.data(), blob.size());

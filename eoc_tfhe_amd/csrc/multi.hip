@@ -28,10 +28,6 @@
 #include <thread>
 #include <vector>
 
-extern "C" int eoc_gate_batch_device_ws(eoc_engine *e, int ws_index, int op, const uint8_t *ops, const int32_t *d_in0,
-                                        const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, size_t count,
-                                        void *hip_stream);
-
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \
@@ -164,31 +160,45 @@ int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, con
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             s.ev.push_back(e);
         }
+        // An error anywhere in the pipeline must not leave copies into (or out of) the caller's buffers in flight after
+        // the call has returned, nor kernels that still use d_io: every exit drains the three streams first.
+        auto drain = [&](int code) {
+            for (int k = 0; k < 3; k++) (void)hipStreamSynchronize(s.st[k]);
+            return code;
+        };
+#define PIPE_TRY(expr)                                                                                        \
+        do {                                                                                                  \
+            hipError_t _e = (expr);                                                                           \
+            if (_e != hipSuccess) {                                                                           \
+                eoc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);    \
+                return drain(EOC_ERR_HIP);                                                                    \
+            }                                                                                                 \
+        } while (0)
         for (size_t c = 0; c < nchunks; c++) { // operands of every chunk, queued back to back on the H2D stream
             size_t lo, hi;
             shard_range(count, (int)c, (int)nchunks, &lo, &hi);
             for (int k = 0; k < 3; k++)
                 if (h[k])
-                    HIP_TRY(hipMemcpyAsync(s.d_io[k] + lo * stride_ints, h[k] + lo * stride_ints, (hi - lo) * row_bytes,
-                                           hipMemcpyHostToDevice, s.st[1]));
-            HIP_TRY(hipEventRecord(s.ev[2 * c], s.st[1]));
+                    PIPE_TRY(hipMemcpyAsync(s.d_io[k] + lo * stride_ints, h[k] + lo * stride_ints, (hi - lo) * row_bytes,
+                                            hipMemcpyHostToDevice, s.st[1]));
+            PIPE_TRY(hipEventRecord(s.ev[2 * c], s.st[1]));
         }
         for (size_t c = 0; c < nchunks; c++) {
             size_t lo, hi;
             shard_range(count, (int)c, (int)nchunks, &lo, &hi);
             const size_t cnt = hi - lo;
-            HIP_TRY(hipStreamWaitEvent(s.st[0], s.ev[2 * c], 0));
-            rc = eoc_gate_batch_device_ws(s.e, 0, op, ops ? ops + lo : nullptr, h[0] ? s.d_io[0] + lo * stride_ints : nullptr,
-                                          h[1] ? s.d_io[1] + lo * stride_ints : nullptr,
-                                          h[2] ? s.d_io[2] + lo * stride_ints : nullptr, s.d_io[3] + lo * stride_ints, cnt, s.st[0]);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(s.ev[2 * c + 1], s.st[0]));
-            HIP_TRY(hipStreamWaitEvent(s.st[2], s.ev[2 * c + 1], 0));
-            HIP_TRY(hipMemcpyAsync(out + lo * stride_ints, s.d_io[3] + lo * stride_ints, cnt * row_bytes,
-                                   hipMemcpyDeviceToHost, s.st[2]));
+            PIPE_TRY(hipStreamWaitEvent(s.st[0], s.ev[2 * c], 0));
+            rc = eoc_gate_batch_device(s.e, op, ops ? ops + lo : nullptr, h[0] ? s.d_io[0] + lo * stride_ints : nullptr,
+                                       h[1] ? s.d_io[1] + lo * stride_ints : nullptr,
+                                       h[2] ? s.d_io[2] + lo * stride_ints : nullptr, s.d_io[3] + lo * stride_ints, cnt, s.st[0]);
+            if (rc) return drain(rc);
+            PIPE_TRY(hipEventRecord(s.ev[2 * c + 1], s.st[0]));
+            PIPE_TRY(hipStreamWaitEvent(s.st[2], s.ev[2 * c + 1], 0));
+            PIPE_TRY(hipMemcpyAsync(out + lo * stride_ints, s.d_io[3] + lo * stride_ints, cnt * row_bytes,
+                                    hipMemcpyDeviceToHost, s.st[2]));
         }
-        HIP_TRY(hipStreamSynchronize(s.st[2]));
-        HIP_TRY(hipStreamSynchronize(s.st[0]));
+#undef PIPE_TRY
+        for (int k = 2; k >= 0; k--) HIP_TRY(hipStreamSynchronize(s.st[k]));
         return EOC_OK;
     }
     hipStream_t st = s.st[0];
@@ -203,8 +213,11 @@ int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, con
         HIP_TRY(hipMemcpyAsync(s.d_io[k], h[k], bytes, hipMemcpyHostToDevice, st));
         d[k] = s.d_io[k];
     }
-    rc = eoc_gate_batch_device_ws(s.e, 0, op, ops, d[0], d[1], d[2], s.d_io[3], count, st);
-    if (rc) return rc;
+    rc = eoc_gate_batch_device(s.e, op, ops, d[0], d[1], d[2], s.d_io[3], count, st);
+    if (rc) {
+        (void)hipStreamSynchronize(st); // no operand copy may outlive the call
+        return rc;
+    }
     if (zero_copy && out_map) {
         const size_t n = count * stride_ints;
         hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st,

@@ -362,3 +362,66 @@ def test_reserved_engine_is_graph_capturable(eoc):
         tot = sum(sk.decrypt_bits(wires[sw[0] + i].cpu().numpy()).astype(np.int64) << i for i in range(4))
         assert np.array_equal(tot, A + B)
     eng.close()
+
+
+def test_mixed_batch_capture_and_replay(eoc):
+    """a mixed batch that takes the gather path (more than 15 opcode runs) is captured with its permutation
+    in the never-re-used arena: a replay after OTHER mixed batches (which rewrite the engine's pinned permutation
+    buffer) still scatters in the captured order, and the next un-captured mixed batch works (perm_ev was not captured).
+    A call that would have to grow the workspace under capture is refused."""
+    torch = torch_cuda()
+    p = eoc.default_params(0)
+    p.n = 36
+    sk = eoc.SecretKey(p, 23)
+    orc = ol.Oracle(0, 23, n_override=36)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    L = eoc.lib()
+    S = 90
+    assert L.eoc_engine_reserve(eng.h, 2 * S, 256, S) == 0
+    rng = np.random.default_rng(8)
+    ops = rng.choice(np.array([0, 4, 10, 11, 2, 13], np.uint8), S)       # ~75 opcode runs: gather path
+    assert (np.diff(ops.astype(int)) != 0).sum() + 1 > 15
+    other = ops[::-1].copy()
+
+    def enc(seed):
+        bits = rng.integers(0, 2, S).astype(np.uint8)
+        return sk.encrypt_bits(bits, seed, 0)
+
+    c = [enc(k) for k in (1, 2, 3)]
+    d = [to_dev(x) for x in c]
+    out = torch.empty_like(d[0])
+    tmp = torch.empty_like(d[0])
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        eng.gate_batch_device(0, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), S, ops=ops, stream=st.cuda_stream)
+    st.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        eng.gate_batch_device(0, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), S, ops=ops, stream=st.cuda_stream)
+    for rnd in range(2):
+        c = [enc(10 * rnd + k) for k in (4, 5, 6)]
+        for k in range(3):
+            d[k].copy_(to_dev(c[k]))
+        # another mixed batch in between rewrites the engine's own permutation buffer and records perm_ev
+        eng.gate_batch_device(0, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), tmp.data_ptr(), S, ops=other)
+        sync()
+        assert np.array_equal(tmp.cpu().numpy(), orc.gate_batch(0, c[0], c[1], c[2], ops=other))
+        out.zero_()
+        g.replay()
+        sync()
+        assert np.array_equal(out.cpu().numpy(), orc.gate_batch(0, c[0], c[1], c[2], ops=ops)), f"replay {rnd}"
+    # growth under capture is refused, loudly, and leaves the engine usable
+    wide = 13 * S                         # 1170 rows: beyond the 1024-job minimum the reserve call allocated
+    big = [to_dev(np.tile(x, (13, 1))) for x in c]
+    bout = torch.empty_like(big[0])
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(eoc.EocError, match="graph capture"):
+        with torch.cuda.graph(g2, stream=st):
+            eng.gate_batch_device(0, big[0].data_ptr(), big[1].data_ptr(), None, bout.data_ptr(), wide, stream=st.cuda_stream)
+    sync()
+    eng.gate_batch_device(0, big[0].data_ptr(), big[1].data_ptr(), None, bout.data_ptr(), wide)
+    sync()
+    assert np.array_equal(bout.cpu().numpy()[:S], orc.gate_batch(0, c[0], c[1]))
+    eng.close()

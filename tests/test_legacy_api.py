@@ -106,6 +106,35 @@ def test_error_conventions(session):
     assert session["pub"] is True and session["key_len"] > 1000
 
 
+def test_jwt_is_never_echoed(session):
+    """the reference prints the whole credential before checking it (eoc-tfhe-run.cpp:96); this library logs the
+    length and the verdict only (INTEGRATION.md quirk list)"""
+    assert TKN not in session["_stdout"] and TKN not in session["_stderr"]
+    assert "JWT shape check: accepted" in session["_stdout"]
+    assert "JWT shape check: rejected" in session["_stdout"]
+
+
+def test_secure_keys_fail_closed_without_entropy(session):
+    """when the OS entropy source does not answer, a secure key must not be installed with the seeded test
+    streams behind it -- generateSecretKey / importSecretKey(EOCSK2) / generateGateKey(seed 0) return NULL / -1 and
+    leave no key behind (EOC_TFHE_TEST_NO_ENTROPY=1 is the fault-injection hook of arm_secure_encryption_locked)"""
+    out, _, stderr = run_child("""
+        import os
+        os.environ['EOC_TFHE_TEST_NO_ENTROPY'] = '1'
+        out['gen'] = Tfhe.generateSecretKey(tkn, jwks)
+        out['enc_after_gen'] = Tfhe.encryptInteger(1, '')
+        out['imp'] = Tfhe.importSecretKey(%r)
+        out['enc_after_imp'] = Tfhe.encryptInteger(1, '')
+        out['gate'] = Tfhe.generateGateKey(80, 0)
+        os.environ['EOC_TFHE_TEST_NO_ENTROPY'] = '0'
+        out['imp_ok'] = Tfhe.importSecretKey(%r)
+        out['rt'] = Tfhe.decryptInteger(Tfhe.encryptInteger(77, ''), '', tkn, jwks)
+    """ % (session["exported"], session["exported"]))
+    assert out == {"gen": None, "enc_after_gen": None, "imp": -1, "enc_after_imp": None, "gate": None,
+                   "imp_ok": 0, "rt": 77}
+    assert "refusing to install a secure key" in stderr
+
+
 def test_secret_key_export_import_across_processes(session):
     """f2: a second process imports the exported key and decrypts what it encrypts; ciphertexts of the first
     process decrypt too (same key)."""
