@@ -140,6 +140,9 @@ def lib():
         "eoc_stats_multi": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
         "eoc_key_broadcast_method": (C.c_char_p, []),
         "eoc_host_path_buffer_grows": (u64, []),
+        "eoc_rccl_origin": (C.c_char_p, []),
+        "eoc_rccl_selftest": (C.c_int, [C.c_int, sz]),
+        "eoc_worker_wakeups": (u64, [C.c_int]),
         "eoc_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
         "eoc_host_alloc": (vp, [sz]),
         "eoc_host_free": (None, [vp]),
@@ -499,7 +502,9 @@ def stats_multi():
         _check(rc, "eoc_stats_multi")
     per = [dict(batches=buf[3 * i], bootstraps=buf[3 * i + 1], keyswitches=buf[3 * i + 2]) for i in range(n)]
     return dict(engines=per, key_broadcast_s=secs.value, key_broadcast_method=lib().eoc_key_broadcast_method().decode(),
-                host_buffer_grows=int(lib().eoc_host_path_buffer_grows()))
+                host_buffer_grows=int(lib().eoc_host_path_buffer_grows()),
+                rccl_origin=lib().eoc_rccl_origin().decode(),
+                worker_wakeups=[int(lib().eoc_worker_wakeups(i)) for i in range(n)])
 
 
 class PinnedArray:

@@ -19,6 +19,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -47,8 +50,64 @@ __global__ __launch_bounds__(256) void k_copy_words(const int32_t *__restrict__ 
 
 namespace {
 
+// One persistent host thread per engine (slots 1..n-1; slot 0's block runs on the calling thread).  A call posts a job
+// to the workers whose blocks are non-empty and waits for them; nobody is woken for an empty block, and no thread is
+// created or joined on the call path (round 2 spawned one std::thread per engine per call, also for the string API's
+// one-gate calls where every block but the first is empty).
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, stop = false;
+    int rc = 0;
+    uint64_t wakeups = 0;
+    void run(int device)
+    {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (stop) return;
+            std::function<int()> j = std::move(job);
+            lk.unlock();
+            const int r = j();
+            lk.lock();
+            rc = r;
+            has_job = false;
+            wakeups++;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            has_job = true;
+        }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !has_job; });
+        return rc;
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct Slot {
     int device = 0;
+    std::unique_ptr<Worker> worker; // null for slot 0 and in single-engine contexts
     eoc_engine *e = nullptr;
     hipStream_t st[3] = {nullptr, nullptr, nullptr}; // [0] kernels, [1] H2D copies, [2] D2H copies
     std::vector<hipEvent_t> ev;                       // chunk hand-offs between the three (grown on demand, re-used)
@@ -261,6 +320,8 @@ int slot_circuit_block(Slot &s, const eoc_gate *gates, size_t n_gates, int32_t *
 
 void destroy_slots_locked()
 {
+    for (auto &s : G.slots)
+        if (s.worker) s.worker->shutdown();
     for (auto &s : G.slots) {
         hipSetDevice(s.device);
         hipDeviceSynchronize();
@@ -280,6 +341,7 @@ void destroy_slots_locked()
 // ---- RCCL, loaded on demand ---------------------------------------------------------------------------------------
 struct Rccl {
     void *lib = nullptr;
+    const char *origin = "not loaded";
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -289,9 +351,23 @@ struct Rccl {
     bool load()
     {
         if (lib) return true;
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
+        static const char *const names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // a process that already maps an RCCL (a torch-hosting harness maps torch/lib/librccl.so) re-uses that copy:
+        // RTLD_NOLOAD returns a handle only if the library is resident, so two RCCLs never share one process
+        for (const char *name : names) {
+            lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (lib) {
+                origin = "already mapped";
+                break;
+            }
+        }
+        if (!lib && dlsym(RTLD_DEFAULT, "ncclCommInitAll")) { // mapped under another path, symbols globally visible
+            lib = dlopen(nullptr, RTLD_NOW);
+            origin = "process symbols";
+        }
+        for (size_t k = 0; !lib && k < sizeof names / sizeof names[0]; k++) {
+            lib = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+            if (lib) origin = names[k];
         }
         if (!lib) return false;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
@@ -316,7 +392,8 @@ int replicate_key_locked(const void *bk0, const void *ksk0, std::vector<void *> 
     bool use_rccl = distinct && n > 1 && !(force && !strcmp(force, "copy"));
     if (use_rccl && !R.load()) {
         if (force && !strcmp(force, "rccl")) {
-            eoc_set_error("EOC_TFHE_KEY_BCAST=rccl but librccl could not be loaded: %s", dlerror());
+            const char *why = dlerror(); // NULL when dlopen succeeded and a dlsym failed
+            eoc_set_error("EOC_TFHE_KEY_BCAST=rccl but librccl could not be loaded: %s", why ? why : "missing symbol");
             return EOC_ERR_STATE;
         }
         use_rccl = false;
@@ -372,18 +449,39 @@ int replicate_key_locked(const void *bk0, const void *ksk0, std::vector<void *> 
     return EOC_OK;
 }
 
-template <class F> int for_each_slot(F fn)
-{ // one host thread per device (inline when there is only one)
+// fn(i, lo, hi) evaluates block [lo, hi) of `total` instances on slot i.  Blocks are eoc_shard_range's; empty blocks wake
+// nobody; the first non-empty block runs on the calling thread (so a call that fits one block -- every one-gate call of
+// the string API -- costs what it costs on a single-engine context), the others on their slots' persistent workers.
+template <class F> int for_each_block(size_t total, F fn)
+{
     const int n = (int)G.slots.size();
-    if (n == 1) return fn(0);
-    std::vector<int> rcs(n, EOC_OK);
-    std::vector<std::thread> th;
-    th.reserve(n);
-    for (int i = 0; i < n; i++) th.emplace_back([&, i] { rcs[i] = fn(i); });
-    for (auto &t : th) t.join();
-    for (int rc : rcs)
-        if (rc) return rc;
-    return EOC_OK;
+    if (n == 1) return fn(0, (size_t)0, total);
+    int first = -1;
+    std::vector<int> posted;
+    for (int i = 0; i < n; i++) {
+        size_t lo, hi;
+        shard_range(total, i, n, &lo, &hi);
+        if (hi == lo) continue;
+        if (first < 0 || !G.slots[i].worker) {
+            if (first < 0) first = i;
+            continue;
+        }
+        G.slots[i].worker->post([fn, i, lo, hi] { return fn(i, lo, hi); });
+        posted.push_back(i);
+    }
+    int rc = EOC_OK;
+    for (int i = 0; i < n; i++) { // inline blocks: the first non-empty one, and any slot without a worker
+        size_t lo, hi;
+        shard_range(total, i, n, &lo, &hi);
+        if (hi == lo || (i != first && G.slots[i].worker)) continue;
+        const int r = fn(i, lo, hi);
+        if (r && !rc) rc = r;
+    }
+    for (int i : posted) {
+        const int r = G.slots[i].worker->wait();
+        if (r && !rc) rc = r;
+    }
+    return rc;
 }
 
 } // namespace
@@ -427,6 +525,13 @@ extern "C" int eoc_gpu_init_multi(const int *devices, int n_devices, const eoc_p
             destroy_slots_locked();
             return rc;
         }
+    }
+    for (int i = 1; i < n_devices; i++) { // slot 0's block always runs on the calling thread
+        Slot &s = G.slots[i];
+        s.worker.reset(new Worker());
+        Worker *w = s.worker.get();
+        const int dev = s.device;
+        w->th = std::thread([w, dev] { w->run(dev); });
     }
     return EOC_OK;
 }
@@ -538,6 +643,73 @@ extern "C" const char *eoc_key_broadcast_method(void)
     copy = G.bcast_method;
     return copy.c_str();
 }
+// how often the persistent worker of engine i (i >= 1) was woken since eoc_gpu_init_multi; 0 for engine 0 (its
+// blocks run on the calling thread).  Lets a test assert that calls whose other blocks are empty wake nobody.
+extern "C" uint64_t eoc_worker_wakeups(int i)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (i < 0 || (size_t)i >= G.slots.size() || !G.slots[i].worker) return 0;
+    std::lock_guard<std::mutex> lk(G.slots[i].worker->m);
+    return G.slots[i].worker->wakeups;
+}
+extern "C" const char *eoc_rccl_origin(void) { return R.origin; }
+
+// One-GPU rehearsal of the library's RCCL call path (every one-GPU test replicates keys by device-to-device copies, so
+// the broadcast branch itself only runs on a multi-GPU node): loads librccl exactly as the key broadcast does, builds a
+// ONE-rank communicator on `device` with ncclCommInitAll and runs a grouped out-of-place ncclBroadcast of `bytes` bytes
+// through the dlopen'ed table, then compares source and destination.  Returns EOC_OK or an error with a message.
+extern "C" int eoc_rccl_selftest(int device, size_t bytes)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (!bytes) bytes = 1 << 20;
+    if (!R.load()) {
+        const char *why = dlerror();
+        eoc_set_error("eoc_rccl_selftest: librccl could not be loaded: %s", why ? why : "missing symbol");
+        return EOC_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    unsigned char *src = nullptr, *dst = nullptr;
+    HIP_TRY(hipMalloc(&src, bytes));
+    if (hipMalloc(&dst, bytes) != hipSuccess) {
+        hipFree(src);
+        eoc_set_error("eoc_rccl_selftest: hipMalloc failed");
+        return EOC_ERR_ALLOC;
+    }
+    std::vector<unsigned char> h(bytes), back(bytes, 0);
+    for (size_t i = 0; i < bytes; i++) h[i] = (unsigned char)((i * 2654435761u) >> 13);
+    int rc = EOC_OK;
+    hipStream_t st = nullptr;
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = ncclSuccess;
+    if (hipMemcpy(src, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dst, 0, bytes) != hipSuccess ||
+        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        eoc_set_error("eoc_rccl_selftest: HIP set-up failed");
+        rc = EOC_ERR_HIP;
+    }
+    if (!rc && (r = R.CommInitAll(&comm, 1, &device)) != ncclSuccess) {
+        eoc_set_error("eoc_rccl_selftest: ncclCommInitAll failed: %s", R.GetErrorString(r));
+        rc = EOC_ERR_HIP;
+    }
+    if (!rc) {
+        R.GroupStart();
+        r = R.Broadcast(src, dst, bytes, ncclChar, 0, comm, st);
+        ncclResult_t r2 = R.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            eoc_set_error("eoc_rccl_selftest: ncclBroadcast failed: %s", R.GetErrorString(r));
+            rc = EOC_ERR_HIP;
+        }
+    }
+    if (!rc && (hipMemcpy(back.data(), dst, bytes, hipMemcpyDeviceToHost) != hipSuccess || back != h)) {
+        eoc_set_error("eoc_rccl_selftest: broadcast result differs from its source");
+        rc = EOC_ERR_STATE;
+    }
+    if (comm) R.CommDestroy(comm);
+    if (st) hipStreamDestroy(st);
+    hipFree(src);
+    hipFree(dst);
+    return rc;
+}
 extern "C" uint64_t eoc_host_path_buffer_grows(void)
 {
     std::lock_guard<std::mutex> g(G.mu);
@@ -567,19 +739,36 @@ extern "C" int eoc_upload_cloud_key_arrays(const int32_t *bk, const int32_t *ksk
         std::vector<void *> dbk(n, nullptr), dksk(n, nullptr);
         dbk[0] = const_cast<void *>(bk0);
         dksk[0] = const_cast<void *>(ksk0);
+        // replicas not yet adopted by their engine are released on every error path
+        auto release_from = [&](int first) {
+            for (int i = std::max(first, 1); i < n; i++) {
+                if (dbk[i]) eoc_device_free(G.slots[i].e, dbk[i]);
+                if (dksk[i]) eoc_device_free(G.slots[i].e, dksk[i]);
+                dbk[i] = dksk[i] = nullptr;
+            }
+        };
         for (int i = 1; i < n; i++) {
             // the engine owns replicas allocated through its own allocator entry points
             rc = eoc_device_alloc(G.slots[i].e, eoc_bkfft_bytes(&G.p), &dbk[i]);
             if (rc == EOC_OK) rc = eoc_device_alloc(G.slots[i].e, eoc_ksk_dev_bytes(&G.p), &dksk[i]);
-            if (rc) return rc;
+            if (rc) {
+                release_from(1);
+                return rc;
+            }
         }
         auto t0 = std::chrono::steady_clock::now();
         rc = replicate_key_locked(bk0, ksk0, dbk, dksk);
         G.bcast_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (rc) return rc;
+        if (rc) {
+            release_from(1);
+            return rc;
+        }
         for (int i = 1; i < n; i++) {
             rc = eoc_engine_adopt_cloud_key_device(G.slots[i].e, dbk[i], dksk[i]);
-            if (rc) return rc;
+            if (rc) {
+                release_from(i);
+                return rc;
+            }
         }
     }
     G.key_loaded = true;
@@ -631,10 +820,7 @@ extern "C" int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, co
     }
     if (!count) return EOC_OK;
     const size_t stride = (size_t)G.p.n + 1;
-    const int world = (int)G.slots.size();
-    return for_each_slot([&](int i) {
-        size_t lo, hi;
-        shard_range(count, i, world, &lo, &hi);
+    return for_each_block(count, [=](int i, size_t lo, size_t hi) {
         return slot_gate_block(G.slots[i], op, ops ? ops + lo : nullptr, in0 ? in0 + lo * stride : nullptr,
                                in1 ? in1 + lo * stride : nullptr, in2 ? in2 + lo * stride : nullptr, out + lo * stride,
                                hi - lo, stride);
@@ -651,11 +837,8 @@ extern "C" int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *w
     if (!gates || !wires) return EOC_ERR_ARG;
     if (!n_gates || !instances) return EOC_OK;
     const size_t stride = (size_t)G.p.n + 1;
-    const int world = (int)G.slots.size();
     // a whole circuit instance stays on one device: no wire ever crosses GPUs
-    return for_each_slot([&](int i) {
-        size_t lo, hi;
-        shard_range(instances, i, world, &lo, &hi);
+    return for_each_block(instances, [=](int i, size_t lo, size_t hi) {
         return slot_circuit_block(G.slots[i], gates, n_gates, wires, n_wires, instances, lo, hi, stride);
     });
 }

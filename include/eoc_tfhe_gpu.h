@@ -262,6 +262,15 @@ int eoc_stats(uint64_t out[3]);                        /* eoc_engine_stats summe
 int eoc_stats_multi(uint64_t *per_device, int cap_devices, double *key_broadcast_seconds);
 const char *eoc_key_broadcast_method(void);            /* "rccl" | "peer-copy" | "none" */
 uint64_t eoc_host_path_buffer_grows(void);             /* growths of the persistent I/O buffers (0 in steady state) */
+/* where the RCCL used by the key broadcast came from: "not loaded" | "already mapped" (the process had one, e.g. a
+ * torch-hosting harness: re-used, never a second copy) | "process symbols" | the name it was dlopen'ed under */
+const char *eoc_rccl_origin(void);
+/* one-GPU rehearsal of the RCCL call path of the key broadcast: one-rank communicator on `device` (ncclCommInitAll), a
+ * grouped out-of-place ncclBroadcast of `bytes` bytes (0 = 1 MiB) through the dlopen'ed table, result compared */
+int eoc_rccl_selftest(int device, size_t bytes);
+/* Engines 1..n-1 each have ONE persistent host thread (engine 0's block runs on the calling thread); a call wakes only
+ * the threads whose block of the call is non-empty.  Wake-ups of engine i's thread since eoc_gpu_init_multi (0 for i = 0) */
+uint64_t eoc_worker_wakeups(int engine_index);
 void eoc_shard_range(size_t total, int rank, int world, size_t *lo, size_t *hi);
 /* pinned host memory for I/O buffers of the batch API (true DMA, chunked overlap); release with eoc_host_free */
 void *eoc_host_alloc(size_t bytes);

@@ -31,6 +31,18 @@ def _enc_planes(sk, bits, seed0):
     return np.stack([sk.encrypt_bits(bits[:, i], seed0 + i, 0) for i in range(bits.shape[1])])
 
 
+def _oracle_netlist(orc, gates, wires):
+    """gate-by-gate evaluation of a netlist by the oracle on host wires [n_wires][S][n+1]"""
+    w = wires.copy()
+    for g in gates:
+        i0 = w[g.in0] if g.in0 >= 0 else np.zeros_like(w[g.out])
+        w[g.out] = orc.gate_batch(g.op, i0, None if g.in1 < 0 else w[g.in1], None if g.in2 < 0 else w[g.in2])
+    return w
+
+
+ORACLE_INSTANCES = 16      # instances of configs 3 and 5 whose EVERY written wire is compared with the oracle
+
+
 def test_config3_adder_4096_pairs(eoc, rig):
     """8-bit ripple-carry add over 4096 input pairs (operands from seed 3, LSB first)."""
     from eoc_tfhe_amd import circuits
@@ -45,6 +57,7 @@ def test_config3_adder_4096_pairs(eoc, rig):
     bbits = ((B[:, None] >> np.arange(8)) & 1).astype(np.uint8)
     wires[aw[0]: aw[0] + 8] = to_dev(_enc_planes(sk, abits, 1000))
     wires[bw[0]: bw[0] + 8] = to_dev(_enc_planes(sk, bbits, 2000))
+    inputs = wires[:, :ORACLE_INSTANCES].cpu().numpy()
     before = eng.stats()["bootstraps"]
     eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
     sync()
@@ -52,6 +65,11 @@ def test_config3_adder_4096_pairs(eoc, rig):
     sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
     total = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
     assert np.array_equal(total, A + B)
+    # ciphertexts vs oracle: every wire the netlist writes, first 16 instances (592 bootstraps)
+    want = _oracle_netlist(ol.Oracle(0, 1), gates, inputs)
+    got = wires[:, :ORACLE_INSTANCES].cpu().numpy()
+    for g in gates:
+        assert np.array_equal(got[g.out], want[g.out]), f"wire {g.out} (op {g.op})"
 
 
 def test_config5_string_equality_1024x32(eoc, rig):
@@ -73,11 +91,17 @@ def test_config5_string_equality_1024x32(eoc, rig):
     wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
     wires[xw[0]: xw[0] + 256] = to_dev(_enc_planes(sk, xb, 3000))
     wires[yw[0]: yw[0] + 256] = to_dev(_enc_planes(sk, yb, 4000))
+    inputs = wires[:, :ORACLE_INSTANCES].cpu().numpy()
     eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
     sync()
     got = sk.decrypt_bits(wires[out].cpu().numpy())
 
     assert np.array_equal(got, (~diff).astype(np.uint8))
+    # ciphertexts vs oracle: every wire of the 511-bootstrap circuit, first 16 pairs (8 equal, 8 different)
+    want = _oracle_netlist(ol.Oracle(0, 1), gates, inputs)
+    gotw = wires[:, :ORACLE_INSTANCES].cpu().numpy()
+    for g in gates:
+        assert np.array_equal(gotw[g.out], want[g.out]), f"wire {g.out} (op {g.op})"
 
 
 def test_config4_mixed_gates_all_eight_shards(eoc, rig):

@@ -92,10 +92,11 @@ def test_circuit_run_instances_stay_on_one_engine(eoc, ctx3):
 
 
 def test_pinned_io_and_steady_state_buffers(eoc, ctx3):
-    """eoc_host_alloc buffers are DMA'd directly (chunks on two streams); a second call of the same size neither grows
-    the persistent I/O buffers nor the engines' workspaces"""
+    """eoc_host_alloc buffers are read in place by the linear stage (512 rows per engine: one un-chunked launch each --
+    the chunked pipeline is test_chunked_host_pipeline's); a second call of the same size neither grows the persistent
+    I/O buffers nor the engines' workspaces"""
     p, sk, orc = ctx3
-    total = 1536                                 # 512 per engine: two chunks each
+    total = 1536                                 # 512 per engine
     rng = np.random.default_rng(5)
     b0, b1 = rng.integers(0, 2, total).astype(np.uint8), rng.integers(0, 2, total).astype(np.uint8)
     pin = [eoc.PinnedArray((total, p.n + 1)) for _ in range(3)]
@@ -171,3 +172,145 @@ def test_concurrent_host_threads_are_serialised(eoc, ctx3):
         b = sk.decrypt_bits(c1[:6].reshape(2, 3, -1)[0]) + 2 * sk.decrypt_bits(c1[:6].reshape(2, 3, -1)[1])
         tot = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(3))
         assert np.array_equal(tot, a.astype(np.int64) + b)
+
+
+def test_chunked_host_pipeline(eoc, monkeypatch):
+    """the chunked host pipeline (nchunks > 1: operand DMA on the H2D stream, all kernels on one stream,
+    results leaving on the D2H stream, 2 x nchunks events) compared with the oracle row for row:
+    2500 pinned rows on ONE engine (3 chunks by size), then EOC_TFHE_HOST_CHUNKS=3 forced on pageable operands and on
+    a mixed batch in arbitrary opcode order (MUX included, so the third operand travels too)."""
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    orc = ol.Oracle(0, 9, n_override=40)
+    eoc.gpu_shutdown()
+    eoc.gpu_init(p, devices=[0])
+    eoc.upload_cloud_key(sk)
+    try:
+        total = 2500
+        rng = np.random.default_rng(15)
+        bits = [rng.integers(0, 2, total).astype(np.uint8) for _ in range(3)]
+        cts = [sk.encrypt_bits(bits[k], 40 + k, 0) for k in range(3)]
+        pin = [eoc.PinnedArray((total, p.n + 1)) for _ in range(4)]
+        for k in range(3):
+            pin[k].array[:] = cts[k]
+        eoc.gate_batch(eoc.OPS["NAND"], pin[0].array, pin[1].array, out=pin[3].array)
+        want = orc.gate_batch(ol.OPS["NAND"], cts[0], cts[1])
+        assert np.array_equal(pin[3].array, want)
+        assert np.array_equal(sk.decrypt_bits(pin[3].array), 1 - (bits[0] & bits[1]))
+        # forced chunking: pageable operands (staged copies) and a mixed batch, ragged chunk sizes (700 = 234 + 233 + 233)
+        monkeypatch.setenv("EOC_TFHE_HOST_CHUNKS", "3")
+        m = 700
+        out = eoc.gate_batch(eoc.OPS["XOR"], cts[0][:m].copy(), cts[1][:m].copy())
+        assert np.array_equal(out, orc.gate_batch(ol.OPS["XOR"], cts[0][:m], cts[1][:m]))
+        ops = rng.choice(np.array([0, 4, 10, 11, 2, 13, 12], np.uint8), m)
+        out = eoc.gate_batch(0, cts[0][:m].copy(), cts[1][:m].copy(), cts[2][:m].copy(), ops=ops)
+        assert np.array_equal(out, orc.gate_batch(0, cts[0][:m], cts[1][:m], cts[2][:m], ops=ops))
+        pin[3].array[:] = 0
+        eoc.gate_batch(0, pin[0].array[:m], pin[1].array[:m], pin[2].array[:m], ops=ops, out=pin[3].array[:m])
+        assert np.array_equal(pin[3].array[:m], out)
+        # an error inside the chunk loop (bad opcode in the LAST chunk) returns with nothing in flight:
+        # the next call on the same buffers is correct
+        bad = ops.copy()
+        bad[-1] = 99
+        with pytest.raises(eoc.EocError):
+            eoc.gate_batch(0, pin[0].array[:m], pin[1].array[:m], pin[2].array[:m], ops=bad, out=pin[3].array[:m])
+        eoc.gate_batch(0, pin[0].array[:m], pin[1].array[:m], pin[2].array[:m], ops=ops, out=pin[3].array[:m])
+        assert np.array_equal(pin[3].array[:m], out)
+        for a in pin:
+            a.free()
+    finally:
+        eoc.gpu_shutdown()
+
+
+def test_one_gate_calls_wake_no_worker(eoc):
+    """engines 1..n-1 have persistent host threads; a call whose other blocks are empty (every
+    one-gate call of the string API) wakes nobody and runs on the calling thread -- it costs what it costs on a
+    single-engine context."""
+    import time
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    c0 = sk.encrypt_bits(np.array([1], np.uint8), 2, 0)
+    c1 = sk.encrypt_bits(np.array([0], np.uint8), 3, 0)
+
+    def median_call_us(devices):
+        eoc.gpu_shutdown()
+        eoc.gpu_init(p, devices=devices)
+        eoc.upload_cloud_key(sk)
+        for _ in range(20):
+            eoc.gate_batch(eoc.OPS["NAND"], c0, c1)
+        ts = []
+        for _ in range(300):
+            t0 = time.perf_counter()
+            eoc.gate_batch(eoc.OPS["NAND"], c0, c1)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e6
+
+    try:
+        t1 = median_call_us([0])
+        t3 = median_call_us([0, 0, 0])
+        st = eoc.stats_multi()
+        assert st["worker_wakeups"] == [0, 0, 0], st
+        assert t3 <= 1.10 * t1 + 5.0, (t1, t3)       # medians of 300 calls; 5 us of slack for timer noise
+        # a call with three non-empty blocks wakes engines 1 and 2 exactly once each
+        c = sk.encrypt_bits(np.ones(11, np.uint8), 4, 0)
+        eoc.gate_batch(eoc.OPS["AND"], c, c)
+        assert eoc.stats_multi()["worker_wakeups"] == [0, 1, 1]
+        # two gates: blocks 1 + 1 + 0 -- engine 2 stays asleep
+        eoc.gate_batch(eoc.OPS["AND"], c[:2], c[:2])
+        assert eoc.stats_multi()["worker_wakeups"] == [0, 2, 1]
+    finally:
+        eoc.gpu_shutdown()
+
+
+def test_rccl_key_broadcast_two_devices(eoc):
+    """the in-library RCCL broadcast (ncclCommInitAll + grouped ncclBroadcast through the dlopen'ed
+    table) on DISTINCT devices.  Needs two visible GPUs -- skipped on the one-GPU boxes this round's builder gets; the
+    driver's 8-GPU node runs it.  A process that already maps an RCCL (this harness: torch's) must re-use that copy."""
+    if eoc.lib().eoc_device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs (the peer-copy branch is what a one-GPU box can rehearse)")
+    from eoc_tfhe_amd import circuits
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    orc = ol.Oracle(0, 9, n_override=40)
+    eoc.gpu_shutdown()
+    eoc.gpu_init(p, devices=[0, 1])
+    try:
+        eoc.upload_cloud_key(sk)
+        st = eoc.stats_multi()
+        assert st["key_broadcast_method"] == "rccl", st
+        assert st["rccl_origin"] in ("already mapped", "process symbols"), st   # torch is imported: no second RCCL
+        total = 37
+        rng = np.random.default_rng(2)
+        b = [rng.integers(0, 2, total).astype(np.uint8) for _ in range(3)]
+        c = [sk.encrypt_bits(b[k], 60 + k, 0) for k in range(3)]
+        ops = rng.choice(np.array([0, 4, 10], np.uint8), total)
+        out = eoc.gate_batch(0, c[0], c[1], c[2], ops=ops)
+        assert np.array_equal(out, orc.gate_batch(0, c[0], c[1], c[2], ops=ops))
+        per = [e["bootstraps"] for e in eoc.stats_multi()["engines"]]
+        assert all(x > 0 for x in per), per                      # both devices evaluated their block with THEIR replica
+        gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(4)
+        S = 9
+        A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+        wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+        for i in range(4):
+            wires[aw[0] + i] = sk.encrypt_bits(((A >> i) & 1).astype(np.uint8), 100 + i, 0)
+            wires[bw[0] + i] = sk.encrypt_bits(((B >> i) & 1).astype(np.uint8), 200 + i, 0)
+        ref = wires.copy()
+        eoc.circuit_run(gates, wires, S)
+        for g in gates:
+            ref[g.out] = orc.gate_batch(g.op, ref[g.in0], None if g.in1 < 0 else ref[g.in1], None if g.in2 < 0 else ref[g.in2])
+        assert np.array_equal(wires[sw[0]: sw[0] + 5], ref[sw[0]: sw[0] + 5])
+    finally:
+        eoc.gpu_shutdown()
+
+
+def test_rccl_call_path_on_one_gpu(eoc):
+    """what a one-GPU box CAN execute of the RCCL branch: the library is found (the copy torch already mapped, not a
+    second one), the dlopen'ed table works, a one-rank communicator broadcasts 8 MiB out of place and the bytes arrive"""
+    L = eoc.lib()
+    rc = L.eoc_rccl_selftest(0, 8 << 20)
+    assert rc == 0, eoc.lib().eoc_last_error()
+    assert L.eoc_rccl_origin().decode() in ("already mapped", "process symbols")
