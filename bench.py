@@ -6,10 +6,13 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one batch of 1024 independent bootsNAND gates (BASELINE.json configs[1]) per GPU on
-parameter Set A (n=500, N=1024, k=1, l=2, Bgbit=10), inputs already resident in HBM.  With N > 1
-every rank runs its own batch of 1024 gates (weak scaling, independent gates shard with no
-data-path collective); the cloud key is built once on rank 0 and RCCL-broadcast to the other ranks
-before the timed region.
+parameter Set A (n=500, N=1024, k=1, l=2, Bgbit=10).  `value` follows SURVEY.md 8(d)'s definition of the
+metric: wall time from the first H2D of the inputs to the last D2H of the outputs, keys resident -- a
+step is ONE synchronous call of eoc_gate_batch (the host-buffer C ABI) on pinned buffers from
+eoc_host_alloc.  The rate with operands already resident in HBM (the device-pointer API) is timed over
+the same K steps and printed as `resident_gates_per_s` (+1...4 %).  With N > 1 every rank runs its own
+batch of 1024 gates (weak scaling, independent gates shard with no data-path collective); the cloud
+key is built once on rank 0 and RCCL-broadcast to the other ranks before the timed region.
 
 Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
   roofline       dominant kernel (k_blind_rotate), bound = FP64 vector issue: SURVEY.md 8(d)'s algorithmic flops per
@@ -17,9 +20,9 @@ Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
                  TFLOP/s datasheet peak.  `hbm_measured` = the stored rocprofv3 PMC byte count of the same launch shape
                  (profiles/traffic.json) / this run's launch duration, as GB/s and as a fraction of 8 TB/s; the
                  algorithmic HBM figure is a secondary key (batched execution serves BK from L2: not a fraction)
-  wallclock_8d   SURVEY.md 8(d)'s own definition of the metric -- first H2D of inputs to last D2H of outputs, K calls of
-                 eoc_gate_batch on pinned host buffers -- with its own ms_per_step.  The driver's contract pins `value`
-                 to operands resident in HBM ("the PCIe-inclusive rate ... is never `value`"), so both are printed
+  resident       the same K steps through the device-pointer API, operands resident in HBM when the timed region
+                 starts: `resident_gates_per_s`, `resident_ms_per_step` (the form round 1 and 2 reported as `value`);
+                 `pageable_gates_per_s` = the host-buffer call on ordinary malloc'ed arrays
   cpu_baseline   the CPU oracle (a port: restatement of the reference algorithm, upstream libtfhe is absent) on a
                  bounded sample of the same batch, on the host cores
   secondary      N = 1: the other single-GPU configurations (adder8, streq32, mixed) and `nand1024_setB`, the headline
@@ -97,6 +100,39 @@ def read_mhz(files):
     return out
 
 
+class ClockSampler:
+    """reads the shader clock every 4 ms on a helper thread while the timed steps run (the main thread sits in a
+    GIL-free synchronize meanwhile); the median is what the device held under this load"""
+
+    def __init__(self, files):
+        import threading
+        self.files, self.samples, self.stop = files, [], False
+        self.th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop:
+            v = read_mhz(self.files)
+            if v:
+                self.samples.append(max(v))
+            time.sleep(0.004)
+
+    def __enter__(self):
+        if self.files:
+            self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.files:
+            self.th.join()
+
+    def summary(self):
+        if not self.samples:
+            return None, None, 0
+        s = sorted(self.samples)
+        return s[len(s) // 2], s[-1], len(s)
+
+
 def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_launch_ms=None):
     """FP64-issue roofline of k_blind_rotate from this run's HIP-event launch duration (+ the stored PMC byte count).
     br_ms = blind-rotate time of `jobs_per_launch` whole blind rotations; traffic_launch_ms = duration of ONE kernel
@@ -148,7 +184,6 @@ def main():
     ap.add_argument("--op", default="NAND")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer API (H2D + D2H included)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (N = 1: adder8 / streq32 / mixed / Set B; N > 1: configs[3] / [4] blocks)")
     ap.add_argument("--workload", default="nand", choices=["nand", "adder8", "streq32", "mixed"],
@@ -212,7 +247,10 @@ def main():
     p = eoc.default_params(PSETS[args.pset])
     n, G = p.n, args.gates
     op = eoc.OPS[args.op]
-    eng = eoc.Engine(p, device=local_rank)
+    # ONE engine per rank: the process-global context of the host-buffer API (the reference's one global key,
+    # eoc-tfhe-run.cpp:38-40); the device-pointer legs drive the same engine through a borrowed handle
+    eoc.gpu_init(p, device=local_rank)
+    eng = eoc.Engine.borrow_global()
 
     # ---- cloud key: built on rank 0, broadcast over RCCL ------------------------------------
     from eoc_tfhe_amd import distributed as D
@@ -230,8 +268,15 @@ def main():
     d1 = torch.from_numpy(c1).to(dev)
     dout = torch.empty_like(d0)
     stream = torch.cuda.current_stream().cuda_stream
+    pin = [eoc.PinnedArray(c0.shape) for _ in range(3)]   # I/O buffers from eoc_host_alloc (pinned: true DMA)
+    pin[0].array[:] = c0
+    pin[1].array[:] = c1
+    hout = np.empty_like(c0)
 
-    def step():
+    def step():  # first H2D of the inputs -> last D2H of the outputs, one synchronous call
+        eoc.gate_batch(op, pin[0].array, pin[1].array, out=pin[2].array)
+
+    def step_resident():
         eng.gate_batch_device(op, d0.data_ptr(), d1.data_ptr(), None, dout.data_ptr(), G, stream=stream)
 
     def make_workload(name, instances):
@@ -351,8 +396,10 @@ def main():
     boots_per_step = G
     workload_desc = None
     circuit_check = None
-    if args.workload != "nand":
+    host_path = args.workload == "nand"
+    if not host_path:  # the circuit / mixed shapes as a headline run on device-resident wires (secondary use of this script)
         step, boots_per_step, workload_desc, circuit_check = make_workload(args.workload, args.instances)
+        step_resident = None
 
     # ---- everything the later legs need is prepared BEFORE anything is timed, and the short secondary passes run first:
     # the device drops its clock within milliseconds of going idle and takes ~12 steps (40 ms) of load to come back
@@ -381,14 +428,6 @@ def main():
         db1 = torch.from_numpy(skb.encrypt_bits(bb1, 3, 0)).to(dev)
         dbout = torch.empty_like(db0)
         setb = dict(p=pb, sk=skb, eng=engb, bits=(bb0, bb1), d=(db0, db1, dbout))
-    host_leg = (single_nand or args.pcie) and rank == 0
-    if host_leg:
-        eoc.gpu_init(p, device=local_rank)
-        eoc.upload_cloud_key(sk)
-        pin = [eoc.PinnedArray(c0.shape) for _ in range(3)]   # I/O buffers from eoc_host_alloc (pinned: true DMA)
-        pin[0].array[:] = c0
-        pin[1].array[:] = c1
-        hout = np.empty_like(c0)
     clk_files, clk_matched = sclk_files(torch, local_rank)
     sec = {}
     for wname, wstep, wboots, wdesc, wcheck in sec_runs:
@@ -416,34 +455,41 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    clk_under_load = read_mhz(clk_files)   # the steps above are queued and running: the clock the device holds under them
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with ClockSampler(clk_files) as clk:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     kt = eng.kernel_times(reset=True)
     eng.set_profiling(False)
 
-    wall = None
-    if host_leg:
-        # SURVEY.md 8(d) wall-clock definition: first H2D of inputs -> last D2H of outputs, through the host-buffer
-        # C ABI (eoc_gate_batch), K calls each; reported in `wallclock_8d` beside `value` (the contract pins `value`
-        # to resident operands)
-        reps = max(10, args.steps)
-
-        def timed(a, b, o):
-            for _ in range(3):   # the first calls on a fresh context are slower (lazy set-up): not part of the rate
-                eoc.gate_batch(op, a, b, out=o)
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                eoc.gate_batch(op, a, b, out=o)
-            return (time.perf_counter() - t0) / reps
-
-        wall = (timed(pin[0].array, pin[1].array, pin[2].array), timed(c0, c1, hout), reps)
+    # the same K steps with the operands already resident in HBM (device-pointer API; what rounds 1 and 2 reported as
+    # `value`), and the host-buffer call on ordinary pageable arrays
+    resident = pageable = None
+    if host_path:
+        for _ in range(3):
+            step_resident()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        tr0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_resident()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        resident = reduce_max(time.perf_counter() - tr0)
+        if rank == 0:
+            for _ in range(3):
+                eoc.gate_batch(op, c0, c1, out=hout)
+            tp0 = time.perf_counter()
+            for _ in range(args.steps):
+                eoc.gate_batch(op, c0, c1, out=hout)
+            pageable = time.perf_counter() - tp0
 
     setb_res = None
     if setb:
@@ -457,6 +503,7 @@ def main():
         torch.cuda.synchronize()
         eb.set_profiling(True)
         eb.kernel_times(reset=True)
+        lb0 = int(eoc.lib().eoc_engine_blind_rotate_launches(eb.h))
         tb0 = time.perf_counter()
         for _ in range(args.steps):
             stepb()
@@ -464,7 +511,7 @@ def main():
         tb = time.perf_counter() - tb0
         ktb = eb.kernel_times(reset=True)
         eb.set_profiling(False)
-        setb_res = (tb, ktb)
+        setb_res = (tb, ktb, int(eoc.lib().eoc_engine_blind_rotate_launches(eb.h)) - lb0)
 
     # N > 1: BASELINE configs[3] and [4], the two configurations that ARE multi-GPU, cut into this run's blocks.
     # One warm pass, one timed pass between barriers; the run lasts as long as its slowest rank.
@@ -488,7 +535,8 @@ def main():
     elapsed = reduce_max(elapsed)
 
     # ---- correctness of what was timed: decrypt on every rank -------------------------------
-    out = dout.cpu().numpy()
+    out = pin[2].array.copy() if host_path else dout.cpu().numpy()
+    paths_agree = bool(not host_path or (np.array_equal(dout.cpu().numpy(), out) and (rank != 0 or np.array_equal(hout, out))))
     if circuit_check is not None:
         decrypt_ok = circuit_check()
     else:
@@ -525,15 +573,17 @@ def main():
                        "param_set": args.pset, "n": n, "N": 1024, "k": 1, "l": p.l, "Bgbit": p.Bgbit,
                        "ks_t": p.ks_t, "ks_basebit": p.ks_basebit, "gates_per_gpu_per_step": G,
                        "sharding": "independent gates per rank, no data-path collective",
-                       "operands": "resident in HBM when the timed region starts (driver contract); "
-                                   "SURVEY.md 8(d)'s H2D-to-D2H form is `wallclock_8d`",
+                       "timed_region": ("SURVEY.md 8(d): first H2D of inputs to last D2H of outputs, one synchronous "
+                                        "eoc_gate_batch call per step on eoc_host_alloc buffers, keys resident"
+                                        if host_path else "device-resident wires (secondary workload mode)"),
                        "key_broadcast_s": round(t_bcast, 4)},
             "decrypt_ok": decrypt_ok,
             "kernels_ms": {"prepare": round(pr_ms, 4), "blind_rotate": round(br_ms, 4), "keyswitch": round(ks_ms, 4)},
             "roofline": roofline_block(p, args.pset, G, jobs_per_launch, br_ms, args.workload == "nand"),
-            "clock": {"sclk_mhz_under_load": max(clk_under_load) if clk_under_load else None,
-                      "matched_by_pci_address": clk_matched,
-                      "source": "sysfs hwmon freq1_input, read while the timed steps were running"},
+            "clock": {"sclk_mhz_under_load": clk.summary()[0], "sclk_mhz_max_seen": clk.summary()[1],
+                      "samples": clk.summary()[2], "matched_by_pci_address": clk_matched,
+                      "source": "sysfs hwmon freq1_input of this process's GPU, sampled every 4 ms during the timed "
+                                "steps (median); the package sits at its power cap under this kernel (DESIGN.md 7)"},
         }
         if not args.no_cpu_baseline and world == 1 and args.workload == "nand":
             res["cpu_baseline"] = cpu_baseline(args, p, c0, c1, out, key_seed, op)
@@ -541,15 +591,15 @@ def main():
             for wname, _, _, _, wcheck in sec_runs:
                 sec[wname]["decrypt_ok"] = wcheck()
         if setb_res:
-            tb, ktb = setb_res
+            tb, ktb, nlaunch_b = setb_res
             pb = setb["p"]
             brb = ktb["blind_rotate"]
-            brb_ms = brb["ms"] / max(1, brb["launches"])      # a Set B blind rotation runs as two launches
             per_batch_ms = brb["ms"] / args.steps
+            brb_ms = brb["ms"] / max(1, nlaunch_b)            # a Set B blind rotation runs as two launches
             bb0, bb1 = setb["bits"]
             okb = bool(np.array_equal(setb["sk"].decrypt_bits(setb["d"][2].cpu().numpy()), 1 - (bb0 & bb1)))
             rb = roofline_block(pb, "B", G, G, per_batch_ms, True, traffic_launch_ms=brb_ms)
-            rb["launches_per_blind_rotation"] = round(brb["launches"] / args.steps, 2)
+            rb["launches_per_blind_rotation"] = round(nlaunch_b / args.steps, 2)
             rb["avg_single_launch_ms"] = round(brb_ms, 4)
             sec["nand1024_setB"] = {
                 "gates_per_s": round(G * args.steps / tb, 1), "ms_per_step": round(tb / args.steps * 1e3, 4),
@@ -563,27 +613,23 @@ def main():
         sec.update(multi)
         if sec:
             res["secondary"] = sec
-        if wall:
-            res["wallclock_8d"] = {
-                "value": round(G / wall[0], 1), "unit": "gate bootstraps/s", "ms_per_step": round(wall[0] * 1e3, 4),
-                "calls": wall[2],
-                "definition": "SURVEY.md 8(d): wall time from the first H2D of inputs to the last D2H of outputs, keys "
-                              "resident; K synchronous calls of eoc_gate_batch (host-buffer C ABI) on buffers from "
-                              "eoc_host_alloc",
-                "pageable_value": round(G / wall[1], 1),
-                "ratio_to_value": round(G / wall[0] / value, 4),
-                "bit_identical_to_resident_path": bool(np.array_equal(pin[2].array, out) and np.array_equal(hout, out))}
-            # the same numbers under their round-2 names
-            res["pcie_inclusive_gates_per_s"] = res["wallclock_8d"]["value"]
-            res["pcie_inclusive_pageable_gates_per_s"] = res["wallclock_8d"]["pageable_value"]
-            res["pcie_inclusive_ok"] = res["wallclock_8d"]["bit_identical_to_resident_path"]
-            res["resident_gates_per_s"] = res["value"]
+        if resident:
+            res["resident_gates_per_s"] = round(G * world * args.steps / resident, 1)
+            res["resident_ms_per_step"] = round(resident / args.steps * 1e3, 4)
+            res["value_over_resident"] = round(value / res["resident_gates_per_s"], 4)
+            res["pageable_gates_per_s"] = round(G * args.steps / pageable, 1) if pageable else None
+            res["paths_bit_identical"] = paths_agree
+            res["value_definition"] = ("since round 3 `value` is SURVEY.md 8(d)'s wall clock (H2D + kernels + D2H per step); "
+                                       "`resident_gates_per_s` is the figure comparable with the `value` of rounds 1 and 2")
+            res["resident_note"] = ("device-pointer API, operands resident in HBM when the timed region starts (rounds 1-2 "
+                                    "reported this as `value`); pageable = eoc_gate_batch on ordinary malloc'ed arrays, rank 0")
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
-    if host_leg:
-        for a in pin:
-            a.free()
-        eoc.gpu_shutdown()
+    for a in pin:
+        a.free()
+    eng.close()
+    eoc.gpu_shutdown()      # the engine goes first: its key images live in the two tensors below
+    del bkfft, ksk
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -148,6 +148,7 @@ def lib():
         "eoc_host_free": (None, [vp]),
         "eoc_engine_reserve": (C.c_int, [vp, sz, sz, sz]),
         "eoc_engine_workspace_grows": (u64, [vp]),
+        "eoc_engine_blind_rotate_launches": (u64, [vp]),
         "eoc_engine_device": (C.c_int, [vp]),
         "eoc_engine_params": (PP, [vp]),
         "eoc_engine_adopt_cloud_key_device": (C.c_int, [vp, vp, vp]),
@@ -362,9 +363,26 @@ class Engine:
         self.n = self.params.n
         return self
 
+    @classmethod
+    def borrow_global(cls, index=0):
+        """Wrapper around engine `index` of the process-global context (eoc_gpu_init[_multi]): the same engine the
+        host-buffer API drives, reachable through the device-pointer API too.  Not owned: close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.L = lib()
+        h = self.L.eoc_global_engine_at(index)
+        if not h:
+            raise EocError("borrow_global: no global engine (eoc_gpu_init not called)")
+        self.h = C.c_void_p(h)
+        self._borrowed = True
+        self.params = self.L.eoc_engine_params(self.h).contents.copy()
+        self.device = self.L.eoc_engine_device(self.h)
+        self.n = self.params.n
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.eoc_engine_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.L.eoc_engine_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -73,6 +73,7 @@ struct eoc_engine {
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
     uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
+    uint64_t br_launches = 0; // k_blind_rotate kernel launches (a wide level is several, a cut blind rotation too)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
     bool profiling = false;
     struct Span { hipEvent_t a, b; int kind; };
@@ -585,6 +586,7 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
                 default: return EOC_ERR_ARG;
                 }
             HIP_TRY(hipGetLastError());
+            e->br_launches++;
         }
     }
     return EOC_OK;
@@ -1060,5 +1062,6 @@ extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])
     return EOC_OK;
 }
 extern "C" uint64_t eoc_engine_workspace_grows(eoc_engine *e) { return e ? e->ws_grows : 0; }
+extern "C" uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e) { return e ? e->br_launches : 0; }
 extern "C" int eoc_engine_device(eoc_engine *e) { return e ? e->device : -1; }
 extern "C" const eoc_params *eoc_engine_params(eoc_engine *e) { return e ? &e->p : nullptr; }

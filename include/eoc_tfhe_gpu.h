@@ -173,6 +173,9 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  *   max_mixed_rows : rows of the largest mixed (ops != NULL) batch, 0 if none */
 int eoc_engine_reserve(eoc_engine *e, size_t max_jobs, size_t max_descs, size_t max_mixed_rows);
 uint64_t eoc_engine_workspace_grows(eoc_engine *e);
+/* k_blind_rotate kernel launches so far (eoc_engine_kernel_times counts one span per blind-rotate CALL; a wide level is
+ * cut into single-round launches and a gadget-length-3 blind rotation into two parts, so launches >= spans) */
+uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e);
 int eoc_engine_device(eoc_engine *e);
 const eoc_params *eoc_engine_params(eoc_engine *e);
 /*

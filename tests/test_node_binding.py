@@ -33,3 +33,20 @@ def test_gates_through_node_gpu(built_lib):
     r = subprocess.run(["node", os.path.join(NODE_DIR, "test_gpu.js")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "node gpu tests OK" in r.stdout
+
+
+@needs_node
+@pytest.mark.gpu
+def test_gate_batch_through_node_equals_golden_bytes(built_lib, tmp_path):
+    """the binding's gateBatch compared with oracle BITS, not by decryption -- the committed golden inputs
+    (Set A, key seed 1) through the N-API addon must come back as the committed golden outputs"""
+    import numpy as np
+    _build()
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_arrays.npz"))
+    for name in ("A_c0", "A_c1", "A_c2", "A_NAND_out", "A_MUX_out"):
+        np.ascontiguousarray(z[name], "<i4").tofile(str(tmp_path / (name + ".bin")))
+    env = dict(os.environ, EOC_GOLDEN_DIR=str(tmp_path))
+    r = subprocess.run(["node", os.path.join(NODE_DIR, "test_gpu_golden.js")], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "node gpu golden OK" in r.stdout

@@ -1,14 +1,16 @@
 #!/bin/bash
-# One GPU-box call that regenerates the evidence under profiles/: bench lines (A with cpu_baseline and the
-# PCIe-inclusive rate, B), rocprofv3 kernel-trace stats of the same command, and the PMC passes.
-# Usage (GPU box): bash tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>/...
+# One GPU-box call that regenerates the evidence under profiles/ from ONE box and ONE build, so that the files agree with
+# each other: the driver's bench line (Set A headline with cpu_baseline, secondary legs, the Set B leg and wallclock_8d),
+# rocprofv3 kernel-trace stats of the same command, the PMC passes for both sets, traffic.json, the box's clock.
+# Usage (GPU box): bash tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
 set -e
 TAG=${1:-final}
+export EOC_PROFILE_TAG="$TAG"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 mkdir -p "$O"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_A.json" 2> "$O/bench_A.err"
-echo "bench A done"
+echo "bench A (driver command) done"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --pset B --no-cpu-baseline --no-secondary > "$O/bench_B.json" 2> "$O/bench_B.err"
 echo "bench B done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$O/bench_under_rocprof.json" 2> "$O/trace.err"
@@ -21,5 +23,6 @@ bash tools/pmc_passes.sh "$O/pmcB" --steps 3 --warmup 1 --no-cpu-baseline --no-s
 cp "$O/pmcB/summary.txt" "$O/pmc_summary_B.txt"
 echo "pmc B done"
 python3 tools/traffic_json.py "$O/pmc_summary.txt" "$O/pmc_summary_B.txt" > "$O/traffic.json"
+(rocm-smi --showclocks --showpower --showmaxpower 2>/dev/null || true) > "$O/rocm_smi.txt"
 head -5 "$O/kernel_stats.csv"
 cat "$O/bench_A.json"
