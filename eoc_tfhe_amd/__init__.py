@@ -144,6 +144,8 @@ def lib():
         "eoc_rccl_selftest": (C.c_int, [C.c_int, sz]),
         "eoc_worker_wakeups": (u64, [C.c_int]),
         "eoc_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
+        "eoc_gate_batch_submit": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz, C.POINTER(u64)]),
+        "eoc_gate_batch_wait": (C.c_int, [u64]),
         "eoc_host_alloc": (vp, [sz]),
         "eoc_host_free": (None, [vp]),
         "eoc_engine_reserve": (C.c_int, [vp, sz, sz, sz]),
@@ -547,6 +549,27 @@ class PinnedArray:
             self.free()
         except Exception:
             pass
+
+
+def gate_batch_submit(op, in0, in1=None, in2=None, ops=None, out=None):
+    """eoc_gate_batch_submit on PinnedArray-backed numpy views (C-contiguous int32 [count][n+1]); returns the ticket.
+    The arrays must stay alive and untouched until gate_batch_wait(ticket)."""
+    for a in (in0, in1, in2, out):
+        if a is not None and (a.dtype != np.int32 or not a.flags.c_contiguous):
+            raise EocError("gate_batch_submit: operands are C-contiguous int32 arrays")
+    if out is None or (in0 is not None and out.shape != in0.shape):
+        raise EocError("gate_batch_submit: `out` must be given and have the operands' shape")
+    opsc = None if ops is None else np.ascontiguousarray(ops, np.uint8)
+    t = C.c_uint64()
+    _check(lib().eoc_gate_batch_submit(int(op), None if opsc is None else opsc.ctypes.data,
+                                       None if in0 is None else in0.ctypes.data, None if in1 is None else in1.ctypes.data,
+                                       None if in2 is None else in2.ctypes.data, out.ctypes.data, out.shape[0], C.byref(t)),
+           "eoc_gate_batch_submit")
+    return t.value
+
+
+def gate_batch_wait(ticket):
+    _check(lib().eoc_gate_batch_wait(ticket), "eoc_gate_batch_wait")
 
 
 def gpu_shutdown():

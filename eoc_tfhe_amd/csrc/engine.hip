@@ -308,6 +308,11 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         HIP_TRY(hipMalloc(&W.d_u, cap * (kN + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&W.d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
         HIP_TRY(hipMemset(W.d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        // the memset runs on the NULL stream and callers may launch on hipStreamNonBlocking streams, which do not wait for
+        // it: without this the fill could land on key-switch operands the first batch has already written (seen as 7
+        // mismatches in 5 000 host-path cases of tools/soak_parity.py once the persistent workers removed the thread
+        // start-up delay that used to hide it)
+        HIP_TRY(hipDeviceSynchronize());
         if (!W.d_acc_state) HIP_TRY(hipMalloc(&W.d_acc_state, (size_t)4 * e->num_cus * 2 * kN * sizeof(int32_t) * 4));
         W.ws_jobs = cap;
         e->ws_grows++;

@@ -118,11 +118,24 @@ struct Slot {
     int32_t *d_wires = nullptr;
     size_t cap_wire_ints = 0;
     uint64_t grows = 0; // buffer growths (0 in steady state)
+    // asynchronous batch path (eoc_gate_batch_submit / _wait): two buffer sets, so that batch k + 1's operands arrive
+    // while batch k computes and batch k's results leave under batch k + 1's kernels
+    int32_t *d_as[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    size_t cap_async = 0;
+    hipEvent_t ev_as[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // operands in, kernels done, results out
+};
+
+struct Pending { // one submitted, not yet awaited batch
+    uint64_t ticket = 0;
+    bool active = false;
+    std::vector<int> slots; // engines that received a non-empty block
 };
 
 struct Global {
     std::mutex mu;
     std::vector<Slot> slots;
+    uint64_t next_ticket = 1;
+    Pending ring[2];
     eoc_params p{};
     double bcast_s = 0.0;
     std::string bcast_method = "none";
@@ -322,9 +335,15 @@ void destroy_slots_locked()
 {
     for (auto &s : G.slots)
         if (s.worker) s.worker->shutdown();
+    for (auto &pd : G.ring) pd = Pending();
     for (auto &s : G.slots) {
         hipSetDevice(s.device);
         hipDeviceSynchronize();
+        for (int r = 0; r < 2; r++) {
+            for (int k = 0; k < 4; k++) hipFree(s.d_as[r][k]);
+            for (int k = 0; k < 3; k++)
+                if (s.ev_as[r][k]) hipEventDestroy(s.ev_as[r][k]);
+        }
         for (int k = 0; k < 4; k++) hipFree(s.d_io[k]);
         hipFree(s.d_wires);
         for (int k = 0; k < 3; k++)
@@ -482,6 +501,93 @@ template <class F> int for_each_block(size_t total, F fn)
         if (r && !rc) rc = r;
     }
     return rc;
+}
+
+// ---- asynchronous batches ------------------------------------------------------------------------------------------
+// wait for one pending submission: its results are in the caller's buffers afterwards
+int finish_pending_locked(Pending &pd)
+{
+    int rc = EOC_OK;
+    if (!pd.active) return rc;
+    const int r = (int)(pd.ticket & 1);
+    for (int i : pd.slots) {
+        Slot &s = G.slots[i];
+        if (hipSetDevice(s.device) != hipSuccess || hipEventSynchronize(s.ev_as[r][2]) != hipSuccess) {
+            eoc_set_error("eoc_gate_batch_wait: waiting for ticket %llu failed on engine %d", (unsigned long long)pd.ticket, i);
+            rc = EOC_ERR_HIP;
+        }
+    }
+    pd.active = false;
+    return rc;
+}
+// every synchronous entry point first drains the asynchronous ones (they share streams and the engines' workspaces)
+int drain_async_locked()
+{
+    int rc = EOC_OK;
+    const int first = G.ring[0].ticket < G.ring[1].ticket ? 0 : 1;
+    for (int k = 0; k < 2; k++) {
+        const int r = finish_pending_locked(G.ring[(first + k) & 1]);
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+
+int slot_async_reserve(Slot &s, size_t rows, size_t stride_ints)
+{
+    HIP_TRY(hipSetDevice(s.device));
+    for (int r = 0; r < 2; r++)
+        for (int k = 0; k < 3; k++)
+            if (!s.ev_as[r][k]) HIP_TRY(hipEventCreateWithFlags(&s.ev_as[r][k], hipEventDisableTiming));
+    if (rows <= s.cap_async) return EOC_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t cap = std::max<size_t>(rows, 1024);
+    for (int r = 0; r < 2; r++)
+        for (int k = 0; k < 4; k++) {
+            hipFree(s.d_as[r][k]);
+            s.d_as[r][k] = nullptr;
+        }
+    s.cap_async = 0;
+    for (int r = 0; r < 2; r++)
+        for (int k = 0; k < 4; k++) HIP_TRY(hipMalloc(&s.d_as[r][k], cap * stride_ints * 4));
+    s.cap_async = cap;
+    s.grows++;
+    return EOC_OK;
+}
+
+// queue one device's block of a submitted batch on buffer set r: operands by DMA on the H2D stream, kernels on the
+// kernel stream behind them, results by DMA on the D2H stream behind the kernels.  Nothing here waits for the device.
+int slot_async_block(Slot &s, int r, int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                     int32_t *out, size_t count, size_t stride_ints)
+{
+    int rc = slot_async_reserve(s, count, stride_ints);
+    if (rc) return rc;
+    const int32_t *h[3] = {in0, in1, in2};
+    const size_t bytes = count * stride_ints * 4;
+    auto fail = [&](int code) {
+        for (int k = 0; k < 3; k++) (void)hipStreamSynchronize(s.st[k]);
+        return code;
+    };
+#define AS_TRY(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            eoc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);       \
+            return fail(EOC_ERR_HIP);                                                                        \
+        }                                                                                                    \
+    } while (0)
+    for (int k = 0; k < 3; k++)
+        if (h[k]) AS_TRY(hipMemcpyAsync(s.d_as[r][k], h[k], bytes, hipMemcpyHostToDevice, s.st[1]));
+    AS_TRY(hipEventRecord(s.ev_as[r][0], s.st[1]));
+    AS_TRY(hipStreamWaitEvent(s.st[0], s.ev_as[r][0], 0));
+    rc = eoc_gate_batch_device(s.e, op, ops, h[0] ? s.d_as[r][0] : nullptr, h[1] ? s.d_as[r][1] : nullptr,
+                               h[2] ? s.d_as[r][2] : nullptr, s.d_as[r][3], count, s.st[0]);
+    if (rc) return fail(rc);
+    AS_TRY(hipEventRecord(s.ev_as[r][1], s.st[0]));
+    AS_TRY(hipStreamWaitEvent(s.st[2], s.ev_as[r][1], 0));
+    AS_TRY(hipMemcpyAsync(out, s.d_as[r][3], bytes, hipMemcpyDeviceToHost, s.st[2]));
+    AS_TRY(hipEventRecord(s.ev_as[r][2], s.st[2]));
+#undef AS_TRY
+    return EOC_OK;
 }
 
 } // namespace
@@ -819,6 +925,10 @@ extern "C" int eoc_gate_batch(int op, const uint8_t *ops, const int32_t *in0, co
         return EOC_ERR_ARG;
     }
     if (!count) return EOC_OK;
+    {
+        int rc = drain_async_locked();
+        if (rc) return rc;
+    }
     const size_t stride = (size_t)G.p.n + 1;
     return for_each_block(count, [=](int i, size_t lo, size_t hi) {
         return slot_gate_block(G.slots[i], op, ops ? ops + lo : nullptr, in0 ? in0 + lo * stride : nullptr,
@@ -836,9 +946,77 @@ extern "C" int eoc_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *w
     }
     if (!gates || !wires) return EOC_ERR_ARG;
     if (!n_gates || !instances) return EOC_OK;
+    {
+        int rc = drain_async_locked();
+        if (rc) return rc;
+    }
     const size_t stride = (size_t)G.p.n + 1;
     // a whole circuit instance stays on one device: no wire ever crosses GPUs
     return for_each_block(instances, [=](int i, size_t lo, size_t hi) {
         return slot_circuit_block(G.slots[i], gates, n_gates, wires, n_wires, instances, lo, hi, stride);
     });
+}
+
+// Asynchronous form of eoc_gate_batch (the reference has no counterpart: it is one synchronous wasm call per operation,
+// eoc-tfhe-bindings.c:12-24).  The call returns once the batch is QUEUED: operands travel on the H2D stream, kernels
+// follow on the kernel stream, results leave on the D2H stream, so a host that keeps two batches in flight hides the PCIe
+// time of one behind the kernels of the other.  All buffers must come from eoc_host_alloc and stay untouched until
+// eoc_gate_batch_wait(ticket).  At most two submissions are in flight: a third first waits for the oldest.  Batches
+// execute in submission order.  Every synchronous call on the global context drains the pending submissions first.
+extern "C" int eoc_gate_batch_submit(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                     int32_t *out, size_t count, uint64_t *ticket)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (G.slots.empty()) {
+        eoc_set_error("eoc_gate_batch_submit: no GPU engine (eoc_gpu_init not called or failed); there is no CPU fallback");
+        return EOC_ERR_NO_DEVICE;
+    }
+    const bool const_only = !ops && (op == EOC_CONST0 || op == EOC_CONST1);
+    if (!ticket || !out || (!in0 && !const_only)) {
+        eoc_set_error("eoc_gate_batch_submit: null argument");
+        return EOC_ERR_ARG;
+    }
+    if (!is_pinned(in0) || !is_pinned(in1) || !is_pinned(in2) || !mapped_address(out)) {
+        eoc_set_error("eoc_gate_batch_submit: every buffer must come from eoc_host_alloc (asynchronous copies from pageable "
+                      "memory are staged synchronously by the runtime)");
+        return EOC_ERR_ARG;
+    }
+    const uint64_t t = G.next_ticket;
+    Pending &pd = G.ring[t & 1];
+    int rc = finish_pending_locked(pd); // the submission that used this buffer set two tickets ago
+    if (rc) return rc;
+    pd.ticket = t;
+    pd.slots.clear();
+    const size_t stride = (size_t)G.p.n + 1;
+    const int world = (int)G.slots.size();
+    for (int i = 0; i < world && count; i++) { // queuing is asynchronous: done from the calling thread, device by device
+        size_t lo, hi;
+        shard_range(count, i, world, &lo, &hi);
+        if (hi == lo) continue;
+        rc = slot_async_block(G.slots[i], (int)(t & 1), op, ops ? ops + lo : nullptr, in0 ? in0 + lo * stride : nullptr,
+                              in1 ? in1 + lo * stride : nullptr, in2 ? in2 + lo * stride : nullptr, out + lo * stride,
+                              hi - lo, stride);
+        if (rc) { // what was queued on earlier engines completes into the caller's buffers; the ticket is not issued
+            pd.active = true;
+            (void)finish_pending_locked(pd);
+            return rc;
+        }
+        pd.slots.push_back(i);
+    }
+    pd.active = true;
+    G.next_ticket = t + 1;
+    *ticket = t;
+    return EOC_OK;
+}
+// returns when the submission's results are in the caller's output buffer (immediately for a ticket already awaited)
+extern "C" int eoc_gate_batch_wait(uint64_t ticket)
+{
+    std::lock_guard<std::mutex> g(G.mu);
+    if (ticket == 0 || ticket >= G.next_ticket) {
+        eoc_set_error("eoc_gate_batch_wait: unknown ticket %llu", (unsigned long long)ticket);
+        return EOC_ERR_ARG;
+    }
+    Pending &pd = G.ring[ticket & 1];
+    if (pd.ticket != ticket) return EOC_OK; // an older ticket: its buffer set was re-used, so it has completed
+    return finish_pending_locked(pd);
 }

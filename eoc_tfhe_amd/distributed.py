@@ -40,6 +40,25 @@ def shard(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# ---- BASELINE.json configs[3]: 2^20 mixed gates, op ~ uniform{NAND, XOR, MUX} from seed 4, contiguous blocks -----------
+CONFIG3_OPCODES = (0, 4, 10)  # NAND, XOR, MUX (include/eoc_tfhe_gpu.h)
+
+
+def config3_ops(total=1 << 20):
+    """the op stream of SURVEY.md 8(d) config 4 / BASELINE configs[3]: one opcode per gate, seed 4"""
+    import numpy as np
+    return np.random.default_rng(4).choice(np.array(CONFIG3_OPCODES, np.uint8), total)
+
+
+def config3_block(total, rank, world):
+    """(lo, hi, opcodes of this rank's block, bootstraps of the WHOLE stream): what bench.py times at N > 1 and
+    tests/test_gpu_baseline_configs.py evaluates shard by shard.  MUX = 2 bootstraps."""
+    import numpy as np
+    ops = config3_ops(total)
+    lo, hi = shard(total, rank, world)
+    return lo, hi, np.ascontiguousarray(ops[lo:hi]), int(total + (ops == 10).sum())
+
+
 def broadcast_key_images(dist, tensors, src=0):
     """One broadcast per key image (BK-FFT, KSK) from `src`; returns seconds spent."""
     import time

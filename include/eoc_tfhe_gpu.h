@@ -275,6 +275,14 @@ int eoc_rccl_selftest(int device, size_t bytes);
  * the threads whose block of the call is non-empty.  Wake-ups of engine i's thread since eoc_gpu_init_multi (0 for i = 0) */
 uint64_t eoc_worker_wakeups(int engine_index);
 void eoc_shard_range(size_t total, int rank, int world, size_t *lo, size_t *hi);
+/* Asynchronous form of eoc_gate_batch: returns once the batch is queued (operands on the H2D stream, kernels behind
+ * them, results on the D2H stream).  Every buffer must come from eoc_host_alloc and stay untouched until
+ * eoc_gate_batch_wait(ticket).  Two submissions may be in flight (a third first waits for the oldest); they execute in
+ * submission order; a host that keeps two in flight hides one batch's PCIe time behind the other's kernels.  Every
+ * synchronous call on the global context drains pending submissions first.  `ops` is read during the call. */
+int eoc_gate_batch_submit(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                          int32_t *out, size_t count, uint64_t *ticket);
+int eoc_gate_batch_wait(uint64_t ticket);
 /* pinned host memory for I/O buffers of the batch API (true DMA, chunked overlap); release with eoc_host_free */
 void *eoc_host_alloc(size_t bytes);
 void eoc_host_free(void *p);

@@ -109,19 +109,16 @@ def test_config4_mixed_gates_all_eight_shards(eoc, rig):
     op stream from seed 4.  One GPU evaluates ALL EIGHT blocks one after the other, exactly as the eight ranks would:
     every gate of the 2^20 is decrypt-checked, and a slice of every block (all three opcodes) is compared with the
     oracle bit for bit."""
-    from eoc_tfhe_amd.distributed import shard
+    from eoc_tfhe_amd.distributed import config3_block
     p, sk, eng = rig
     torch = torch_cuda()
     total = 1 << 20
-    rng = np.random.default_rng(4)
-    ops_all = rng.choice(np.array([eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["MUX"]], np.uint8), total)
     orc = ol.Oracle(0, 1)
     covered = 0
     for rank in range(8):
-        lo, hi = shard(total, rank, 8)
+        lo, hi, ops, _ = config3_block(total, rank, 8)    # the blocks bench.py --gpus 8 times, one per rank
         cnt = hi - lo
-        covered += cnt
-        ops = ops_all[lo:hi]               # arbitrary order: the engine groups equal opcodes on the device
+        covered += cnt                     # arbitrary opcode order: the engine groups equal opcodes on the device
         b = [np.random.default_rng(40 + 10 * rank + k).integers(0, 2, cnt).astype(np.uint8) for k in range(3)]
         c = [to_dev(sk.encrypt_bits(b[k], 5000 + k, lo)) for k in range(3)]
         out = torch.empty_like(c[0])

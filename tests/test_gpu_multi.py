@@ -314,3 +314,54 @@ def test_rccl_call_path_on_one_gpu(eoc):
     rc = L.eoc_rccl_selftest(0, 8 << 20)
     assert rc == 0, eoc.lib().eoc_last_error()
     assert L.eoc_rccl_origin().decode() in ("already mapped", "process symbols")
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_async_submit_wait_pipeline(eoc, devices):
+    """eoc_gate_batch_submit / _wait: seven batches of different widths and opcodes kept two deep in flight (operands by
+    DMA while the previous batch computes, results leaving under the next batch's kernels) equal the oracle row for
+    row; a synchronous call in between drains the pipeline; pageable buffers and unknown tickets are refused."""
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    orc = ol.Oracle(0, 9, n_override=40)
+    eoc.gpu_shutdown()
+    eoc.gpu_init(p, devices=devices)
+    eoc.upload_cloud_key(sk)
+    try:
+        rng = np.random.default_rng(33)
+        widths = [700, 64, 1030, 5, 333, 1, 512]
+        jobs = []
+        for k, w in enumerate(widths):
+            pin = [eoc.PinnedArray((w, p.n + 1)) for _ in range(4)]
+            for j in range(3):
+                pin[j].array[:] = sk.encrypt_bits(rng.integers(0, 2, w).astype(np.uint8), 100 + 10 * k + j, 0)
+            ops = rng.choice(np.array([0, 4, 10, 11, 2, 13], np.uint8), w) if k % 2 else None
+            op = int(rng.choice([0, 1, 4, 10])) if ops is None else 0
+            jobs.append((pin, op, ops))
+        tickets = []
+        for k, (pin, op, ops) in enumerate(jobs):
+            if k >= 2:
+                eoc.gate_batch_wait(tickets[k - 2])
+                pk, opk, opsk = jobs[k - 2]
+                want = orc.gate_batch(opk, pk[0].array, pk[1].array, pk[2].array, ops=opsk)
+                assert np.array_equal(pk[3].array, want), f"batch {k - 2}"
+            tickets.append(eoc.gate_batch_submit(op, pin[0].array, pin[1].array, pin[2].array, ops=ops, out=pin[3].array))
+        assert tickets == sorted(tickets) and len(set(tickets)) == len(tickets)
+        # a synchronous call drains what is still in flight (the last two submissions)
+        c = sk.encrypt_bits(np.ones(9, np.uint8), 5, 0)
+        assert np.array_equal(eoc.gate_batch(eoc.OPS["AND"], c, c), orc.gate_batch(ol.OPS["AND"], c, c))
+        for k in (len(jobs) - 2, len(jobs) - 1):
+            pk, opk, opsk = jobs[k]
+            assert np.array_equal(pk[3].array, orc.gate_batch(opk, pk[0].array, pk[1].array, pk[2].array, ops=opsk)), f"batch {k}"
+        for t in tickets:                      # waiting again (or late) is harmless
+            eoc.gate_batch_wait(t)
+        with pytest.raises(eoc.EocError):
+            eoc.gate_batch_wait(tickets[-1] + 1)
+        with pytest.raises(eoc.EocError, match="eoc_host_alloc"):
+            eoc.gate_batch_submit(0, c, c, out=np.empty_like(c))
+        for pin, _, _ in jobs:
+            for a in pin:
+                a.free()
+    finally:
+        eoc.gpu_shutdown()

@@ -32,7 +32,7 @@ while time.time() < t_end:
     eng.load_cloud_key(sk)
     orc = ol.Oracle(pset, seed, n_override=n)
     for _ in range(4):
-        kind = rng.choice(["uniform", "mixed", "circuit", "host"])
+        kind = rng.choice(os.environ.get("SOAK_KINDS", "uniform,mixed,circuit,host").split(","))
         count = int(rng.choice([1, 2, 63, 64, 65, 127, 1023, 1024, 1025, int(rng.integers(1, 2600))]))
         c = [sk.encrypt_bits(rng.integers(0, 2, count).astype(np.uint8), int(rng.integers(1, 1 << 30)), 0) for _ in range(3)]
         if kind == "circuit":
