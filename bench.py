@@ -561,6 +561,27 @@ def main():
         decrypt_ok = bool(truth is None or np.array_equal(sk.decrypt_bits(out), truth))
     decrypt_ok = reduce_all_ok(decrypt_ok)  # every rank must have produced correct gates
 
+    # N = 1 on a box that shows several GPUs: the OTHER multi-GPU product -- one process, one engine per GPU behind the same
+    # eoc_gate_batch call, keys replicated by the library's own RCCL broadcast -- as a child process, after this
+    # process has finished with the GPU and before the line is printed.  A failure or a time-out becomes an `error` entry.
+    in_library = None
+    inlib_devices = os.environ.get("EOC_BENCH_INLIB_DEVICES", "all" if ndev >= 2 else "")  # "0,0": one-GPU rehearsal
+    if single_nand and not args.no_secondary and inlib_devices and os.environ.get("EOC_BENCH_NO_INLIB") != "1":
+        import subprocess
+        for a in pin:
+            a.free()
+        pin = []
+        eng.close()
+        eoc.gpu_shutdown()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "in_library_multi.py"), "--steps", "10",
+                                "--devices", inlib_devices],
+                               capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            in_library = json.loads(line[-1]) if line else {"error": f"rc={r.returncode}", "stderr_tail": r.stderr[-600:]}
+        except Exception as e:  # noqa: BLE001 -- time-out, missing interpreter, bad JSON: reported, never fatal
+            in_library = {"error": repr(e)[:600]}
+
     if rank == 0:
         total_gates = boots_per_step * world * args.steps
         value = total_gates / elapsed
@@ -627,6 +648,8 @@ def main():
                 "workload": f"{G} independent bootsNAND gates per step on the parameter set the reference's keygen selects "
                             f"(minimum_lambda = 128, eoc-tfhe-run.cpp:34,230), operands resident, {args.steps} timed steps"}
         sec.update(multi)
+        if in_library is not None:
+            sec["in_library_all_devices"] = in_library
         if sec:
             res["secondary"] = sec
         if resident:
