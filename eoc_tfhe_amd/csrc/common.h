@@ -6,3 +6,6 @@
 // last error message (also echoed on stderr, the reference's convention:
 // ao-tfhe/eoc-tfhe-run.cpp:218-219,277-278)
 void eoc_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+// the message is per thread (eoc_last_error reads the calling thread's): a result produced on a worker thread hands its
+// message over to the thread that reports the error code (already echoed on stderr once, so not again)
+void eoc_adopt_error(const char *msg);

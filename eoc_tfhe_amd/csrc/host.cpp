@@ -32,6 +32,10 @@ void eoc_set_error(const char *fmt, ...)
     va_end(ap);
     fprintf(stderr, "eoc-tfhe: %s\n", g_err);
 }
+void eoc_adopt_error(const char *msg)
+{
+    snprintf(g_err, sizeof g_err, "%s", msg ? msg : "");
+}
 extern "C" const char *eoc_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------------

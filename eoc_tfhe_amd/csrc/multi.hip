@@ -61,6 +61,7 @@ struct Worker {
     std::function<int()> job;
     bool has_job = false, stop = false;
     int rc = 0;
+    std::string err; // the worker thread's error message of the last job (eoc_last_error is per thread)
     uint64_t wakeups = 0;
     void run(int device)
     {
@@ -72,8 +73,10 @@ struct Worker {
             std::function<int()> j = std::move(job);
             lk.unlock();
             const int r = j();
+            std::string msg = r ? eoc_last_error() : "";
             lk.lock();
             rc = r;
+            err.swap(msg);
             has_job = false;
             wakeups++;
             cv.notify_all();
@@ -92,6 +95,7 @@ struct Worker {
     {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return !has_job; });
+        if (rc) eoc_adopt_error(err.c_str()); // the caller's eoc_last_error() now explains the code it is about to get
         return rc;
     }
     void shutdown()

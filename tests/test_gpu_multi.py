@@ -365,3 +365,15 @@ def test_async_submit_wait_pipeline(eoc, devices):
                 a.free()
     finally:
         eoc.gpu_shutdown()
+
+
+def test_error_from_a_worker_block_reaches_the_caller(eoc, ctx3):
+    """an error raised while engine 2's persistent thread evaluates its block comes back with ITS message
+    (eoc_last_error is per thread: the worker hands the text over), and the context stays usable"""
+    p, sk, orc = ctx3
+    c = sk.encrypt_bits(np.ones(12, np.uint8), 1, 0)
+    ops = np.zeros(12, np.uint8)
+    ops[11] = 99                                   # blocks 4 + 4 + 4: the bad opcode is in engine 2's block
+    with pytest.raises(eoc.EocError, match="bad opcode 99"):
+        eoc.gate_batch(0, c, c, ops=ops)
+    assert np.array_equal(eoc.gate_batch(eoc.OPS["OR"], c, c), orc.gate_batch(ol.OPS["OR"], c, c))
