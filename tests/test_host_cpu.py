@@ -108,6 +108,15 @@ def test_hot_path_fails_loudly_without_gpu(eoc):
     assert eoc.Tfhe.decryptBit("AAAA") == -1
     assert eoc.Tfhe.nand("AAAA", "AAAA") is None
     assert eoc.Tfhe.generateGateKey(80, 1) is None   # cannot bring the engine up
+    # round-3 entry points: the asynchronous batch, the worker counter, the RCCL rehearsal
+    with pytest.raises(eoc.EocError, match="no CPU fallback"):
+        eoc.gate_batch_submit(0, x, x, out=np.zeros_like(x))
+    with pytest.raises(eoc.EocError, match="unknown ticket"):
+        eoc.gate_batch_wait(1)
+    assert L.eoc_worker_wakeups(0) == 0 and L.eoc_gpu_engine_count() == 0
+    assert L.eoc_rccl_selftest(0, 4096) != 0         # no device to run it on: an error code, not a crash
+    with pytest.raises(eoc.EocError, match="no global engine"):
+        eoc.Engine.borrow_global()
 
 
 def test_circuit_bootstrap_count(eoc):
