@@ -146,6 +146,7 @@ def lib():
         "eoc_shard_range": (None, [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]),
         "eoc_gate_batch_submit": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz, C.POINTER(u64)]),
         "eoc_gate_batch_wait": (C.c_int, [u64]),
+        "eoc_global_gate_batch_submit": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, sz, C.POINTER(u64)]),
         "eoc_host_alloc": (vp, [sz]),
         "eoc_host_free": (None, [vp]),
         "eoc_engine_reserve": (C.c_int, [vp, sz, sz, sz]),

@@ -712,6 +712,20 @@ extern "C" int eoc_global_gate_batch(int op, const uint8_t *ops, const int32_t *
     if (rc) return rc;
     return eoc_gate_batch(op, ops, in0, in1, in2, out, count);
 }
+// the asynchronous form on the global key's engine (buffers from eoc_host_alloc; eoc_gate_batch_wait completes it)
+extern "C" int eoc_global_gate_batch_submit(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
+                                            const int32_t *in2, int32_t *out, size_t count, uint64_t *ticket)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.sk) {
+        fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
+        return EOC_ERR_NO_KEY;
+    }
+    int rc = ensure_engine_locked();
+    if (rc) return rc;
+    return eoc_gate_batch_submit(op, ops, in0, in1, in2, out, count, ticket);
+}
 extern "C" int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,
                                       size_t instances)
 {

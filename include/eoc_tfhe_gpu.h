@@ -356,6 +356,8 @@ int eoc_engine_create_from_cloud_key_blob(int device, const void *buf, size_t le
 int eoc_global_params(eoc_params *out);
 int eoc_global_encrypt_bits(const uint8_t *bits, size_t count, int32_t *cts);
 int eoc_global_decrypt_bits(const int32_t *cts, size_t count, uint8_t *bits);
+int eoc_global_gate_batch_submit(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
+                                 const int32_t *in2, int32_t *out, size_t count, uint64_t *ticket);
 int eoc_global_gate_batch(int op, const uint8_t *ops, const int32_t *in0, const int32_t *in1,
                           const int32_t *in2, int32_t *out, size_t count);
 int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires, size_t n_wires,

@@ -268,6 +268,62 @@ static napi_value n_gateBatch(napi_env env, napi_callback_info info)
         return ret_null(env);
     return out;
 }
+/* ---- asynchronous batches on pinned buffers (eoc_gate_batch_submit / _wait): a Node host keeps two batches in flight
+ * and the PCIe time of one disappears behind the kernels of the other ---- */
+static void free_pinned(napi_env env, void *data, void *hint)
+{
+    (void)env;
+    (void)hint;
+    eoc_host_free(data);
+}
+static napi_value n_hostAlloc(napi_env env, napi_callback_info info)
+{ /* (bytes) -> Buffer over pinned, device-mapped host memory (eoc_host_alloc); freed when the Buffer is collected */
+    ARGS(1);
+    int64_t bytes = 0;
+    napi_get_value_int64(env, argv[0], &bytes);
+    if (bytes <= 0) return ret_null(env);
+    void *p = eoc_host_alloc((size_t)bytes);
+    if (!p) return ret_null(env);
+    napi_value out;
+    if (napi_create_external_buffer(env, (size_t)bytes, p, free_pinned, NULL, &out) != napi_ok) {
+        eoc_host_free(p);
+        return ret_null(env);
+    }
+    return out;
+}
+static napi_value n_gateBatchSubmit(napi_env env, napi_callback_info info)
+{ /* (op, in0, in1 | null, in2 | null, ops | null, out) -- every Buffer from hostAlloc -> ticket (number), or null.
+   * The Buffers must stay referenced and untouched until gateBatchWait(ticket). */
+    ARGS(6);
+    int op = arg_int(env, argv[0]);
+    void *in[3] = {NULL, NULL, NULL}, *ops = NULL, *out = NULL;
+    size_t bytes[3] = {0, 0, 0}, nops = 0, obytes = 0;
+    for (int k = 0; k < 3; k++) get_buffer(env, argv[1 + k], &in[k], &bytes[k]);
+    get_buffer(env, argv[4], &ops, &nops);
+    if (!get_buffer(env, argv[5], &out, &obytes) || !in[0]) return ret_null(env);
+    eoc_params p;
+    if (eoc_global_params(&p) != EOC_OK) return ret_null(env);
+    const size_t row = (size_t)(p.n + 1) * 4;
+    if (bytes[0] % row || obytes != bytes[0]) return ret_null(env);
+    const size_t count = bytes[0] / row;
+    for (int k = 1; k < 3; k++)
+        if (in[k] && bytes[k] != bytes[0]) return ret_null(env);
+    if (ops && nops != count) return ret_null(env);
+    uint64_t ticket = 0;
+    if (eoc_global_gate_batch_submit(op, (const uint8_t *)ops, (const int32_t *)in[0], (const int32_t *)in[1],
+                                     (const int32_t *)in[2], (int32_t *)out, count, &ticket) != EOC_OK)
+        return ret_null(env);
+    napi_value t;
+    NAPI_OK(napi_create_double(env, (double)ticket, &t));
+    return t;
+}
+static napi_value n_gateBatchWait(napi_env env, napi_callback_info info)
+{ /* (ticket) -> 0, or a negative error code */
+    ARGS(1);
+    double t = 0;
+    napi_get_value_double(env, argv[0], &t);
+    return ret_int(env, eoc_gate_batch_wait((uint64_t)t));
+}
 static napi_value n_circuitRun(napi_env env, napi_callback_info info)
 { /* (Int32Array gates [5 per gate: op, in0, in1, in2, out], Buffer wires [nWires][instances][n+1], nWires, instances)
    * -> the same Buffer, evaluated in place (eoc_global_circuit_run), or null on error */
@@ -339,7 +395,8 @@ static napi_value init(napi_env env, napi_value exports)
         {"sampleInts", n_sampleInts}, {"encryptBits", n_encryptBits}, {"decryptBits", n_decryptBits},
         {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount}, {"circuitRun", n_circuitRun},
         {"netlistOptimize", n_netlistOptimize}, {"circuitBootstraps", n_circuitBootstraps}, {"engineCount", n_engineCount},
-        {"setDevices", n_setDevices},
+        {"setDevices", n_setDevices}, {"hostAlloc", n_hostAlloc}, {"gateBatchSubmit", n_gateBatchSubmit},
+        {"gateBatchWait", n_gateBatchWait},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++) {
         napi_value fn;

@@ -66,6 +66,27 @@ assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptString
   assert.strictEqual(B.gateBatch(0, one, one.slice(0, w), null), null);
   assert.strictEqual(B.decryptBits(B.gateBatch(14, null, null, null, null, 3)).join(''), '111');   // bootsCONSTANT
 }
+// asynchronous batches on pinned Buffers: four batches kept two deep in flight equal the synchronous call's bytes
+{
+  const B = tfhe.backend, w = B.sampleInts() * 4, n = 600;
+  const mk = seed => { const bits = Buffer.alloc(n); for (let i = 0; i < n; i++) bits[i] = (i * seed + (i >> 2)) & 1; return B.encryptBits(bits); };
+  const jobs = [3, 5, 7, 11].map(seed => {
+    const a = mk(seed), b = mk(seed + 1), pa = B.hostAlloc(n * w), pb = B.hostAlloc(n * w), po = B.hostAlloc(n * w);
+    assert.ok(pa && pb && po, 'hostAlloc failed');
+    a.copy(pa); b.copy(pb);
+    return { a, b, pa, pb, po, op: seed % 2 ? tfhe.OP.XOR : tfhe.OP.NAND };
+  });
+  const tickets = [];
+  jobs.forEach((j, k) => {
+    if (k >= 2) assert.strictEqual(B.gateBatchWait(tickets[k - 2]), 0);
+    const t = B.gateBatchSubmit(j.op, j.pa, j.pb, null, null, j.po);
+    assert.ok(t !== null, 'gateBatchSubmit failed');
+    tickets.push(t);
+  });
+  tickets.forEach(t => assert.strictEqual(B.gateBatchWait(t), 0));
+  jobs.forEach((j, k) => assert.ok(Buffer.from(j.po).equals(B.gateBatch(j.op, j.a, j.b, null)), `async batch ${k}`));
+  assert.strictEqual(B.gateBatchSubmit(0, jobs[0].a, jobs[0].b, null, null, jobs[0].po), null);   // pageable operands are refused
+}
 assert.strictEqual(tfhe.backend.engineCount(), 2);
 tfhe.backend.resetGateKey();
 console.log('node gpu tests OK');

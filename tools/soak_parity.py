@@ -32,7 +32,7 @@ while time.time() < t_end:
     eng.load_cloud_key(sk)
     orc = ol.Oracle(pset, seed, n_override=n)
     for _ in range(4):
-        kind = rng.choice(os.environ.get("SOAK_KINDS", "uniform,mixed,circuit,host").split(","))
+        kind = rng.choice(os.environ.get("SOAK_KINDS", "uniform,mixed,circuit,host,async").split(","))
         count = int(rng.choice([1, 2, 63, 64, 65, 127, 1023, 1024, 1025, int(rng.integers(1, 2600))]))
         c = [sk.encrypt_bits(rng.integers(0, 2, count).astype(np.uint8), int(rng.integers(1, 1 << 30)), 0) for _ in range(3)]
         if kind == "circuit":
@@ -62,7 +62,29 @@ while time.time() < t_end:
                 ops = rng.choice(np.array(BOOT + FREE, np.uint8), count)
                 op = 0
             want = orc.gate_batch(op, c[0], c[1], c[2], ops=ops)
-            if kind == "host":
+            if kind == "async":
+                # three submissions kept two deep in flight on pinned buffers (eoc_gate_batch_submit / _wait)
+                eoc.gpu_shutdown()
+                eoc.gpu_init(p, devices=[0] * int(rng.integers(1, 4)))
+                eoc.upload_cloud_key(sk)
+                pins = [[eoc.PinnedArray(c[0].shape) for _ in range(4)] for _b in range(3)]
+                wants, tks = [], []
+                for b, pb in enumerate(pins):
+                    for k in range(3):
+                        pb[k].array[:] = np.roll(c[k], b, axis=0)
+                    wants.append(orc.gate_batch(op, pb[0].array, pb[1].array, pb[2].array, ops=ops))
+                    if b >= 2:
+                        eoc.gate_batch_wait(tks[b - 2])
+                    tks.append(eoc.gate_batch_submit(op, pb[0].array, pb[1].array, pb[2].array, ops=ops, out=pb[3].array))
+                for t in tks:
+                    eoc.gate_batch_wait(t)
+                got = np.concatenate([pb[3].array for pb in pins])
+                want = np.concatenate(wants)
+                for pb in pins:
+                    for a in pb:
+                        a.free()
+                eoc.gpu_shutdown()
+            elif kind == "host":
                 eoc.gpu_shutdown()
                 eoc.gpu_init(p, devices=[0] * int(rng.integers(1, 4)))
                 eoc.upload_cloud_key(sk)
