@@ -634,11 +634,8 @@ static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint3
     else if (bb == 2 && t == 8 && nw == 4) EOC_KS_LAUNCH(2, 8, 8, 4, 64);
     else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 12, 4, 64);
     else if (bb == 2 && t == 8 && nw == 8) EOC_KS_LAUNCH(2, 8, 8, 2, 128);
-    else {
-        eoc_set_error("key switch: unsupported (basebit=%d, t=%d, n=%d); supported: basebit 2, t 8, n <= 1023",
-                      bb, t, e->p.n);
-        return EOC_ERR_ARG;
-    }
+    else // any other shape (no default set has one): the plain one-thread-per-word form
+        hipLaunchKernelGGL(k_keyswitch_generic, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
 #undef EOC_KS_LAUNCH
     HIP_TRY(hipGetLastError());
     return EOC_OK;

@@ -1092,4 +1092,27 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void k_keyswitch(const G
     }
 }
 
+// Key switch for any (basebit <= 4, t) the tiled kernels above are not instantiated for (both default parameter sets use
+// basebit 2, t 8 and never come here): one thread per output word, rows read straight from the key image.  A plain,
+// slow, exact form -- lweKeySwitchTranslate_fromArray as written.  The output row holds (0, ..., 0, b')
+// when it starts (k_ks_init or the blind rotate's epilogue wrote it).  grid: x = S, y = gates; block = 256
+__global__ __launch_bounds__(256) void k_keyswitch_generic(const GateDesc *__restrict__ descs, KSArgs A)
+{
+    const GateDesc d = descs[blockIdx.y];
+    const uint32_t s = blockIdx.x, job = d.job_base + s;
+    const int base1 = (1 << A.basebit) - 1;
+    int32_t *o = d.out + (size_t)s * (A.n + 1);
+    for (int m = threadIdx.x; m <= A.n; m += 256) {
+        uint32_t acc = (uint32_t)o[m];
+        for (int i = 0; i < kN; i++) {
+            const uint32_t ub = A.ubarT[(size_t)i * A.jstride + job];
+            for (int j = 0; j < A.t; j++) {
+                const uint32_t dg = (ub >> (32 - (j + 1) * A.basebit)) & (uint32_t)base1;
+                if (dg) acc -= (uint32_t)A.ksk[(((size_t)i * A.t + j) * base1 + (dg - 1)) * A.n1p + m];
+            }
+        }
+        o[m] = (int32_t)acc;
+    }
+}
+
 } // namespace eoc

@@ -343,19 +343,35 @@ def test_custom_parameter_shapes_bit_exact(eoc, n, l, bgbit):
     eng.close()
 
 
-def test_unsupported_keyswitch_shape_fails_loudly(eoc):
-    """key-switch kernels exist for basebit = 2, t = 8 (both reference sets); anything else is an error, not a
-    wrong answer"""
+@pytest.mark.parametrize("ks_t,ks_basebit,n", [(4, 3, 8), (5, 1, 11), (3, 4, 300), (10, 3, 17)])
+def test_other_keyswitch_shapes(eoc, ks_t, ks_basebit, n):
+    """the tiled key-switch kernels exist for basebit = 2, t = 8 (both reference sets); every other (basebit <= 4, t)
+    takes the plain one-thread-per-word kernel (round 2 refused them) -- NAND, MUX and the stand-alone key switch
+    against the oracle"""
     torch = torch_cuda()
     p = eoc.default_params(0)
-    p.n, p.ks_t, p.ks_basebit = 8, 4, 3
+    p.n, p.ks_t, p.ks_basebit = n, ks_t, ks_basebit
     sk = eoc.SecretKey(p, 3)
+    orc = ol.Oracle(0, 3, n_override=n)
+    orc.p.ks_t, orc.p.ks_basebit = ks_t, ks_basebit
+    orc.gen_cloud()
+    assert np.array_equal(sk.ksk, orc.ksk)
     eng = eoc.Engine(p)
     eng.load_cloud_key(sk)
-    c = to_dev(sk.encrypt_bits([0, 1], 1, 0))
-    out = torch.empty_like(c)
-    with pytest.raises(eoc.EocError, match="key switch: unsupported"):
-        eng.gate_batch_device(0, c.data_ptr(), c.data_ptr(), None, out.data_ptr(), 2)
+    cnt = 9
+    rng = np.random.default_rng(5)
+    c = [sk.encrypt_bits(rng.integers(0, 2, cnt), 70 + k, 0) for k in range(3)]
+    d = [to_dev(x) for x in c]
+    out = torch.empty_like(d[0])
+    for name in ("NAND", "MUX"):
+        eng.gate_batch_device(eoc.OPS[name], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), cnt)
+        sync()
+        assert np.array_equal(out.cpu().numpy(), orc.gate_batch(ol.OPS[name], c[0], c[1], c[2] if name == "MUX" else None)), name
+    u = rng.integers(-2**31, 2**31, (cnt, N + 1)).astype(np.int32)
+    d_o = dev_empty((cnt, n + 1), torch.int32)
+    eng.keyswitch_device(to_dev(u).data_ptr(), d_o.data_ptr(), cnt)
+    sync()
+    assert np.array_equal(d_o.cpu().numpy(), np.stack([orc.keyswitch(x) for x in u]))
     eng.close()
 
 
