@@ -324,13 +324,46 @@ int slot_circuit_block(Slot &s, const eoc_gate *gates, size_t n_gates, int32_t *
         s.grows++;
     }
     hipStream_t st = s.st[0];
-    // strided block copy: row w of the device array holds instances [lo, hi) of wire w
-    HIP_TRY(hipMemcpy2DAsync(s.d_wires, blk * stride_ints * 4, wires + lo * stride_ints, instances * stride_ints * 4,
-                             blk * stride_ints * 4, n_wires, hipMemcpyHostToDevice, st));
-    int rc = eoc_circuit_run_device(s.e, gates, n_gates, s.d_wires, n_wires, blk, st);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(wires + lo * stride_ints, instances * stride_ints * 4, s.d_wires, blk * stride_ints * 4,
-                             blk * stride_ints * 4, n_wires, hipMemcpyDeviceToHost, st));
+    // Only the wires that matter cross PCIe: host -> device the wires some gate READS BEFORE any gate has written them
+    // (the circuit's inputs), device -> host the wires some gate WRITES; a wire nobody touches keeps the caller's bytes
+    // and a wire that is overwritten before it is read is never sent (an 8-bit adder moves 16 of its 57 wires in and
+    // 41 out).  Gates are evaluated in netlist order semantics (eoc_circuit_run_device levelises on hazards), so the
+    // scan below is in that order.  Consecutive wires travel as one strided copy: row w of the device array holds
+    // instances [lo, hi) of wire w.
+    std::vector<uint8_t> live_in(n_wires, 0), written(n_wires, 0);
+    for (size_t k = 0; k < n_gates; k++) {
+        const int32_t ins[3] = {gates[k].in0, gates[k].in1, gates[k].in2};
+        for (int a = 0; a < 3; a++)
+            if (ins[a] >= 0 && (size_t)ins[a] < n_wires && !written[ins[a]]) live_in[ins[a]] = 1;
+        if (gates[k].out >= 0 && (size_t)gates[k].out < n_wires) written[gates[k].out] = 1;
+    }
+    auto copy_runs = [&](const std::vector<uint8_t> &sel, bool to_device) -> int {
+        for (size_t w = 0; w < n_wires;) {
+            if (!sel[w]) {
+                w++;
+                continue;
+            }
+            size_t e = w;
+            while (e < n_wires && sel[e]) e++;
+            int32_t *dev = s.d_wires + w * blk * stride_ints;
+            int32_t *host = wires + (w * instances + lo) * stride_ints;
+            if (to_device)
+                HIP_TRY(hipMemcpy2DAsync(dev, blk * stride_ints * 4, host, instances * stride_ints * 4, blk * stride_ints * 4,
+                                         e - w, hipMemcpyHostToDevice, st));
+            else
+                HIP_TRY(hipMemcpy2DAsync(host, instances * stride_ints * 4, dev, blk * stride_ints * 4, blk * stride_ints * 4,
+                                         e - w, hipMemcpyDeviceToHost, st));
+            w = e;
+        }
+        return EOC_OK;
+    };
+    int rc = copy_runs(live_in, true);
+    if (rc == EOC_OK) rc = eoc_circuit_run_device(s.e, gates, n_gates, s.d_wires, n_wires, blk, st);
+    if (rc == EOC_OK) rc = copy_runs(written, false);
+    if (rc) {
+        (void)hipStreamSynchronize(st); // no copy may outlive the call
+        return rc;
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return EOC_OK;
 }

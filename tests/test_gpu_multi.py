@@ -78,8 +78,12 @@ def test_circuit_run_instances_stay_on_one_engine(eoc, ctx3):
     for i in range(4):
         wires[aw[0] + i] = sk.encrypt_bits(((A >> i) & 1).astype(np.uint8), 100 + i, 0)
         wires[bw[0] + i] = sk.encrypt_bits(((B >> i) & 1).astype(np.uint8), 200 + i, 0)
+    # a wire no gate touches keeps the caller's bytes, and so do the inputs (only live-in wires travel to the device,
+    # only written wires travel back)
+    wires = np.concatenate([wires, np.full((1, S, p.n + 1), 0x5A5A5A5A, np.int32)])
     ref = wires.copy()
     eoc.circuit_run(gates, wires, S)
+    assert np.array_equal(wires[-1], ref[-1]) and np.array_equal(wires[aw[0]: aw[0] + 4], ref[aw[0]: aw[0] + 4])
     tot = sum(sk.decrypt_bits(wires[sw[0] + i]).astype(np.int64) << i for i in range(5))
     assert np.array_equal(tot, A + B)
     # the oracle evaluates the same netlist gate by gate on the whole instance range
