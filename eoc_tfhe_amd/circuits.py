@@ -100,6 +100,85 @@ def min_max(nbits=8):
     return gates, nxt + 2 * nbits, a, b, mn, mx
 
 
+def subtractor(nbits=8):
+    """a - b mod 2^nbits with the final borrow (= a < b), LSB first: p_i = a_i XOR b_i, d_i = p_i XOR br_i,
+    br_{i+1} = MUX(p_i, b_i, br_i) (a_i != b_i: a borrow arises iff b_i = 1; equal bits pass the borrow on).
+    Bit 0 has no incoming borrow: d_0 = p_0, br_1 = ANDNY(a_0, b_0).  2 + 4 (nbits - 1) bootstraps.
+    Returns (gates, n_wires, a_wires, b_wires, diff_wires, borrow_wire)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    d = list(range(2 * nbits, 3 * nbits))
+    nxt = 3 * nbits
+    gates = [Gate(OPS["XOR"], a[0], b[0], -1, d[0]), Gate(OPS["ANDNY"], a[0], b[0], -1, nxt)]
+    br = nxt
+    nxt += 1
+    for i in range(1, nbits):
+        p, new = nxt, nxt + 1
+        nxt += 2
+        gates.append(Gate(OPS["XOR"], a[i], b[i], -1, p))
+        gates.append(Gate(OPS["XOR"], p, br, -1, d[i]))
+        gates.append(Gate(OPS["MUX"], p, b[i], br, new))
+        br = new
+    return gates, nxt, a, b, d, br
+
+
+def multiplier(nbits=4):
+    """a * b -> 2 nbits product bits, LSB first: nbits^2 AND partial products, then nbits - 1 shifted ripple-carry rows
+    (row r adds the partial products a_j b_r at weight r + j into the running sum; the low bit of every running sum is
+    final).  All partial products are one level; the rows chain through their carries.
+    Returns (gates, n_wires, a_wires, b_wires, product_wires)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    nxt = 2 * nbits
+    gates = []
+    pp = [[0] * nbits for _ in range(nbits)]            # pp[r][j] = a_j AND b_r
+    for r in range(nbits):
+        for j in range(nbits):
+            gates.append(Gate(OPS["AND"], a[j], b[r], -1, nxt))
+            pp[r][j] = nxt
+            nxt += 1
+    prod = [pp[0][0]]
+    acc = pp[0][1:]                                     # running sum above the bits already final (nbits - 1 wires)
+    top = None                                          # its carry-out bit, None while it is known to be zero
+    for r in range(1, nbits):
+        row = pp[r]                                     # nbits wires, aligned with acc[0]
+        new_acc, carry = [], None
+        for j in range(nbits):
+            x = acc[j] if j < len(acc) else top         # bit j of the running sum (None = constant 0)
+            y = row[j]
+            if x is None and carry is None:
+                sbit, cout = y, None
+            elif x is None or carry is None:            # half adder
+                z = carry if x is None else x
+                sbit, cout = nxt, nxt + 1
+                nxt += 2
+                gates.append(Gate(OPS["XOR"], z, y, -1, sbit))
+                gates.append(Gate(OPS["AND"], z, y, -1, cout))
+            else:                                       # full adder: 2 XOR + 2 AND + 1 OR
+                p, g, pc = nxt, nxt + 1, nxt + 2
+                sbit, cout = nxt + 3, nxt + 4
+                nxt += 5
+                gates.append(Gate(OPS["XOR"], x, y, -1, p))
+                gates.append(Gate(OPS["AND"], x, y, -1, g))
+                gates.append(Gate(OPS["XOR"], p, carry, -1, sbit))
+                gates.append(Gate(OPS["AND"], p, carry, -1, pc))
+                gates.append(Gate(OPS["OR"], g, pc, -1, cout))
+            new_acc.append(sbit)
+            carry = cout
+        prod.append(new_acc[0])
+        acc, top = new_acc[1:], carry
+    prod += acc
+    if top is not None:
+        prod.append(top)
+    else:
+        z = nxt
+        nxt += 1
+        gates.append(Gate(OPS["CONST0"], -1, -1, -1, z))
+        prod.append(z)
+    assert len(prod) == 2 * nbits
+    return gates, nxt, a, b, prod
+
+
 # ---- plaintext semantics and netlist rewriting -----------------------------------------------------
 
 _NAMES = {v: k for k, v in OPS.items()}

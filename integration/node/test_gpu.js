@@ -66,6 +66,20 @@ assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptString
   assert.strictEqual(B.gateBatch(0, one, one.slice(0, w), null), null);
   assert.strictEqual(B.decryptBits(B.gateBatch(14, null, null, null, null, 3)).join(''), '111');   // bootsCONSTANT
 }
+// word-level circuits added in round 3: 4-bit subtraction and multiplication over 64 instances, one circuitRun each
+{
+  const B = tfhe.backend, S = 64, nb = 4, w = B.sampleInts() * 4, plane = S * w;
+  const A = [...Array(S).keys()].map(i => (i * 7 + 3) & 15), Bv = [...Array(S).keys()].map(i => (i * 5 + 9) & 15);
+  const enc = vals => Buffer.concat([...Array(nb).keys()].map(k => B.encryptBits(Buffer.from(vals.map(v => (v >> k) & 1)))));
+  const dec = (buf, nplanes) => { const t = new Array(S).fill(0); for (let k = 0; k < nplanes; k++) { const bits = B.decryptBits(buf.slice(k * plane, (k + 1) * plane)); for (let i = 0; i < S; i++) t[i] |= bits[i] << k; } return t; };
+  const d = dec(tfhe.subtractBitsBatch(enc(A), enc(Bv), nb, S), nb + 1);
+  const p = dec(tfhe.multiplyBitsBatch(enc(A), enc(Bv), nb, S), 2 * nb);
+  for (let i = 0; i < S; i++) {
+    assert.strictEqual(d[i] & 15, (A[i] - Bv[i]) & 15);
+    assert.strictEqual(d[i] >> 4, A[i] < Bv[i] ? 1 : 0);
+    assert.strictEqual(p[i], A[i] * Bv[i]);
+  }
+}
 // asynchronous batches on pinned Buffers: four batches kept two deep in flight equal the synchronous call's bytes
 {
   const B = tfhe.backend, w = B.sampleInts() * 4, n = 600;

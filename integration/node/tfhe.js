@@ -80,6 +80,44 @@ Tfhe.minMaxNetlist = nbits => {
   for (let i = 0; i < nbits; i++) { min.push(nl.gate(OP.MUX, lt, a + i, b + i)); max.push(nl.gate(OP.MUX, lt, b + i, a + i)); }
   return { nl, a, b, lt, min, max };
 };
+// a - b mod 2^nbits and the final borrow (= a < b), LSB first: d_i = a_i ^ b_i ^ br_i, br_{i+1} = MUX(a_i ^ b_i, b_i, br_i)
+Tfhe.subtractorNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), diff = [];
+  diff.push(nl.gate(OP.XOR, a, b));
+  let br = nl.gate(OP.ANDNY, a, b);
+  for (let i = 1; i < nbits; i++) {
+    const p = nl.gate(OP.XOR, a + i, b + i);
+    diff.push(nl.gate(OP.XOR, p, br));
+    br = nl.gate(OP.MUX, p, b + i, br);
+  }
+  return { nl, a, b, diff, borrow: br };
+};
+// a * b -> 2 nbits bits, LSB first: nbits^2 AND partial products, nbits - 1 shifted ripple-carry rows
+Tfhe.multiplierNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  const pp = [...Array(nbits).keys()].map(r => [...Array(nbits).keys()].map(j => nl.gate(OP.AND, a + j, b + r)));
+  const prod = [pp[0][0]];
+  let acc = pp[0].slice(1), top = null;
+  for (let r = 1; r < nbits; r++) {
+    const next = [];
+    let carry = null;
+    for (let j = 0; j < nbits; j++) {
+      const x = j < acc.length ? acc[j] : top, y = pp[r][j];
+      if (x === null && carry === null) { next.push(y); carry = null; continue; }
+      if (x === null || carry === null) {
+        const z = x === null ? carry : x;
+        next.push(nl.gate(OP.XOR, z, y)); carry = nl.gate(OP.AND, z, y);
+      } else {
+        const p = nl.gate(OP.XOR, x, y), g = nl.gate(OP.AND, x, y);
+        next.push(nl.gate(OP.XOR, p, carry)); carry = nl.gate(OP.OR, g, nl.gate(OP.AND, p, carry));
+      }
+    }
+    prod.push(next[0]); acc = next.slice(1); top = carry;
+  }
+  prod.push(...acc);
+  prod.push(top === null ? nl.gate(OP.CONST0, -1) : top);
+  return { nl, a, b, prod };
+};
 // run a netlist over `instances` instances: inputs = {firstWire: Buffer [k][instances][n+1]}; returns the wire Buffer
 Tfhe.runNetlist = (nl, inputs, instances, outputs) => {
   const w = B.sampleInts() * 4, plane = instances * w;
@@ -121,6 +159,16 @@ Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {
   const { nl, a, b, sum } = Tfhe.adderNetlist(nbits);
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
   return wires && Buffer.concat(sum.map(wi => planes(wires, wi, 1, instances)));   // [nbits + 1][instances][n+1]
+};
+Tfhe.subtractBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [nbits + 1][instances][n+1]: difference bits, then the borrow
+  const { nl, a, b, diff, borrow } = Tfhe.subtractorNetlist(nbits);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  return wires && Buffer.concat([...diff, borrow].map(wi => planes(wires, wi, 1, instances)));
+};
+Tfhe.multiplyBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [2 nbits][instances][n+1]
+  const { nl, a, b, prod } = Tfhe.multiplierNetlist(nbits);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  return wires && Buffer.concat(prod.map(wi => planes(wires, wi, 1, instances)));
 };
 Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1] (one instance)
   const nbits = X.length / (B.sampleInts() * 4);

@@ -206,3 +206,25 @@ def test_native_optimizer_matches_python(built_lib):
     with pytest.raises(eoc.EocError):
         eoc.netlist_optimize([Gate(OPS["AND"], 3, 1, -1, 2), Gate(OPS["OR"], 0, 1, -1, 3)], [2])
     assert eoc.netlist_optimize([], []) == []
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 4, 5])
+def test_subtractor_and_multiplier_all_inputs(nbits):
+    """round 3: a - b (with the final borrow = a < b) and a * b (schoolbook: nbits^2 partial products + nbits - 1
+    ripple rows), every input pair; the host-side optimiser (NOT folding, MUX fusion, dead gates) keeps their meaning"""
+    A, B, S = _words(nbits)
+    gates, nw, a, b, d, br = c.subtractor(nbits)
+    assert circuit_bootstraps(gates) == 2 + 4 * (nbits - 1)
+    w = np.zeros((nw, S), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    r = c.evaluate_plain(gates, w)
+    assert np.array_equal(_value(r, d), (A - B) % (1 << nbits)) and np.array_equal(r[br], (A < B).astype(np.uint8))
+    gates, nw, a, b, p = c.multiplier(nbits)
+    w = np.zeros((nw, S), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    assert np.array_equal(_value(c.evaluate_plain(gates, w), p), A * B)
+    opt = c.optimize(gates, p)
+    assert circuit_bootstraps(opt) <= circuit_bootstraps(gates)
+    assert np.array_equal(_value(c.evaluate_plain(opt, w), p), A * B)

@@ -425,3 +425,26 @@ def test_mixed_batch_capture_and_replay(eoc):
     sync()
     assert np.array_equal(bout.cpu().numpy()[:S], orc.gate_batch(0, c[0], c[1]))
     eng.close()
+
+
+def test_subtractor_and_multiplier_bit_exact(eoc):
+    """round 3 word-level circuits on the engine: 5-bit subtractor and 3-bit multiplier (30 bootstraps, CONST-free) over
+    21 instances, every written wire against the oracle, results against plaintext"""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng, orc = _setup(eoc, 0, 6, 28)
+    S = 21
+    rng = np.random.default_rng(12)
+    for build, nbits, expect in ((circuits.subtractor, 5, lambda a, b: (a - b) % 32), (circuits.multiplier, 3, lambda a, b: a * b)):
+        res = build(nbits)
+        gates, n_wires, aw, bw, outw = res[0], res[1], res[2], res[3], res[4]
+        A, B = rng.integers(0, 1 << nbits, S), rng.integers(0, 1 << nbits, S)
+        wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+        for i in range(nbits):
+            wires[aw[i]] = sk.encrypt_bits((A >> i) & 1, 300 + i, 0)
+            wires[bw[i]] = sk.encrypt_bits((B >> i) & 1, 400 + i, 0)
+        got = eoc_run(eoc, eng, gates, wires, n_wires, S)
+        want = _oracle_run(orc, gates, wires)
+        for g in gates:
+            assert np.array_equal(got[g.out], want[g.out]), (build.__name__, g.out)
+        val = sum(sk.decrypt_bits(got[w]).astype(np.int64) << i for i, w in enumerate(outw))
+        assert np.array_equal(val, expect(A, B)), build.__name__
