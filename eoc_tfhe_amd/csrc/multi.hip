@@ -824,8 +824,9 @@ extern "C" int eoc_rccl_selftest(int device, size_t bytes)
     hipStream_t st = nullptr;
     ncclComm_t comm = nullptr;
     ncclResult_t r = ncclSuccess;
+    // (the NULL-stream fill is drained before the non-blocking stream below may touch dst: such streams do not wait for it)
     if (hipMemcpy(src, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dst, 0, bytes) != hipSuccess ||
-        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        hipDeviceSynchronize() != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
         eoc_set_error("eoc_rccl_selftest: HIP set-up failed");
         rc = EOC_ERR_HIP;
     }
