@@ -199,6 +199,14 @@ def lib():
         "eoc_global_circuit_run": (C.c_int, [vp, sz, vp, sz, sz]),
         "exportSecretKey": (vp, []),
         "importSecretKey": (C.c_int, [C.c_char_p]),
+        # f2, server side: the cloud ("public") key on the global context
+        "exportCloudKey": (vp, []),
+        "importCloudKey": (C.c_int, [C.c_char_p]),
+        "exportCloudKeyToFile": (C.c_int, [C.c_char_p]),
+        "importCloudKeyFromFile": (C.c_int, [C.c_char_p]),
+        "eoc_global_cloud_key_export": (sz, [vp, sz]),
+        "eoc_global_import_cloud_key_blob": (C.c_int, [vp, sz]),
+        "eoc_global_key_mode": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -633,6 +641,72 @@ def circuit_run(gates, wires, instances):
     return wires
 
 
+# ---- raw-buffer calls on the string API's global key (what the Node / Lua batch wrappers use) ------------------
+def global_key_mode():
+    return lib().eoc_global_key_mode()
+
+
+def global_params():
+    p = Params()
+    _check(lib().eoc_global_params(C.byref(p)), "eoc_global_params")
+    return p
+
+
+def global_import_cloud_key_blob(blob):
+    """Server side: install an EOCCK1 blob (numpy uint8 / bytes) as the cloud-key-only global context."""
+    blob = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if isinstance(blob, (bytes, bytearray)) else blob, np.uint8)
+    _check(lib().eoc_global_import_cloud_key_blob(blob.ctypes.data, blob.size), "eoc_global_import_cloud_key_blob")
+
+
+def global_cloud_key_export():
+    need = lib().eoc_global_cloud_key_export(None, 0)
+    if not need:
+        raise EocError("eoc_global_cloud_key_export: no key on the global context")
+    buf = np.empty(need, np.uint8)
+    if lib().eoc_global_cloud_key_export(buf.ctypes.data, need) != need:
+        raise EocError("eoc_global_cloud_key_export failed")
+    return buf
+
+
+def global_encrypt_bits(bits):
+    bits = np.ascontiguousarray(np.asarray(bits).ravel(), np.uint8)
+    out = np.empty((bits.size, global_params().n + 1), np.int32)
+    _check(lib().eoc_global_encrypt_bits(bits.ctypes.data, bits.size, out.ctypes.data), "eoc_global_encrypt_bits")
+    return out
+
+
+def global_decrypt_bits(cts):
+    cts = np.ascontiguousarray(cts, np.int32).reshape(-1, global_params().n + 1)
+    out = np.empty(cts.shape[0], np.uint8)
+    _check(lib().eoc_global_decrypt_bits(cts.ctypes.data, cts.shape[0], out.ctypes.data), "eoc_global_decrypt_bits")
+    return out
+
+
+def global_gate_batch(op, in0, in1=None, in2=None, ops=None):
+    """eoc_global_gate_batch: brings the GPU engine(s) up behind the global key on first use."""
+    in0 = np.ascontiguousarray(in0, np.int32)
+    in1c = None if in1 is None else np.ascontiguousarray(in1, np.int32)
+    in2c = None if in2 is None else np.ascontiguousarray(in2, np.int32)
+    opsc = None if ops is None else np.ascontiguousarray(ops, np.uint8)
+    for a in (in1c, in2c):
+        if a is not None and a.shape != in0.shape:
+            raise EocError("global_gate_batch: operand shapes differ")
+    out = np.empty_like(in0)
+    _check(lib().eoc_global_gate_batch(int(op), None if opsc is None else opsc.ctypes.data, in0.ctypes.data,
+                                       None if in1c is None else in1c.ctypes.data,
+                                       None if in2c is None else in2c.ctypes.data, out.ctypes.data, in0.shape[0]),
+           "eoc_global_gate_batch")
+    return out
+
+
+def global_circuit_run(gates, wires, instances):
+    wires = np.ascontiguousarray(wires, np.int32)
+    arr = (Gate * len(gates))(*gates)
+    _check(lib().eoc_global_circuit_run(C.addressof(arr), len(gates), wires.ctypes.data, wires.shape[0], instances),
+           "eoc_global_circuit_run")
+    return wires
+
+
 class Tfhe:
     """String façade in the shape of ao-tfhe/tfhe.lua (Tfhe.* -> backend.*), for the Boolean path."""
 
@@ -695,6 +769,28 @@ class Tfhe:
     @staticmethod
     def importSecretKey(b64):
         return lib().importSecretKey(b64.encode())
+
+    # ---- the cloud ("public") key: exported by the client, imported by a server that never sees the secret key ----
+    @staticmethod
+    def exportCloudKey():
+        return _take_str(lib().exportCloudKey())
+
+    @staticmethod
+    def importCloudKey(b64):
+        return lib().importCloudKey(b64.encode())
+
+    @staticmethod
+    def exportCloudKeyToFile(path):
+        return lib().exportCloudKeyToFile(os.fsencode(path))
+
+    @staticmethod
+    def importCloudKeyFromFile(path):
+        return lib().importCloudKeyFromFile(os.fsencode(path))
+
+    @staticmethod
+    def keyMode():
+        """0 no key, 1 secret + cloud key (client / single host), 2 cloud key only (server)"""
+        return lib().eoc_global_key_mode()
 
     # ---- Boolean path -----------------------------------------------------------------------------
     @staticmethod

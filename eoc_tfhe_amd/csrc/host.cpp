@@ -531,17 +531,32 @@ uint64_t mix64(uint64_t z) { return Stream::fin(z); }
 int ensure_engine_locked()
 {
     GlobalCtx &c = ctx();
-    if (!c.sk) return EOC_ERR_NO_KEY;
+    const eoc_params *p = c.params();
+    if (!p) return EOC_ERR_NO_KEY;
     if (c.engine_ready) return EOC_OK;
+    // the cloud key of a full key set, or the imported one of a cloud-key-only (server) context
+    const std::vector<int32_t> &bk = c.sk ? c.sk->bk : c.ck->bk, &ksk = c.sk ? c.sk->ksk : c.ck->ksk;
+    if (bk.empty() || ksk.empty()) return EOC_ERR_NO_KEY;
     if (!eoc_global_engine()) { // EOC_TFHE_DEVICES = "all" | "0,1,..." puts several GPUs behind the one global key
-        int rc = eoc_gpu_init_from_env(&c.sk->p);
+        int rc = eoc_gpu_init_from_env(p);
         if (rc) return rc;
     }
-    if (c.sk->bk.empty() || c.sk->ksk.empty()) return EOC_ERR_NO_KEY;
-    int rc = eoc_upload_cloud_key_arrays(c.sk->bk.data(), c.sk->ksk.data());
+    int rc = eoc_upload_cloud_key_arrays(bk.data(), ksk.data());
     if (rc) return rc;
     c.engine_ready = true;
     return EOC_OK;
+}
+void drop_keys_locked()
+{
+    GlobalCtx &c = ctx();
+    eoc_secret_key_free(c.sk);
+    c.sk = nullptr;
+    delete c.ck;
+    c.ck = nullptr;
+    explicit_bzero(c.enc_key, sizeof c.enc_key);
+    c.enc_secure = false;
+    c.enc_seed = c.enc_counter = 0;
+    c.engine_ready = false;
 }
 } // namespace eoc_host
 
@@ -551,7 +566,7 @@ extern "C" const char *generateGateKey(int minimum_lambda, uint64_t seed)
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (c.sk) { // eoc-tfhe-run.cpp:245-249
+    if (c.sk || c.ck) { // eoc-tfhe-run.cpp:245-249 (a cloud-key-only context counts: one key per process)
         fprintf(stdout, "Secret key is already generated for this instance...\n");
         return nullptr;
     }
@@ -582,12 +597,7 @@ extern "C" void resetGateKey(void)
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    eoc_secret_key_free(c.sk);
-    c.sk = nullptr;
-    explicit_bzero(c.enc_key, sizeof c.enc_key);
-    c.enc_secure = false;
-    c.enc_seed = c.enc_counter = 0;
-    c.engine_ready = false;
+    drop_keys_locked();
     eoc_gpu_shutdown();
 }
 
@@ -610,13 +620,14 @@ extern "C" const char *constantBit(int bit)
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) { // the sample length comes from the key's parameter set
-        fprintf(stderr, "Secret key not initialized. Generate the secret key first.\n");
+    const eoc_params *p = c.params();
+    if (!p) { // the sample length comes from the key's parameter set (a cloud key is enough: nothing secret is involved)
+        fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
         return nullptr;
     }
-    std::vector<int32_t> ct(c.sk->p.n + 1, 0); // lweNoiselessTrivial(+-1/8)
-    ct[c.sk->p.n] = bit ? (int32_t)(1u << 29) : (int32_t)(0u - (1u << 29));
-    return sample_to_b64(ct.data(), c.sk->p.n, 0.0);
+    std::vector<int32_t> ct(p->n + 1, 0); // lweNoiselessTrivial(+-1/8)
+    ct[p->n] = bit ? (int32_t)(1u << 29) : (int32_t)(0u - (1u << 29));
+    return sample_to_b64(ct.data(), p->n, 0.0);
 }
 
 extern "C" int decryptBit(const char *b64ct, const char *)
@@ -639,12 +650,12 @@ static const char *gate_strings(int op, const char *c1, const char *c2, const ch
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) { // eoc-tfhe-run.cpp:465-468
+    if (!c.params()) { // eoc-tfhe-run.cpp:465-468: the gates need the PUBLIC (cloud) key only, as addCiphertexts does
         fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
         return nullptr;
     }
     if (ensure_engine_locked()) return nullptr; // no GPU: no gates (message already on stderr)
-    const int n = c.sk->p.n;
+    const int n = c.params()->n;
     std::vector<int32_t> a, b, cc, out(n + 1);
     if (!b64_to_sample(c1, n, a, nullptr) || (op != EOC_NOT && !b64_to_sample(c2, n, b, nullptr)) ||
         (op == EOC_MUX && !b64_to_sample(c3, n, cc, nullptr))) {
@@ -671,8 +682,8 @@ extern "C" int eoc_global_params(eoc_params *out)
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk || !out) return EOC_ERR_NO_KEY;
-    *out = c.sk->p;
+    if (!c.params() || !out) return EOC_ERR_NO_KEY;
+    *out = *c.params();
     return EOC_OK;
 }
 extern "C" int eoc_global_encrypt_bits(const uint8_t *bits, size_t count, int32_t *cts)
@@ -704,7 +715,7 @@ extern "C" int eoc_global_gate_batch(int op, const uint8_t *ops, const int32_t *
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) {
+    if (!c.params()) {
         fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
         return EOC_ERR_NO_KEY;
     }
@@ -718,7 +729,7 @@ extern "C" int eoc_global_gate_batch_submit(int op, const uint8_t *ops, const in
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) {
+    if (!c.params()) {
         fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
         return EOC_ERR_NO_KEY;
     }
@@ -731,7 +742,10 @@ extern "C" int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) return EOC_ERR_NO_KEY;
+    if (!c.params()) {
+        fprintf(stderr, "Public key not initialized. Generate the public key first.\n");
+        return EOC_ERR_NO_KEY;
+    }
     int rc = ensure_engine_locked();
     if (rc) return rc;
     return eoc_circuit_run(gates, n_gates, wires, n_wires, instances);

@@ -17,6 +17,13 @@ struct eoc_secret_key {
     std::vector<int32_t> lwe, tlwe, bk, ksk;
 };
 
+// TFheGateBootstrappingCloudKeySet (the reference's globalPublicKey, ao-tfhe/eoc-tfhe-run.cpp:39,232-234): everything an
+// evaluating server needs and nothing secret -- parameters, the bootstrapping key in torus form, the key-switch key
+struct eoc_cloud_key {
+    eoc_params p;
+    std::vector<int32_t> bk, ksk;
+};
+
 namespace eoc_host {
 
 std::string b64_encode(const unsigned char *d, size_t len);
@@ -32,6 +39,10 @@ uint64_t mix64(uint64_t z);
 struct GlobalCtx {
     std::mutex mu;
     eoc_secret_key *sk = nullptr;
+    // cloud-key-only (server) mode: set by importCloudKey / eoc_global_import_cloud_key_blob, sk stays null.  Gates,
+    // constants, circuits and the linear ops work; everything that needs the secret key answers as if no key existed.
+    eoc_cloud_key *ck = nullptr;
+    const eoc_params *params() const { return sk ? &sk->p : ck ? &ck->p : nullptr; }
     uint64_t enc_seed = 0, enc_counter = 0;
     bool enc_secure = false;    // encryption randomness from ChaCha20 keyed by enc_key (fresh per process, from
     uint8_t enc_key[32] = {0};  // getrandom(2), independent of the key material) instead of the seeded test streams
@@ -47,5 +58,6 @@ void lwe_encrypt_secure(const eoc_secret_key *sk, const uint8_t enc_key[32], uin
 bool arm_secure_encryption_locked();
 void wipe_secret_key(eoc_secret_key *sk); // explicit_bzero over the master key and the key bits
 int ensure_engine_locked(); // caller holds ctx().mu
+void drop_keys_locked();    // wipes and frees whichever key the context holds (caller holds ctx().mu)
 
 } // namespace eoc_host

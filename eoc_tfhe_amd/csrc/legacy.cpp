@@ -97,11 +97,11 @@ const char *linear_op(const char *b64a, const char *b64b, int sign)
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) { // eoc-tfhe-run.cpp:465-468
+    if (!c.params()) { // eoc-tfhe-run.cpp:465-468: needs the public (cloud) key only
         std::cerr << "Public key not initialized. Generate the public key first." << std::endl;
         return nullptr;
     }
-    const int n = c.sk->p.n;
+    const int n = c.params()->n;
     std::vector<int32_t> a, b;
     double va = 0, vb = 0;
     if (!b64_to_sample(b64a, n, a, &va) || !b64_to_sample(b64b, n, b, &vb)) {
@@ -267,7 +267,7 @@ extern "C" int importSecretKey(const char *base64Key)
 {
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (c.sk) {
+    if (c.sk || c.ck) {
         std::cout << "Secret key is already generated for this instance..." << std::endl;
         return -1;
     }
@@ -288,6 +288,150 @@ extern "C" int importSecretKey(const char *base64Key)
     }
     c.engine_ready = false;
     return 0;
+}
+
+// ---- the cloud ("public") key of the global context: export on the client, import on the server ------------------------
+// The point of the scheme is that the evaluating host never holds the secret key.  A client exports the cloud key of its
+// key set (EOCCK1: params | bk | ksk, nothing secret); a server installs it as a cloud-key-ONLY global context on which
+// gate*, constantBit, add/subtractCiphertexts, eoc_global_gate_batch(_submit) and eoc_global_circuit_run work and every
+// call that needs the secret key (encrypt*, decrypt*, exportSecretKey) answers NULL / -1 with the reference's "Secret
+// key not initialized" message.  The blob is 83 MB (Set A) / 145 MB (Set B), so next to the base64 string form (the
+// reference's style for keys, eoc-tfhe-run.cpp:235-243) there are a file form and a raw-buffer form.
+namespace {
+// EOCCK1 bytes of whichever key the context holds (caller holds ctx().mu); empty when there is none
+bool cloud_blob_locked(GlobalCtx &c, std::vector<unsigned char> &blob)
+{
+    const eoc_params *p = c.params();
+    const std::vector<int32_t> *bk = c.sk ? &c.sk->bk : c.ck ? &c.ck->bk : nullptr;
+    const std::vector<int32_t> *ksk = c.sk ? &c.sk->ksk : c.ck ? &c.ck->ksk : nullptr;
+    if (!p || !bk || bk->empty() || ksk->empty()) {
+        std::cerr << "Public key not initialized. Generate the public key first." << std::endl;
+        return false;
+    }
+    blob.resize(eoc_cloud_key_blob_bytes(p));
+    memcpy(blob.data(), kMagicCK, 8);
+    put_params(*p, blob.data() + 8);
+    memcpy(blob.data() + 8 + kParamBytes, bk->data(), bk->size() * 4);
+    memcpy(blob.data() + 8 + kParamBytes + bk->size() * 4, ksk->data(), ksk->size() * 4);
+    return true;
+}
+int install_cloud_blob_locked(GlobalCtx &c, const void *buf, size_t len)
+{
+    if (c.sk || c.ck) { // one key per process, as in the reference (eoc-tfhe-run.cpp:245-249)
+        std::cout << "Secret key is already generated for this instance..." << std::endl;
+        return -1;
+    }
+    const unsigned char *o = static_cast<const unsigned char *>(buf);
+    eoc_params p;
+    if (!buf || len < 8 + kParamBytes || memcmp(o, kMagicCK, 8) != 0 || !get_params(o + 8, p) ||
+        len != eoc_cloud_key_blob_bytes(&p)) {
+        if (buf && len >= 6 && memcmp(o, "EOCSK", 5) == 0)
+            std::cerr << "importCloudKey: this is a SECRET key blob; a server takes the cloud key only." << std::endl;
+        else
+            std::cerr << "importCloudKey: not an EOCCK1 cloud key blob." << std::endl;
+        return -1;
+    }
+    eoc_cloud_key *ck = new eoc_cloud_key();
+    ck->p = p;
+    const int32_t *w = reinterpret_cast<const int32_t *>(o + 8 + kParamBytes);
+    ck->bk.assign(w, w + eoc_bk_len(&p));
+    ck->ksk.assign(w + eoc_bk_len(&p), w + eoc_bk_len(&p) + eoc_ksk_len(&p));
+    c.ck = ck;
+    c.enc_secure = false;
+    c.enc_seed = c.enc_counter = 0;
+    c.engine_ready = false; // the GPU engine comes up on the first gate call
+    return 0;
+}
+bool read_file(const char *path, std::vector<unsigned char> &out)
+{
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) return false;
+    bool ok = fseek(f, 0, SEEK_END) == 0;
+    const long sz = ok ? ftell(f) : -1;
+    ok = ok && sz >= 0 && fseek(f, 0, SEEK_SET) == 0;
+    if (ok) {
+        out.resize((size_t)sz);
+        ok = fread(out.data(), 1, out.size(), f) == out.size();
+    }
+    fclose(f);
+    return ok;
+}
+} // namespace
+
+extern "C" const char *exportCloudKey(void)
+{
+    GlobalCtx &c = ctx();
+    std::vector<unsigned char> blob;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        if (!cloud_blob_locked(c, blob)) return nullptr;
+    }
+    return dup_cstr(b64_encode(blob.data(), blob.size()));
+}
+extern "C" int importCloudKey(const char *base64CloudKey)
+{
+    if (!base64CloudKey) return -1;
+    std::string raw = b64_decode(base64CloudKey);
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return install_cloud_blob_locked(c, raw.data(), raw.size());
+}
+extern "C" int exportCloudKeyToFile(const char *path)
+{
+    GlobalCtx &c = ctx();
+    std::vector<unsigned char> blob;
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        if (!cloud_blob_locked(c, blob)) return -1;
+    }
+    FILE *f = path ? fopen(path, "wb") : nullptr;
+    if (!f) {
+        std::cerr << "exportCloudKeyToFile: cannot open the file for writing." << std::endl;
+        return -1;
+    }
+    const bool ok = fwrite(blob.data(), 1, blob.size(), f) == blob.size();
+    if (fclose(f) != 0 || !ok) {
+        std::cerr << "exportCloudKeyToFile: short write." << std::endl;
+        return -1;
+    }
+    return 0;
+}
+extern "C" int importCloudKeyFromFile(const char *path)
+{
+    std::vector<unsigned char> blob;
+    if (!read_file(path, blob)) {
+        std::cerr << "importCloudKeyFromFile: cannot read the file." << std::endl;
+        return -1;
+    }
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return install_cloud_blob_locked(c, blob.data(), blob.size());
+}
+extern "C" size_t eoc_global_cloud_key_export(void *buf, size_t cap)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    const eoc_params *p = c.params();
+    if (!p) return 0;
+    const size_t need = eoc_cloud_key_blob_bytes(p);
+    if (!buf || cap < need) return need;
+    std::vector<unsigned char> blob;
+    if (!cloud_blob_locked(c, blob)) return 0;
+    memcpy(buf, blob.data(), need);
+    return need;
+}
+extern "C" int eoc_global_import_cloud_key_blob(const void *buf, size_t len)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return install_cloud_blob_locked(c, buf, len) ? EOC_ERR_ARG : EOC_OK;
+}
+// 0 = no key, 1 = secret + cloud key (client / single-host mode), 2 = cloud key only (server mode)
+extern "C" int eoc_global_key_mode(void)
+{
+    GlobalCtx &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return c.sk ? 1 : c.ck ? 2 : 0;
 }
 
 // ================================================================================================
@@ -332,7 +476,7 @@ extern "C" const char *generateSecretKey(const char *jwtToken, const char *jwksB
     }
     GlobalCtx &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
-    if (c.sk) {
+    if (c.sk || c.ck) {
         std::cout << "Secret key is already generated for this instance..." << std::endl;
         return nullptr;
     }
@@ -363,17 +507,9 @@ extern "C" const char *generateSecretKey(const char *jwtToken, const char *jwksB
 }
 
 // declared in eoc-tfhe-run.h:10, never defined by the reference (l_generatePublicKey pushes nothing,
-// eoc-tfhe-bindings.c:51-57).  Here: a short description of the cloud key, or NULL without a key.
-extern "C" const char *generatePublicKey()
-{
-    GlobalCtx &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    if (!c.sk) return no_secret_key();
-    char tok[128];
-    snprintf(tok, sizeof tok, "EOCCLOUDKEY n=%d l=%d Bgbit=%d bytes=%zu", c.sk->p.n, c.sk->p.l, c.sk->p.Bgbit,
-             eoc_cloud_key_blob_bytes(&c.sk->p));
-    return dup_cstr(b64_encode(reinterpret_cast<const unsigned char *>(tok), strlen(tok)));
-}
+// eoc-tfhe-bindings.c:51-57); its "public key" is the cloud key set of the secret key (:232-234).  Here it returns exactly
+// that: base64 of the EOCCK1 blob of the global key (= exportCloudKey), which importCloudKey installs on a server.
+extern "C" const char *generatePublicKey() { return exportCloudKey(); }
 
 extern "C" const char *encryptInteger(int32_t value, const char *)
 { // eoc-tfhe-run.cpp:282-310

@@ -322,7 +322,7 @@ const char *gateMUX(const char *ct1, const char *ct2, const char *ct3, const cha
  * generateSecretKey uses minimum_lambda = 128 (Set B) and returns the compact key blob below.
  * ---------------------------------------------------------------------------------------------- */
 const char *generateSecretKey(const char *jwtToken, const char *jwksBase64);
-const char *generatePublicKey();
+const char *generatePublicKey(); /* declared but never defined by the reference (eoc-tfhe-run.h:10); here = exportCloudKey() */
 const char *encryptInteger(int32_t value, const char *base64SecretKey);
 const char *encryptInteger_dummy(int32_t value, const char *base64SecretKey);
 const int decryptInteger(char *base64Ciphertext, const char *base64SecretKey, const char *jwtToken,
@@ -364,6 +364,29 @@ int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int32_t *wires
                            size_t instances);
 const char *exportSecretKey(void);          /* base64 of the EOCSK1 blob of the global key */
 int importSecretKey(const char *base64Key); /* 0, or -1 (malformed / a key already exists) */
+
+/* ------------------------------------------------------------------------------------------------
+ * f2, server side: the cloud ("public") key on the global context.  The reference aliases the cloud key set of its
+ * secret key as globalPublicKey (ao-tfhe/eoc-tfhe-run.cpp:232-234), checks only that one in its homomorphic ops
+ * (:427-470, :472-513), declares generatePublicKey (ao-tfhe/eoc-tfhe-run.h:10) and leaves both it and the binding
+ * (ao-tfhe/eoc-tfhe-bindings.c:51-57) empty; every op takes a base64PublicKey argument the bindings never fill
+ * (:63-110).  Here the pair is real:
+ *   client:  generateGateKey / generateSecretKey / importSecretKey, then exportCloudKey (= generatePublicKey)
+ *   server:  importCloudKey -> a cloud-key-ONLY context: gate*, constantBit, addCiphertexts / subtractCiphertexts,
+ *            eoc_global_gate_batch(_submit), eoc_global_circuit_run, eoc_global_params work; encryptBit, decryptBit,
+ *            encryptInteger, decryptInteger, the ASCII-string calls, eoc_global_encrypt_bits / _decrypt_bits and
+ *            exportSecretKey return NULL / -1 / EOC_ERR_NO_KEY with "Secret key not initialized..." on stderr.
+ * One key per process (eoc-tfhe-run.cpp:245-249): importing into a context that has a key fails; resetGateKey clears.
+ * The EOCCK1 blob is 83 MB (Set A) / 145 MB (Set B): next to the reference-style base64 string form there are a
+ * file form and a raw-buffer form.
+ * ---------------------------------------------------------------------------------------------- */
+const char *exportCloudKey(void);                    /* base64(EOCCK1) of the global key, NULL without one */
+int importCloudKey(const char *base64CloudKey);      /* 0, or -1 (malformed / a secret-key blob / a key already exists) */
+int exportCloudKeyToFile(const char *path);          /* raw EOCCK1 bytes; 0 or -1 */
+int importCloudKeyFromFile(const char *path);        /* 0 or -1 */
+size_t eoc_global_cloud_key_export(void *buf, size_t cap); /* bytes needed (0 without a key); fills buf when cap suffices */
+int eoc_global_import_cloud_key_blob(const void *buf, size_t len);
+int eoc_global_key_mode(void);                       /* 0 no key, 1 secret + cloud key, 2 cloud key only (server) */
 
 #ifdef __cplusplus
 }

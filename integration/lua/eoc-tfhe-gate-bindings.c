@@ -18,7 +18,7 @@ static int l_generateGateKey(lua_State *L) {          /* like l_generateSecretKe
 }
 static int l_resetGateKey(lua_State *L) { (void)L; resetGateKey(); return 0; }
 static int l_setDevices(lua_State *L) {               /* (dev, dev, ...) -> 0 or a negative code; no arguments = forget */
-  int devs[64], n = lua_gettop(L);                    /* the devices the next generateGateKey / importPublicKey brings up */
+  int devs[64], n = lua_gettop(L);                    /* the devices the next generateGateKey / importCloudKey brings up */
   if (n > 64) n = 64;
   for (int i = 0; i < n; i++) devs[i] = (int)luaL_checkinteger(L, i + 1);
   lua_pushinteger(L, eoc_gpu_set_devices(devs, n));
@@ -72,6 +72,26 @@ static int l_importSecretKey(lua_State *L) {
   lua_pushinteger(L, importSecretKey(luaL_checkstring(L, 1)));
   return 1;
 }
+/* the cloud ("public") key (eoc-tfhe-run.cpp:232-234): exported by the client, installed by a secret-free server.
+ * l_generatePublicKey's commented-out body (ao-tfhe/eoc-tfhe-bindings.c:51-57) can be restored as it stands:
+ * generatePublicKey() now returns this same export. */
+static int l_exportCloudKey(lua_State *L) {
+  const char *r = exportCloudKey();
+  lua_pushstring(L, r); free((void *)r); return 1;
+}
+static int l_importCloudKey(lua_State *L) {
+  lua_pushinteger(L, importCloudKey(luaL_checkstring(L, 1)));
+  return 1;
+}
+static int l_exportCloudKeyToFile(lua_State *L) {
+  lua_pushinteger(L, exportCloudKeyToFile(luaL_checkstring(L, 1)));
+  return 1;
+}
+static int l_importCloudKeyFromFile(lua_State *L) {
+  lua_pushinteger(L, importCloudKeyFromFile(luaL_checkstring(L, 1)));
+  return 1;
+}
+static int l_keyMode(lua_State *L) { lua_pushinteger(L, eoc_global_key_mode()); return 1; }
 
 /* ---- raw-buffer batch calls on the global key ---- */
 static int l_sampleInts(lua_State *L) {               /* n + 1 of the global key, or -1 */
@@ -161,5 +181,8 @@ static int l_netlistOptimize(lua_State *L) {          /* (gates, outputs: int32 
   {"gateNAND", l_gateNAND}, {"gateAND", l_gateAND}, {"gateOR", l_gateOR}, {"gateNOR", l_gateNOR},
   {"gateXOR", l_gateXOR}, {"gateXNOR", l_gateXNOR}, {"gateNOT", l_gateNOT}, {"gateMUX", l_gateMUX},
   {"exportSecretKey", l_exportSecretKey}, {"importSecretKey", l_importSecretKey},
+  {"exportCloudKey", l_exportCloudKey}, {"importCloudKey", l_importCloudKey},
+  {"exportCloudKeyToFile", l_exportCloudKeyToFile}, {"importCloudKeyFromFile", l_importCloudKeyFromFile},
+  {"keyMode", l_keyMode},
   {"sampleInts", l_sampleInts}, {"encryptBits", l_encryptBits}, {"decryptBits", l_decryptBits},
   {"gateBatch", l_gateBatch}, {"circuitRun", l_circuitRun}, {"netlistOptimize", l_netlistOptimize},

@@ -17,6 +17,12 @@ function Tfhe.bnot(a, pk)                   return Tfhe.backend.gateNOT(a, pk) e
 function Tfhe.mux(a, b, c, pk)              return Tfhe.backend.gateMUX(a, b, c, pk) end
 function Tfhe.exportSecretKey()             return Tfhe.backend.exportSecretKey() end
 function Tfhe.importSecretKey(k)            return Tfhe.backend.importSecretKey(k) end
+-- the cloud ("public") key: exported by the client (= generatePublicKey), all a server installs
+function Tfhe.exportCloudKey()              return Tfhe.backend.exportCloudKey() end
+function Tfhe.importCloudKey(k)             return Tfhe.backend.importCloudKey(k) end
+function Tfhe.exportCloudKeyToFile(path)    return Tfhe.backend.exportCloudKeyToFile(path) end
+function Tfhe.importCloudKeyFromFile(path)  return Tfhe.backend.importCloudKeyFromFile(path) end
+function Tfhe.keyMode()                     return Tfhe.backend.keyMode() end          -- 0 none, 1 secret + cloud, 2 cloud only
 
 -- ---- circuit layer: netlists evaluated by ONE backend call (circuitRun), batched over instances ----
 -- wires travel as one binary string [nWires][instances][n+1] of int32 samples; a netlist is packed as 5 int32 per gate

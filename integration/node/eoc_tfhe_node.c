@@ -166,6 +166,34 @@ static napi_value n_importSecretKey(napi_env env, napi_callback_info info)
     free(k);
     return ret_int(env, v);
 }
+/* the cloud ("public") key: exported by the client, installed by a server that never holds the secret key
+ * (eoc-tfhe-run.cpp:232-234 aliases it as globalPublicKey; generatePublicKey, eoc-tfhe-run.h:10, is the same export) */
+static napi_value n_exportCloudKey(napi_env env, napi_callback_info info) { (void)info; return ret_string(env, exportCloudKey()); }
+static napi_value n_importCloudKey(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    char *k = arg_string(env, argv[0]);
+    int v = importCloudKey(k);
+    free(k);
+    return ret_int(env, v);
+}
+static napi_value n_exportCloudKeyToFile(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    char *path = arg_string(env, argv[0]);
+    int v = exportCloudKeyToFile(path);
+    free(path);
+    return ret_int(env, v);
+}
+static napi_value n_importCloudKeyFromFile(napi_env env, napi_callback_info info)
+{
+    ARGS(1);
+    char *path = arg_string(env, argv[0]);
+    int v = importCloudKeyFromFile(path);
+    free(path);
+    return ret_int(env, v);
+}
+static napi_value n_keyMode(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_global_key_mode()); }
 
 /* ---- raw-buffer batch calls on the global key: Buffers of bytes / int32 LWE samples ---- */
 static napi_value n_sampleInts(napi_env env, napi_callback_info info)
@@ -291,6 +319,17 @@ static napi_value n_hostAlloc(napi_env env, napi_callback_info info)
     }
     return out;
 }
+static napi_ref g_held[2][5];      /* Buffers of the (at most two) submissions in flight */
+static uint64_t g_held_ticket[2];
+static void release_held(napi_env env, int slot)
+{
+    for (int k = 0; k < 5; k++)
+        if (g_held[slot][k]) {
+            napi_delete_reference(env, g_held[slot][k]);
+            g_held[slot][k] = NULL;
+        }
+    g_held_ticket[slot] = 0;
+}
 static napi_value n_gateBatchSubmit(napi_env env, napi_callback_info info)
 { /* (op, in0, in1 | null, in2 | null, ops | null, out) -- every Buffer from hostAlloc -> ticket (number), or null.
    * The Buffers must stay referenced and untouched until gateBatchWait(ticket). */
@@ -313,6 +352,16 @@ static napi_value n_gateBatchSubmit(napi_env env, napi_callback_info info)
     if (eoc_global_gate_batch_submit(op, (const uint8_t *)ops, (const int32_t *)in[0], (const int32_t *)in[1],
                                      (const int32_t *)in[2], (int32_t *)out, count, &ticket) != EOC_OK)
         return ret_null(env);
+    /* the pinned Buffers stay referenced until gateBatchWait(ticket): a collected Buffer would run free_pinned
+     * (eoc_host_free) under a DMA in flight.  Slot ticket & 1 is free again: the library completed its previous
+     * occupant (ticket - 2) before it accepted this submission. */
+    release_held(env, (int)(ticket & 1));
+    g_held_ticket[ticket & 1] = ticket;
+    const napi_value keep[5] = {argv[1], argv[2], argv[3], argv[4], argv[5]};
+    for (int k = 0; k < 5; k++) {
+        void *q; size_t qb;
+        if (get_buffer(env, keep[k], &q, &qb)) napi_create_reference(env, keep[k], 1, &g_held[ticket & 1][k]);
+    }
     napi_value t;
     NAPI_OK(napi_create_double(env, (double)ticket, &t));
     return t;
@@ -322,7 +371,9 @@ static napi_value n_gateBatchWait(napi_env env, napi_callback_info info)
     ARGS(1);
     double t = 0;
     napi_get_value_double(env, argv[0], &t);
-    return ret_int(env, eoc_gate_batch_wait((uint64_t)t));
+    const int rc = eoc_gate_batch_wait((uint64_t)t);
+    if (g_held_ticket[(uint64_t)t & 1] == (uint64_t)t) release_held(env, (int)((uint64_t)t & 1));
+    return ret_int(env, rc);
 }
 static napi_value n_circuitRun(napi_env env, napi_callback_info info)
 { /* (Int32Array gates [5 per gate: op, in0, in1, in2, out], Buffer wires [nWires][instances][n+1], nWires, instances)
@@ -370,7 +421,7 @@ static napi_value n_circuitBootstraps(napi_env env, napi_callback_info info)
 }
 static napi_value n_engineCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_gpu_engine_count()); }
 static napi_value n_setDevices(napi_env env, napi_callback_info info)
-{ /* (Int32Array devices) -> 0 or a negative code: the devices the next generateGateKey / importPublicKey brings up, one
+{ /* (Int32Array devices) -> 0 or a negative code: the devices the next generateGateKey / importCloudKey brings up, one
    * engine each (a device may repeat; an empty array returns to EOC_TFHE_DEVICES / device 0) */
     ARGS(1);
     int32_t *d;
@@ -392,6 +443,9 @@ static napi_value init(napi_env env, napi_value exports)
         {"decryptBit", n_decryptBit}, {"gateNAND", n_gateNAND}, {"gateAND", n_gateAND}, {"gateOR", n_gateOR},
         {"gateNOR", n_gateNOR}, {"gateXOR", n_gateXOR}, {"gateXNOR", n_gateXNOR}, {"gateNOT", n_gateNOT},
         {"gateMUX", n_gateMUX}, {"exportSecretKey", n_exportSecretKey}, {"importSecretKey", n_importSecretKey},
+        {"exportCloudKey", n_exportCloudKey}, {"importCloudKey", n_importCloudKey},
+        {"exportCloudKeyToFile", n_exportCloudKeyToFile}, {"importCloudKeyFromFile", n_importCloudKeyFromFile},
+        {"keyMode", n_keyMode},
         {"sampleInts", n_sampleInts}, {"encryptBits", n_encryptBits}, {"decryptBits", n_decryptBits},
         {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount}, {"circuitRun", n_circuitRun},
         {"netlistOptimize", n_netlistOptimize}, {"circuitBootstraps", n_circuitBootstraps}, {"engineCount", n_engineCount},

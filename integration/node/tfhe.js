@@ -34,6 +34,16 @@ Tfhe.xor = (a, b, pk) => B.gateXOR(a, b, pk);
 Tfhe.xnor = (a, b, pk) => B.gateXNOR(a, b, pk);
 Tfhe.not = (a, pk) => B.gateNOT(a, pk);
 Tfhe.mux = (a, b, c, pk) => B.gateMUX(a, b, c, pk);
+// ---- keys: the secret key stays with the client, the cloud ("public") key is all a server installs ----
+Tfhe.resetGateKey = () => B.resetGateKey();
+Tfhe.setDevices = devices => B.setDevices(Int32Array.from(devices));   // GPUs behind the next gate key / cloud key
+Tfhe.exportSecretKey = () => B.exportSecretKey();
+Tfhe.importSecretKey = k => B.importSecretKey(k);
+Tfhe.exportCloudKey = () => B.exportCloudKey();                 // = generatePublicKey(): base64 of the EOCCK1 blob
+Tfhe.importCloudKey = k => B.importCloudKey(k);                 // server: cloud-key-only context (no encrypt / decrypt)
+Tfhe.exportCloudKeyToFile = path => B.exportCloudKeyToFile(path);
+Tfhe.importCloudKeyFromFile = path => B.importCloudKeyFromFile(path);
+Tfhe.keyMode = () => B.keyMode();                               // 0 none, 1 secret + cloud, 2 cloud only
 
 // ---- circuit layer: netlists evaluated by ONE backend call (eoc_global_circuit_run), batched over instances --------
 // A netlist is a list of gates {op, in0, in1, in2, out} over numbered wires; wires travel as one Buffer

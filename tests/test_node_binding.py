@@ -27,6 +27,31 @@ def test_reference_tests_in_node_cpu(built_lib):
 
 
 @needs_node
+def test_cloud_key_client_server_in_node_cpu(built_lib, tmp_path):
+    """f2 through the N-API addon: a client process exports the cloud key, a second process installs ONLY that key
+    (keyMode 2: no encrypt / decrypt / secret export), adds two ciphertexts, and the client decrypts the sum"""
+    _build()
+    for mode in ("client", "server", "verify"):
+        r = subprocess.run(["node", os.path.join(NODE_DIR, "test_cpu_cloud.js"), mode, str(tmp_path)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        assert "node cloud %s OK" % mode in r.stdout
+
+
+@needs_node
+@pytest.mark.gpu
+def test_cloud_key_server_in_node_gpu(built_lib, tmp_path):
+    """the same three Node processes on the GPU box: the cloud-key-only server evaluates a string-API gate and a raw
+    XOR batch on the GPU, the client decrypts them"""
+    _build()
+    for mode in ("client", "server", "verify"):
+        r = subprocess.run(["node", os.path.join(NODE_DIR, "test_cpu_cloud.js"), mode, str(tmp_path)],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "node cloud gpu leg verified" in r.stdout
+
+
+@needs_node
 @pytest.mark.gpu
 def test_gates_through_node_gpu(built_lib):
     _build()
