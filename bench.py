@@ -6,26 +6,32 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one batch of 1024 independent bootsNAND gates (BASELINE.json configs[1]) per GPU on
-parameter Set A (n=500, N=1024, k=1, l=2, Bgbit=10).  `value` follows SURVEY.md 8(d)'s definition of the
-metric: wall time from the first H2D of the inputs to the last D2H of the outputs, keys resident -- a
-step is ONE synchronous call of eoc_gate_batch (the host-buffer C ABI) on pinned buffers from
-eoc_host_alloc.  The rate with operands already resident in HBM (the device-pointer API) is timed over
-the same K steps and printed as `resident_gates_per_s` (+1...4 %).  With N > 1 every rank runs its own
-batch of 1024 gates (weak scaling, independent gates shard with no data-path collective); the cloud
-key is built once on rank 0 and RCCL-broadcast to the other ranks before the timed region.
+parameter Set A (n=500, N=1024, k=1, l=2, Bgbit=10).  `value` = whole-job throughput with the operands
+ALREADY RESIDENT IN HBM when the timed region starts (the device-pointer layer of the C ABI,
+eoc_gate_batch_device, K steps between barrier + synchronize on both sides) -- the definition this round's
+task text gives for `value`.  The PCIe-inclusive rate SURVEY.md 8(d) words the metric on (first H2D of the
+inputs to last D2H of the outputs, ONE synchronous eoc_gate_batch call per step on eoc_host_alloc buffers;
+round 3's `value`) is timed right after on the same engine and printed as `wallclock_gates_per_s` (-4...7 %),
+next to `pipelined_gates_per_s` (two batches in flight) and `pageable_gates_per_s`.  With N > 1 every rank
+runs its own batch of 1024 gates (weak scaling, independent gates shard with no data-path collective); the
+cloud key is built once on rank 0 and RCCL-broadcast to the other ranks before the timed region.
 
 Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
   roofline       dominant kernel (k_blind_rotate), bound = FP64 vector issue: SURVEY.md 8(d)'s algorithmic flops per
                  blind rotation x jobs per launch / the HIP-event duration measured in this run, against the 78.6
-                 TFLOP/s datasheet peak.  `hbm_measured` = the stored rocprofv3 PMC byte count of the same launch shape
-                 (profiles/traffic.json) / this run's launch duration, as GB/s and as a fraction of 8 TB/s; the
-                 algorithmic HBM figure is a secondary key (batched execution serves BK from L2: not a fraction)
-  resident       the same K steps through the device-pointer API, operands resident in HBM when the timed region
-                 starts: `resident_gates_per_s`, `resident_ms_per_step` (the form round 1 and 2 reported as `value`);
+                 TFLOP/s datasheet peak.  Co-bounds in the same block, so that the fraction explains itself:
+                 `l2_served` (key-row bytes per launch / launch time against the 16.8-18.8 TB/s the microarch guide
+                 measures for rows served by the XCDs' L2), `lds` (stored PMC: share of wave cycles in which an LDS
+                 instruction is ready but the LDS pipe is taken, LDS instructions per wave-step, bank conflicts),
+                 `hbm_measured` (stored PMC bytes of the same launch shape / this run's launch duration, GB/s and
+                 fraction of 8 TB/s); the algorithmic HBM figure is a secondary key (a batch serves BK from L2)
+  wallclock      the same K steps through the host-buffer call (PCIe inclusive): `wallclock_gates_per_s`,
+                 `wallclock_ms_per_step`; `pipelined_gates_per_s` = eoc_gate_batch_submit / _wait two deep;
                  `pageable_gates_per_s` = the host-buffer call on ordinary malloc'ed arrays
   cpu_baseline   the CPU oracle (a port: restatement of the reference algorithm, upstream libtfhe is absent) on a
                  bounded sample of the same batch, on the host cores
-  secondary      N = 1: the other single-GPU configurations (adder8, streq32, mixed) and `nand1024_setB`, the headline
+  secondary      N = 1: the other single-GPU configurations (adder8 = BASELINE configs[2] as written: 40 bootstraps per
+                 pair x 4096 pairs = 163 840; streq32; mixed) and `nand1024_setB`, the headline
                  workload on the parameter set the reference's own keygen selects (eoc-tfhe-run.cpp:34,230), with its
                  own roofline block.  N > 1: `config3_mixed_1M` and `config4_streq_1024x32`, BASELINE configs[3] and
                  [4] cut into this run's N blocks (strong scaling: total bootstraps / slowest rank, decrypt-checked on
@@ -53,6 +59,7 @@ PSETS = {"A": 0, "B": 1}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # datasheet FP64 vector peak (256 CUs x 4 SIMDs x 16 FMA lanes x 2 flop x 2.4 GHz)
 PREFLIGHT_STEPS = 16
+L2_ROWS_GBPS_LO, L2_ROWS_GBPS_HI = 16800.0, 18800.0  # MI355X_MICROARCH.md "Indexed rows": rows served by the XCD's L2
 FP64_SUSTAINED_TFLOPS = 62.0  # pure v_fma_f64 loop, tools/fp64_issue_bench.hip: the clock drops under FP64 load
 
 
@@ -163,8 +170,31 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
                                "peak_GBps": HBM_PEAK_GBPS,
                                "note": "every gate streams the whole BK-FFT once; a batch re-uses BK "
                                        "slices from L2, so this rate is not HBM-bound and may exceed the peak"},
-           "note": "FP64 vector issue + LDS transposes bound the kernel (DESIGN.md 5.1); flops are "
-                   "SURVEY.md 8(d)'s algorithmic count, not executed instructions"}
+           "note": "FP64 vector issue + LDS transposes bound the kernel (DESIGN.md 5.1), the key-row stream from L2 is the "
+                   "third resource (l2_served); flops are SURVEY.md 8(d)'s algorithmic count, not executed instructions"}
+    # co-bound 1: the key rows stream from the XCDs' L2 -- every job reads its whole BK-FFT (PMC: TCC_HIT x 128 B equals
+    # this byte count), 99 % of it as L2 hits
+    if br_ms > 0:
+        l2 = bk_b * jobs_per_launch / (br_ms * 1e-3) / 1e9
+        blk["l2_served"] = {"GBps": round(l2, 1), "key_bytes_per_launch": int(bk_b * jobs_per_launch),
+                            "ceiling_GBps": [L2_ROWS_GBPS_LO, L2_ROWS_GBPS_HI],
+                            "frac_of_ceiling": [round(l2 / L2_ROWS_GBPS_HI, 3), round(l2 / L2_ROWS_GBPS_LO, 3)],
+                            "note": "ceiling = MI355X_MICROARCH.md 'Indexed rows', rows shared by every workgroup of an XCD "
+                                    "(served by its L2): 16.8-18.8 TB/s chip-wide; timing-only ablation without the key-row "
+                                    "loads: -6.6 % (DESIGN.md 5.1)"}
+    # co-bound 2: the CU's LDS pipe (the transposes of the three transforms per wave-step), from the stored PMC passes
+    cb = None
+    if with_traffic and os.path.exists(tpath):
+        try:
+            cb = json.load(open(tpath)).get(f"cobounds_{pset}")
+        except Exception:
+            cb = None
+    if cb:
+        blk["lds"] = dict(cb, source="profiles/traffic.json (stored rocprofv3 PMC passes of this launch shape; not "
+                                      "measured in this run)",
+                          note="lds_wait_frac = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES: share of wave cycles in which an LDS "
+                               "instruction is ready but the CU's LDS pipe is taken; the store path moves ~79 B/clk/CU "
+                               "(ds_write_b128 = 13.6 cycles), 56 such stores per wave-step (DESIGN.md 5.1)")
     if traffic and br_ms > 0:
         gbps = traffic / ((traffic_launch_ms or br_ms) * 1e-3) / 1e9
         blk["hbm_measured"] = {"GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
@@ -273,11 +303,11 @@ def main():
     pin[1].array[:] = c1
     hout = np.empty_like(c0)
 
-    def step():  # first H2D of the inputs -> last D2H of the outputs, one synchronous call
-        eoc.gate_batch(op, pin[0].array, pin[1].array, out=pin[2].array)
-
-    def step_resident():
+    def step():  # the headline step: operands resident in HBM, one eoc_gate_batch_device call on the current stream
         eng.gate_batch_device(op, d0.data_ptr(), d1.data_ptr(), None, dout.data_ptr(), G, stream=stream)
+
+    def step_wallclock():  # first H2D of the inputs -> last D2H of the outputs, one synchronous call
+        eoc.gate_batch(op, pin[0].array, pin[1].array, out=pin[2].array)
 
     def make_workload(name, instances):
         """(step, bootstraps per step, description, check) of a secondary workload on this rank's shard"""
@@ -286,11 +316,12 @@ def main():
         if name in ("adder8", "streq32"):
             if name == "adder8":
                 S = instances or 4096 // max(1, world) or 1
-                gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8)
+                gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8, carry_in_zero=True)
                 A, B = wrng.integers(0, 256, S), wrng.integers(0, 256, S)
                 bits_in = {aw[0]: ((A[:, None] >> np.arange(8)) & 1), bw[0]: ((B[:, None] >> np.arange(8)) & 1)}
                 desc = (f"8-bit ripple-carry add, {S} input pairs per GPU (BASELINE configs[2]); "
-                        f"{eoc.circuit_bootstraps(gates)} bootstraps per pair (half adder at bit 0; BASELINE.md counts 40)")
+                        f"{eoc.circuit_bootstraps(gates)} bootstraps per pair = BASELINE.md's uniform 5 gates per bit "
+                        f"(full adder at bit 0 with a constant-0 carry-in), {eoc.circuit_bootstraps(gates) * S} in all")
             else:
                 S = instances or 1024 // max(1, world) or 1
                 gates, n_wires, xw, yw, outw = circuits.string_equal(32)
@@ -395,19 +426,20 @@ def main():
     host_path = args.workload == "nand"
     if not host_path:  # the circuit / mixed shapes as a headline run on device-resident wires (secondary use of this script)
         step, boots_per_step, workload_desc, circuit_check = make_workload(args.workload, args.instances)
-        step_resident = None
 
     # ---- everything the later legs need is prepared BEFORE anything is timed, and the short secondary passes run first:
     # the device drops its clock within milliseconds of going idle and takes ~12 steps (40 ms) of load to come back
     # (tools/clock_ramp.py), so host-side preparation between legs would put a ramp inside each of them
     headline_nand = args.workload == "nand" and args.op == "NAND"
-    single_nand = world == 1 and headline_nand
+    # dist is set at world == 1 only by EOC_BENCH_FORCE_DIST=1: that run rehearses the N > 1 code (process group, device
+    # tensor all-reduces, the configs[3] / [4] block legs) on one rank and skips the single-GPU secondary legs
+    single_nand = world == 1 and headline_nand and dist is None
     sec_runs = []
     if single_nand and not args.no_secondary:
         for wname, inst in (("adder8", 0), ("streq32", 256), ("mixed", 32768)):
             sec_runs.append((wname,) + make_workload(wname, inst))
     multi_legs = []
-    if world > 1 and headline_nand and not args.no_secondary:
+    if dist is not None and headline_nand and not args.no_secondary:   # world > 1, or the forced one-rank RCCL smoke
         multi_legs.append(("config3_mixed_1M",) + make_config3_block())
         multi_legs.append(("config4_streq_1024x32",) + make_config4_block())
     setb = None
@@ -463,10 +495,22 @@ def main():
     kt = eng.kernel_times(reset=True)
     eng.set_profiling(False)
 
-    # the same K steps with the operands already resident in HBM (device-pointer API; what rounds 1 and 2 reported as
-    # `value`), and the host-buffer call on ordinary pageable arrays
-    resident = pageable = pipelined = None
+    # the same K steps through the host-buffer call (PCIe inclusive: SURVEY.md 8(d)'s wording of the metric, round 3's
+    # `value`), its asynchronous two-deep form, and the host-buffer call on ordinary pageable arrays
+    wallclock = pageable = pipelined = None
+    pipelined_ok = True
     if host_path:
+        for _ in range(3):
+            step_wallclock()
+        if dist:
+            dist.barrier()
+        tw0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_wallclock()
+        if dist:
+            dist.barrier()
+        wallclock = reduce_max(time.perf_counter() - tw0)
+        wall_out = pin[2].array.copy()
         # the asynchronous form of the same call, two batches in flight: batch k + 1's operands travel while batch k
         # computes, batch k's results leave under batch k + 1's kernels -- still first H2D -> last D2H of the whole job
         pin2 = eoc.PinnedArray(c0.shape)
@@ -486,19 +530,7 @@ def main():
                 dist.barrier()
             pipelined = time.perf_counter() - tq0
         pipelined = reduce_max(pipelined)
-        pipelined_ok = bool(np.array_equal(pin2.array, pin[2].array))
-        for _ in range(3):
-            step_resident()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        tr0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_resident()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        resident = reduce_max(time.perf_counter() - tr0)
+        pipelined_ok = bool(np.array_equal(pin2.array, pin[2].array)) if args.steps >= 2 else True
         if rank == 0:
             for _ in range(3):
                 eoc.gate_batch(op, c0, c1, out=hout)
@@ -551,8 +583,8 @@ def main():
     elapsed = reduce_max(elapsed)
 
     # ---- correctness of what was timed: decrypt on every rank -------------------------------
-    out = pin[2].array.copy() if host_path else dout.cpu().numpy()
-    paths_agree = bool(not host_path or (np.array_equal(dout.cpu().numpy(), out) and (rank != 0 or np.array_equal(hout, out))))
+    out = dout.cpu().numpy()
+    paths_agree = bool(not host_path or (np.array_equal(wall_out, out) and (rank != 0 or np.array_equal(hout, out))))
     if circuit_check is not None:
         decrypt_ok = circuit_check()
     else:
@@ -610,8 +642,9 @@ def main():
                        "param_set": args.pset, "n": n, "N": 1024, "k": 1, "l": p.l, "Bgbit": p.Bgbit,
                        "ks_t": p.ks_t, "ks_basebit": p.ks_basebit, "gates_per_gpu_per_step": G,
                        "sharding": "independent gates per rank, no data-path collective",
-                       "timed_region": ("SURVEY.md 8(d): first H2D of inputs to last D2H of outputs, one synchronous "
-                                        "eoc_gate_batch call per step on eoc_host_alloc buffers, keys resident"
+                       "timed_region": ("operands and keys resident in HBM when the timed region starts; one "
+                                        "eoc_gate_batch_device call (device-pointer layer of the C ABI) per step; "
+                                        "barrier + synchronize on both sides"
                                         if host_path else "device-resident wires (secondary workload mode)"),
                        "key_broadcast_s": round(t_bcast, 4)},
             "decrypt_ok": decrypt_ok,
@@ -652,21 +685,20 @@ def main():
             sec["in_library_all_devices"] = in_library
         if sec:
             res["secondary"] = sec
-        if resident:
-            res["resident_gates_per_s"] = round(G * world * args.steps / resident, 1)
-            res["resident_ms_per_step"] = round(resident / args.steps * 1e3, 4)
-            res["value_over_resident"] = round(value / res["resident_gates_per_s"], 4)
+        if wallclock:
+            res["wallclock_gates_per_s"] = round(G * world * args.steps / wallclock, 1)
+            res["wallclock_ms_per_step"] = round(wallclock / args.steps * 1e3, 4)
+            res["wallclock_over_value"] = round(res["wallclock_gates_per_s"] / value, 4)
             res["pageable_gates_per_s"] = round(G * args.steps / pageable, 1) if pageable else None
             res["pipelined_gates_per_s"] = round(G * world * args.steps / pipelined, 1)
             res["pipelined_note"] = ("eoc_gate_batch_submit / _wait, two batches in flight on pinned buffers: first H2D of the "
                                      "first batch to last D2H of the last one, PCIe time hidden behind the neighbouring "
-                                     "batch's kernels (an API the reference has no counterpart of; `value` stays the "
-                                     "synchronous call)")
+                                     "batch's kernels (an API the reference has no counterpart of)")
             res["paths_bit_identical"] = paths_agree and pipelined_ok
-            res["value_definition"] = ("since round 3 `value` is SURVEY.md 8(d)'s wall clock (H2D + kernels + D2H per step); "
-                                       "`resident_gates_per_s` is the figure comparable with the `value` of rounds 1 and 2")
-            res["resident_note"] = ("device-pointer API, operands resident in HBM when the timed region starts (rounds 1-2 "
-                                    "reported this as `value`); pageable = eoc_gate_batch on ordinary malloc'ed arrays, rank 0")
+            res["value_definition"] = ("`value` = operands resident in HBM when the timed region starts (this round's task "
+                                       "definition; rounds 1-2 reported the same quantity; round 3's `value` was the "
+                                       "PCIe-inclusive synchronous call, now `wallclock_gates_per_s`: SURVEY.md 8(d)'s first "
+                                       "H2D -> last D2H, one eoc_gate_batch call per step on eoc_host_alloc buffers)")
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     for a in pin:

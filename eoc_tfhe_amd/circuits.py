@@ -7,9 +7,12 @@ samples; eoc_circuit_run(_device) levelises and batches every level over all ins
 from . import OPS, Gate
 
 
-def ripple_carry_adder(nbits=8):
-    """a[0..nbits) + b[0..nbits) -> s[0..nbits], LSB first.  5 gates per bit (2 XOR, 2 AND, 1 OR) except
-    bit 0 (XOR + AND): 5*nbits - 3 bootstraps; BASELINE config 3 counts the uniform 5/bit = 40.
+def ripple_carry_adder(nbits=8, carry_in_zero=False):
+    """a[0..nbits) + b[0..nbits) -> s[0..nbits], LSB first.  5 gates per bit (2 XOR, 2 AND, 1 OR).
+    Default: bit 0 is a half adder (XOR + AND), 5*nbits - 3 bootstraps (37 for 8 bits).
+    carry_in_zero=True: bit 0 is a full adder too, its carry-in the noiseless constant 0 (bootsCONSTANT, free) --
+    the uniform 5 gates per bit BASELINE.md counts for configs[2]: 5*nbits = 40 bootstraps per 8-bit pair, 163 840 for
+    4096 pairs.  Same sums; the literal configuration costs 3 bootstraps more per pair.
     Wires: a = 0..nbits-1, b = nbits..2nbits-1, sum = 2nbits..3nbits (nbits+1 wires), then temporaries.
     Returns (gates, n_wires, a_wires, b_wires, sum_wires)."""
     a = list(range(nbits))
@@ -18,6 +21,9 @@ def ripple_carry_adder(nbits=8):
     nxt = 3 * nbits + 1
     gates = []
     carry = None
+    if carry_in_zero:
+        carry = nxt; nxt += 1
+        gates.append(Gate(OPS["CONST0"], -1, -1, -1, carry))
     for i in range(nbits):
         if carry is None:
             gates.append(Gate(OPS["XOR"], a[i], b[i], -1, s[i]))
@@ -35,7 +41,7 @@ def ripple_carry_adder(nbits=8):
                 nxt += 1
             gates.append(Gate(OPS["OR"], g, pc, -1, newc))
             carry = newc
-    if nbits == 1:
+    if nbits == 1 and not carry_in_zero:
         gates.append(Gate(OPS["COPY"], carry, -1, -1, s[1]))
     return gates, nxt, a, b, s
 

@@ -107,6 +107,10 @@ struct Worker {
         cv.notify_all();
         if (th.joinable()) th.join();
     }
+    // A process may exit (return from main, exit(), the interpreter's shutdown) without eoc_gpu_shutdown / resetGateKey:
+    // the static context then destroys its slots, and a std::thread that is still joinable there calls std::terminate
+    // (SIGABRT at exit).  Stop and join here; the thread only waits on `cv`, it makes no HIP call on the way out.
+    ~Worker() { shutdown(); }
 };
 
 struct Slot {
@@ -870,6 +874,10 @@ extern "C" int eoc_upload_cloud_key_arrays(const int32_t *bk, const int32_t *ksk
         return EOC_ERR_STATE;
     }
     if (!bk || !ksk) return EOC_ERR_NO_KEY;
+    {   // pending submissions still read the key images that are about to be rebuilt
+        int rc = drain_async_locked();
+        if (rc) return rc;
+    }
     // images are built once, on the first device (H2D of the torus form, forward transforms on the GPU, KSK padding)
     int rc = eoc_engine_load_cloud_key(G.slots[0].e, bk, ksk);
     if (rc) return rc;
@@ -942,6 +950,11 @@ extern "C" void *eoc_host_alloc(size_t bytes)
 extern "C" void eoc_host_free(void *p)
 {
     if (!p) return;
+    {   // a buffer of a submission still in flight must not be released under its DMA (a Node Buffer finalizer, a Python
+        // PinnedArray going out of scope): complete what is pending first
+        std::lock_guard<std::mutex> g(G.mu);
+        if (G.ring[0].active || G.ring[1].active) (void)drain_async_locked();
+    }
     {
         std::lock_guard<std::mutex> g(g_pin_mu);
         g_pinned.erase(reinterpret_cast<uintptr_t>(p));

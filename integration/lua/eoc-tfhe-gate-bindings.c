@@ -174,6 +174,19 @@ static int l_netlistOptimize(lua_State *L) {          /* (gates, outputs: int32 
   return 1;
 }
 
+static int l_circuitBootstraps(lua_State *L) {        /* (gates) -> blind rotations per instance (MUX = 2, NOT / COPY = 0), or -1 */
+  size_t gbytes;
+  const char *g = luaL_checklstring(L, 1, &gbytes);
+  if (gbytes % sizeof(eoc_gate)) { lua_pushinteger(L, -1); return 1; }
+  lua_pushinteger(L, (lua_Integer)eoc_circuit_bootstraps((const eoc_gate *)g, gbytes / sizeof(eoc_gate)));
+  return 1;
+}
+static int l_deviceCount(lua_State *L) { lua_pushinteger(L, eoc_device_count()); return 1; }
+static int l_engineCount(lua_State *L) { lua_pushinteger(L, eoc_gpu_engine_count()); return 1; }
+/* NOT mirrored from the Node addon (tests/test_binding_surfaces.py lists them): hostAlloc / gateBatchSubmit /
+ * gateBatchWait -- the asynchronous batch path works on pinned, MUTABLE host buffers the caller keeps alive, which a
+ * Lua string (immutable, garbage collected) cannot be. */
+
 /* appended to the luaL_Reg table of luaopen_tfhe (ao-tfhe/eoc-tfhe-bindings.c:130-144) */
   {"generateGateKey", l_generateGateKey}, {"resetGateKey", l_resetGateKey}, {"setDevices", l_setDevices},
   {"encryptBit", l_encryptBit},
@@ -186,3 +199,4 @@ static int l_netlistOptimize(lua_State *L) {          /* (gates, outputs: int32 
   {"keyMode", l_keyMode},
   {"sampleInts", l_sampleInts}, {"encryptBits", l_encryptBits}, {"decryptBits", l_decryptBits},
   {"gateBatch", l_gateBatch}, {"circuitRun", l_circuitRun}, {"netlistOptimize", l_netlistOptimize},
+  {"circuitBootstraps", l_circuitBootstraps}, {"deviceCount", l_deviceCount}, {"engineCount", l_engineCount},

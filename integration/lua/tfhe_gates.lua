@@ -1,8 +1,12 @@
 -- tfhe_gates.lua -- text to append to ao-tfhe/tfhe.lua (same pass-through style as :4-53; needs Lua 5.3 string.pack).
 -- Not executed in this repository (no Lua interpreter in the image); integration/node/tfhe.js is its tested twin and has
--- the same functions with the same netlists.
+-- the same functions with the same netlists: tests/test_binding_surfaces.py compares the two name by name (`and`, `or`,
+-- `not` are Lua keywords: band / bor / bnot here) and lists the three string-level circuits only the JS side has
+-- (addBits, lessThanBits, minMaxBits: they decode base64, which the Lua 5.3 standard library cannot).
 function Tfhe.generateGateKey(lambda, seed) return Tfhe.backend.generateGateKey(lambda, seed) end
 function Tfhe.resetGateKey()                return Tfhe.backend.resetGateKey() end
+function Tfhe.deviceCount()                 return Tfhe.backend.deviceCount() end     -- GPUs the process can see
+function Tfhe.engineCount()                 return Tfhe.backend.engineCount() end     -- engines behind the global key
 function Tfhe.setDevices(...)               return Tfhe.backend.setDevices(...) end   -- GPUs behind the next gate key
 function Tfhe.encryptBit(bit, key)          return Tfhe.backend.encryptBit(bit, key) end
 function Tfhe.constantBit(bit)              return Tfhe.backend.constantBit(bit) end
@@ -40,10 +44,13 @@ local function newNetlist()
   function nl.packed() return table.concat(nl.gates) end
   return nl
 end
--- ripple-carry adder, LSB first: half adder at bit 0, then 2 XOR + 2 AND + 1 OR per bit
-function Tfhe.adderNetlist(nbits)
+-- ripple-carry adder, LSB first: half adder at bit 0, then 2 XOR + 2 AND + 1 OR per bit (5 nbits - 3 bootstraps);
+-- carryInZero = true: a full adder at bit 0 as well, its carry-in bootsCONSTANT(0) -- the uniform 5 gates per bit
+-- (40 per 8-bit pair) BASELINE.md counts
+function Tfhe.adderNetlist(nbits, carryInZero)
   local nl = newNetlist()
   local a, b, sum, c = nl.wire(nbits), nl.wire(nbits), {}, nil
+  if carryInZero then c = nl.gate(OP.CONST0, -1) end
   for i = 0, nbits - 1 do
     local p, g = nl.gate(OP.XOR, a + i, b + i), nl.gate(OP.AND, a + i, b + i)
     if c then
@@ -80,6 +87,53 @@ function Tfhe.minMaxNetlist(nbits)
   end
   return nl, a, b, lt, mn, mx
 end
+-- a - b mod 2^nbits and the final borrow (= a < b), LSB first: d_i = a_i ^ b_i ^ br_i, br_{i+1} = MUX(a_i ^ b_i, b_i, br_i)
+function Tfhe.subtractorNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, diff = nl.wire(nbits), nl.wire(nbits), {}
+  diff[1] = nl.gate(OP.XOR, a, b)
+  local br = nl.gate(OP.ANDNY, a, b)
+  for i = 1, nbits - 1 do
+    local p = nl.gate(OP.XOR, a + i, b + i)
+    diff[#diff + 1] = nl.gate(OP.XOR, p, br)
+    br = nl.gate(OP.MUX, p, b + i, br)
+  end
+  return nl, a, b, diff, br
+end
+-- a * b -> 2 nbits bits, LSB first: nbits^2 AND partial products, nbits - 1 shifted ripple-carry rows
+function Tfhe.multiplierNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, pp = nl.wire(nbits), nl.wire(nbits), {}
+  for r = 0, nbits - 1 do
+    pp[r] = {}
+    for j = 0, nbits - 1 do pp[r][j] = nl.gate(OP.AND, a + j, b + r) end
+  end
+  local prod, acc, top = { pp[0][0] }, {}, nil          -- acc[0 .. nbits - 2]: the row above the current one, shifted
+  for j = 1, nbits - 1 do acc[j - 1] = pp[0][j] end
+  for r = 1, nbits - 1 do
+    local nxt, carry = {}, nil
+    for j = 0, nbits - 1 do
+      local x, y = top, pp[r][j]
+      if j < nbits - 1 then x = acc[j] end
+      if x == nil and carry == nil then nxt[j] = y
+      elseif x == nil or carry == nil then
+        local z = x
+        if z == nil then z = carry end
+        nxt[j] = nl.gate(OP.XOR, z, y); carry = nl.gate(OP.AND, z, y)
+      else
+        local p, g = nl.gate(OP.XOR, x, y), nl.gate(OP.AND, x, y)
+        nxt[j] = nl.gate(OP.XOR, p, carry); carry = nl.gate(OP.OR, g, nl.gate(OP.AND, p, carry))
+      end
+    end
+    prod[#prod + 1] = nxt[0]
+    for j = 1, nbits - 1 do acc[j - 1] = nxt[j] end
+    top = carry
+  end
+  for j = 0, nbits - 2 do prod[#prod + 1] = acc[j] end
+  if top == nil then top = nl.gate(OP.CONST0, -1) end
+  prod[#prod + 1] = top
+  return nl, a, b, prod
+end
 -- run a netlist over `instances` instances; inputs = { [firstWire] = samples [k][instances][n+1] }
 function Tfhe.runNetlist(nl, inputs, instances)
   local plane = instances * Tfhe.backend.sampleInts() * 4
@@ -103,6 +157,23 @@ function Tfhe.addBitsBatch(A, B, nbits, instances)
   local out = {}
   for i = 1, #sum do out[i] = planes(wires, sum[i], 1, instances) end
   return table.concat(out)                                -- [nbits + 1][instances][n+1]
+end
+function Tfhe.subtractBitsBatch(A, B, nbits, instances)  -- -> [nbits + 1][instances][n+1]: difference bits, then the borrow
+  local nl, a, b, diff, borrow = Tfhe.subtractorNetlist(nbits)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  if not wires then return nil end
+  local out = {}
+  for i = 1, #diff do out[i] = planes(wires, diff[i], 1, instances) end
+  out[#out + 1] = planes(wires, borrow, 1, instances)
+  return table.concat(out)
+end
+function Tfhe.multiplyBitsBatch(A, B, nbits, instances)  -- -> [2 nbits][instances][n+1]
+  local nl, a, b, prod = Tfhe.multiplierNetlist(nbits)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  if not wires then return nil end
+  local out = {}
+  for i = 1, #prod do out[i] = planes(wires, prod[i], 1, instances) end
+  return table.concat(out)
 end
 function Tfhe.equalBits(X, Y)                             -- X, Y: samples [nbits][n+1]; one ciphertext: 1 iff equal
   local nbits = #X // (Tfhe.backend.sampleInts() * 4)

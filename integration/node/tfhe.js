@@ -44,6 +44,8 @@ Tfhe.importCloudKey = k => B.importCloudKey(k);                 // server: cloud
 Tfhe.exportCloudKeyToFile = path => B.exportCloudKeyToFile(path);
 Tfhe.importCloudKeyFromFile = path => B.importCloudKeyFromFile(path);
 Tfhe.keyMode = () => B.keyMode();                               // 0 none, 1 secret + cloud, 2 cloud only
+Tfhe.deviceCount = () => B.deviceCount();
+Tfhe.engineCount = () => B.engineCount();
 
 // ---- circuit layer: netlists evaluated by ONE backend call (eoc_global_circuit_run), batched over instances --------
 // A netlist is a list of gates {op, in0, in1, in2, out} over numbered wires; wires travel as one Buffer
@@ -59,9 +61,11 @@ class Netlist {
 }
 Tfhe.Netlist = Netlist;
 // ripple-carry adder, LSB first: half adder at bit 0, then 2 XOR + 2 AND + 1 OR per bit (5 nbits - 3 bootstraps)
-Tfhe.adderNetlist = nbits => {
+// carryInZero: a full adder at bit 0 as well, its carry-in bootsCONSTANT(0) -- the uniform 5 gates per bit (40 per 8-bit
+// pair) BASELINE.md counts
+Tfhe.adderNetlist = (nbits, carryInZero) => {
   const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), sum = [];
-  let c = -1;
+  let c = carryInZero ? nl.gate(OP.CONST0, -1) : -1;
   for (let i = 0; i < nbits; i++) {
     const p = nl.gate(OP.XOR, a + i, b + i), g = nl.gate(OP.AND, a + i, b + i);
     if (c < 0) { sum.push(p); c = g; } else { sum.push(nl.gate(OP.XOR, p, c)); c = nl.gate(OP.OR, g, nl.gate(OP.AND, p, c)); }
@@ -179,6 +183,12 @@ Tfhe.multiplyBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [2 nbits][i
   const { nl, a, b, prod } = Tfhe.multiplierNetlist(nbits);
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
   return wires && Buffer.concat(prod.map(wi => planes(wires, wi, 1, instances)));
+};
+Tfhe.minMaxBitsBatch = (Abuf, Bbuf, nbits, instances) => {     // -> { min, max: [nbits][instances][n+1], lt: [instances][n+1] }
+  const { nl, a, b, lt, min, max } = Tfhe.minMaxNetlist(nbits);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  const pick = ws => Buffer.concat(ws.map(wi => planes(wires, wi, 1, instances)));
+  return wires && { min: pick(min), max: pick(max), lt: planes(wires, lt, 1, instances) };
 };
 Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1] (one instance)
   const nbits = X.length / (B.sampleInts() * 4);

@@ -319,13 +319,10 @@ static inline int32_t wrap_convert(double x)
     return (int32_t)(uint32_t)(uint64_t)(int64_t)x; /* C cast: truncation toward zero */
 }
 
-void orc_fft_inv(const double *spec, int32_t *poly)
+/* the inverse transform up to, not including, the conversion: vals[j] = Re y_j, vals[j + NH] = Im y_j */
+void orc_fft_inv_raw(const double *spec, double *vals)
 {
     double xr[NH], xi[NH];
-    if (g_round_nearest < 0) {
-        const char *m = getenv("ORC_ROUND_NEAREST");
-        g_round_nearest = (m && m[0] == '1') ? 1 : 0;
-    }
     for (int e = 0; e < NH; e++) {
         xr[e] = spec[2 * sigma_of(e)];
         xi[e] = spec[2 * sigma_of(e) + 1];
@@ -336,15 +333,26 @@ void orc_fft_inv(const double *spec, int32_t *poly)
             for (int j = 0; j < h; j++)
                 butterfly_inv(&xr[base + j], &xi[base + j], &xr[base + j + h], &xi[base + j + h], j << s, s >= 6);
     }
-    double mx = 0.0;
     for (int j = 0; j < NH; j++) {
         double tc = EOC_E2048[j][0] * 0.001953125, ts = EOC_E2048[j][1] * 0.001953125;
-        double re = FMA(xr[j], tc, xi[j] * ts);
-        double im = FMA(xi[j], tc, -(xr[j] * ts));
-        if (fabs(re) > mx) mx = fabs(re);
-        if (fabs(im) > mx) mx = fabs(im);
-        poly[j] = wrap_convert(re);
-        poly[j + NH] = wrap_convert(im);
+        vals[j] = FMA(xr[j], tc, xi[j] * ts);
+        vals[j + NH] = FMA(xi[j], tc, -(xr[j] * ts));
+    }
+}
+
+/* tLweFromFFTConvert / TorusPolynomial_fft: Torus32(int64(x)), truncation then wrap */
+void orc_fft_inv(const double *spec, int32_t *poly)
+{
+    double vals[N];
+    if (g_round_nearest < 0) {
+        const char *m = getenv("ORC_ROUND_NEAREST");
+        g_round_nearest = (m && m[0] == '1') ? 1 : 0;
+    }
+    orc_fft_inv_raw(spec, vals);
+    double mx = 0.0;
+    for (int j = 0; j < N; j++) {
+        if (fabs(vals[j]) > mx) mx = fabs(vals[j]);
+        poly[j] = wrap_convert(vals[j]);
     }
     if (mx > g_max_abs_conv) g_max_abs_conv = mx; /* benign race between threads: a diagnostic high-water mark */
 }

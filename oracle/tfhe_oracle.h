@@ -82,6 +82,7 @@ int orc_decrypt_bit(const orc_params *p, const int32_t *lwe_key, const int32_t *
 /* ---- canonical transform v2 ---- */
 void orc_fft_fwd(const int32_t *poly, double *spec);   /* 1024 ints -> 512 complex, order sigma */
 void orc_fft_inv(const double *spec, int32_t *poly);   /* 512 complex -> 1024 torus32 (truncated, wrapped) */
+void orc_fft_inv_raw(const double *spec, double *vals); /* the same, stopped before the conversion: 1024 doubles */
 /* largest magnitude the inverse transform has converted so far (diagnostic: tests assert < 2^51, the range on which
  * the HIP kernel's two-operation conversion equals Torus32(int64(x))) */
 double orc_dbg_max_conv(int reset);

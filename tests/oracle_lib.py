@@ -62,6 +62,7 @@ def lib():
         L.orc_decrypt_bit.argtypes = [PP, i32p, i32p]
         L.orc_fft_fwd.argtypes = [i32p, f64p]
         L.orc_fft_inv.argtypes = [f64p, i32p]
+        L.orc_fft_inv_raw.argtypes = [f64p, f64p]
         L.orc_gate_linear.argtypes = [PP, C.c_int, i32p, i32p, i32p]
         L.orc_modswitch_sample.argtypes = [PP, i32p, i32p, i32p]
         L.orc_blind_rotate_step.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_int, i32p, C.c_int]
@@ -166,3 +167,10 @@ def fft_inv(spec):
     poly = np.zeros(N, np.int32)
     lib().orc_fft_inv(np.ascontiguousarray(spec, np.float64), poly)
     return poly
+
+
+def fft_inv_raw(spec):
+    """the inverse transform's values BEFORE Torus32(int64(.)): what the conversion contract is stated on"""
+    vals = np.zeros(N, np.float64)
+    lib().orc_fft_inv_raw(np.ascontiguousarray(spec, np.float64), vals)
+    return vals

@@ -32,6 +32,22 @@ def test_adder_all_inputs(nbits):
     assert np.array_equal(_value(c.evaluate_plain(gates, w), s), A + B)
 
 
+@pytest.mark.parametrize("nbits", [1, 2, 4])
+def test_literal_baseline_adder_five_gates_per_bit(nbits):
+    """BASELINE.md counts configs[2] at a uniform 5 bootstrapped gates per bit (40 per 8-bit pair, 163 840 for 4096
+    pairs): the carry_in_zero variant is that netlist -- a full adder at bit 0 whose carry-in is bootsCONSTANT(0)"""
+    gates, nw, a, b, s = c.ripple_carry_adder(nbits, carry_in_zero=True)
+    assert circuit_bootstraps(gates) == 5 * nbits
+    assert gates[0].op == OPS["CONST0"]
+    A, B, S = _words(nbits)
+    w = np.zeros((nw, S), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    assert np.array_equal(_value(c.evaluate_plain(gates, w), s), A + B)
+    assert circuit_bootstraps(c.ripple_carry_adder(8, carry_in_zero=True)[0]) * 4096 == 163840
+    assert circuit_bootstraps(c.ripple_carry_adder(8)[0]) == 37
+
+
 @pytest.mark.parametrize("nbits", [1, 3, 5])
 def test_less_than_and_min_max_all_inputs(nbits):
     A, B, S = _words(nbits)

@@ -48,7 +48,10 @@ def test_config3_adder_4096_pairs(eoc, rig):
     from eoc_tfhe_amd import circuits
     p, sk, eng = rig
     torch = torch_cuda()
-    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8)
+    # the literal configuration: 5 bootstrapped gates per bit = 40 per pair = 163 840 bootstraps; the
+    # 37-gate form with a half adder at bit 0 is covered by tests/test_gpu_circuits.py and tests/test_gpu_cloud_server.py
+    gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8, carry_in_zero=True)
+    assert eoc.circuit_bootstraps(gates) == 40
     S = 4096
     rng = np.random.default_rng(3)
     A, B = rng.integers(0, 256, S), rng.integers(0, 256, S)
@@ -61,11 +64,11 @@ def test_config3_adder_4096_pairs(eoc, rig):
     before = eng.stats()["bootstraps"]
     eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
     sync()
-    assert eng.stats()["bootstraps"] - before == 37 * S
+    assert eng.stats()["bootstraps"] - before == 40 * S == 163840
     sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
     total = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
     assert np.array_equal(total, A + B)
-    # ciphertexts vs oracle: every wire the netlist writes, first 16 instances (592 bootstraps)
+    # ciphertexts vs oracle: every wire the netlist writes, first 16 instances (640 bootstraps)
     want = _oracle_netlist(ol.Oracle(0, 1), gates, inputs)
     got = wires[:, :ORACLE_INSTANCES].cpu().numpy()
     for g in gates:

@@ -96,6 +96,40 @@ def test_fft_forward_inverse_bit_exact(eoc, rig_small):
     assert np.array_equal(got_i, want_i)
 
 
+def test_conversion_contract_pinned_around_2_pow_51(eoc, rig_small):
+    """Torus32(int64(x)).  The kernel converts with two exact operations, t = trunc(x) and
+    t + 1.5 * 2^52 (low dword), which IS Torus32(int64(x)) for |x| < 2^51 and is NOT beyond (the sum leaves the binade
+    whose unit is 1).  This test pins both halves of that contract on the device:
+      * |x| < 2^51, including values within 2^31 of the limit and non-integers of both signs: device == oracle;
+      * 2^51 <= |x| < 2^52: the device returns exactly what the two-operation form computes (emulated here in numpy
+        on the oracle's pre-conversion doubles) -- a defined, documented divergence from the oracle, not noise.
+    Why no reachable accumulator is up there: DESIGN.md 2.1 (Set B and every shape with l * Bg < 1024: impossible by
+    the exact bound 2 l N (Bg/2) 2^31 < 2^51; Set A: the exact bound is 2^52 and the probability bound is 2 e^-512)."""
+    rng = np.random.default_rng(51)
+    rows = []
+    for scale_bits, hi in ((31, (1 << 20) - 1), (31, (1 << 21) - 1), (30.5, (1 << 20) - 1), (31.7, (1 << 19))):
+        c = rng.integers(-hi, hi + 1, N).astype(np.int32)
+        c[:8] = [hi, -hi, hi - 1, -(hi - 1), 1, -1, 0, hi // 2]
+        rows.append(ol.fft_fwd(c) * (2.0 ** scale_bits))         # inverse transform returns ~ c * 2^scale_bits
+    specs = np.stack(rows)
+    raw = np.stack([ol.fft_inv_raw(s) for s in specs])           # the values the conversion is applied to
+    want = np.stack([ol.fft_inv(s) for s in specs])
+    d_in = to_dev(specs)
+    d_out = dev_empty((specs.shape[0], N), torch_cuda().int32)
+    rig_small.eng.fft_inv_device(d_in.data_ptr(), d_out.data_ptr(), specs.shape[0])
+    sync()
+    got = d_out.cpu().numpy()
+    mag = np.abs(raw)
+    low, high = mag < 2.0 ** 51, (mag >= 2.0 ** 51) & (mag < 2.0 ** 52)
+    assert low.sum() > 2000 and high.sum() > 400                  # both ranges are populated ...
+    assert (mag[low] > 2.0 ** 51 - 2.0 ** 32).sum() >= 4          # ... also right below the limit
+    assert (raw != np.trunc(raw)).sum() > 1000                    # ... with fractional parts to truncate
+    assert np.array_equal(got[low], want[low])                    # the contract
+    emu = ((np.trunc(raw) + 6755399441055744.0).view(np.uint64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    assert np.array_equal(got, emu)                               # the device is the two-operation form, everywhere
+    assert (got[high] != want[high]).mean() > 0.5                 # and that form is not int64 conversion up there
+
+
 def test_keygen_and_bkfft_parity(eoc, rig_small):
     r = rig_small
     assert np.array_equal(r.sk.lwe_key, r.orc.lwe_key)

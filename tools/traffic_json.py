@@ -30,4 +30,19 @@ for path, name, kern in zip(sys.argv[1:], ("A", "B"), ("eoc::k_blind_rotate<2, 1
         out[f"blind_rotate_{name}_1024"] = int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
         out[f"detail_{name}"] = {"FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
                                  "TCC_HIT": v.get("TCC_HIT_sum"), "TCC_MISS": v.get("TCC_MISS_sum")}
+    # the co-bounds bench.py prints beside the FP64 fraction: the LDS pipe (SQ passes) and the L2 stream (TCC pass)
+    if "SQ_WAIT_INST_LDS" in v and "SQ_WAVE_CYCLES" in v and v["SQ_WAVE_CYCLES"] > 0:
+        waves = v.get("SQ_WAVES", 2048.0)
+        steps = {"A": 500, "B": 630}[name] * (1 if name == "A" else 0.5)   # Set B: a launch is half a blind rotation
+        wave_steps = waves * steps
+        cb = {"lds_wait_frac": round(v["SQ_WAIT_INST_LDS"] / v["SQ_WAVE_CYCLES"], 4),
+              "SQ_WAIT_INST_LDS": v["SQ_WAIT_INST_LDS"], "SQ_WAVE_CYCLES": v["SQ_WAVE_CYCLES"],
+              "lds_insts_per_wave_step": round(v.get("SQ_INSTS_LDS", 0.0) / wave_steps, 1),
+              "valu_insts_per_wave_step": round(v.get("SQ_INSTS_VALU", 0.0) / wave_steps, 1),
+              "ds_write_b128_per_wave_step": {"A": 56, "B": 72}[name],
+              "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT")}
+        if v.get("TCC_HIT_sum") is not None:
+            cb["tcc_hit_bytes_per_launch"] = int(v["TCC_HIT_sum"] * 128)
+            cb["tcc_hit_rate"] = round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v.get("TCC_MISS_sum", 0.0)), 4)
+        out[f"cobounds_{name}"] = cb
 print(json.dumps(out, indent=1))
