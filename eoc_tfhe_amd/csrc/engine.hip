@@ -229,14 +229,14 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (getenv("EOC_TFHE_NO_FOLD")) e->no_fold = true;
         if (const char *s = getenv("EOC_TFHE_BR_PARTS")) e->br_parts = atoi(s);
     }
-    // key-switch kernels use > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
-#define EOC_KS_ATTR(BB, TT, NWV, JBV, CWV)                                                                       \
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_keyswitch<BB, TT, NWV, JBV, CWV>),                      \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, KSCfg<BB, TT, NWV, JBV, CWV>::LDS_BYTES)
-    EOC_KS_ATTR(2, 8, 2, 4, 128);
-    EOC_KS_ATTR(2, 8, 8, 4, 64);
-    EOC_KS_ATTR(2, 8, 12, 4, 64);
-    EOC_KS_ATTR(2, 8, 8, 2, 128);
+    // the key-switch kernel uses > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
+#define EOC_KS_ATTR(TT, NWV, IWV)                                                                   \
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_keyswitch_waves<TT, NWV, IWV>),           \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, KS3Cfg<TT, NWV, IWV>::LDS_BYTES)
+    EOC_KS_ATTR(8, 8, 16);
+    EOC_KS_ATTR(8, 8, 32);
+    EOC_KS_ATTR(8, 4, 64);
+    EOC_KS_ATTR(8, 8, 64);
 #undef EOC_KS_ATTR
     *out = e;
     return EOC_OK;
@@ -617,23 +617,21 @@ static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint3
         HIP_TRY(hipGetLastError());
     }
     const uint32_t ntiles = (S + KS_GT - 1) / KS_GT;
-    const int nw = (int)(e->n1p / KS_CW);
-    dim3 grid(ntiles * (kN / KS_IT), ngates);
+    const int ncb = (int)(e->n1p / 64); // blocks of 64 key columns: 4 (n <= 255), 8 (Set A), 12 (Set B), 16
     const int bb = e->p.ks_basebit, t = e->p.ks_t;
-#define EOC_KS_LAUNCH(BB, TT, NWV, JBV, CWV)                                                              \
+#define EOC_KS_LAUNCH(TT, NWV, IWV)                                                                     \
     do {                                                                                                  \
-        auto kfn = k_keyswitch<BB, TT, NWV, JBV, CWV>;                                                    \
-        constexpr int lds = KSCfg<BB, TT, NWV, JBV, CWV>::LDS_BYTES;                                      \
-        static_assert(NWV * CWV % KS_CW == 0, "waves x columns must cover whole 128-column units");       \
-        hipLaunchKernelGGL(kfn, grid, dim3(64 * NWV), lds, st, d_descs, a);                               \
+        auto kfn = k_keyswitch_waves<TT, NWV, IWV>;                                                       \
+        constexpr int lds = KS3Cfg<TT, NWV, IWV>::LDS_BYTES;                                              \
+        constexpr int ns = KS3Cfg<TT, NWV, IWV>::NS;                                                      \
+        hipLaunchKernelGGL(kfn, dim3(ntiles * (unsigned)ncb * ns, ngates), dim3(64 * NWV), lds, st, d_descs, a); \
     } while (0)
-    // n1p = 512 (385 <= n <= 511, Set A): eight waves of 64 columns (122 VGPRs, four waves per SIMD) beat four waves
-    // of 128 columns (200 VGPRs, two per SIMD) by 6 % at 1024 gates and 9 % at 4096; n1p = 768 (Set B): twelve waves
-    // of 64 columns with 4 digits per stage beat six of 128 with 2 (one workgroup per CU either way) by 16 %
-    if (bb == 2 && t == 8 && nw == 2) EOC_KS_LAUNCH(2, 8, 2, 4, 128);
-    else if (bb == 2 && t == 8 && nw == 4) EOC_KS_LAUNCH(2, 8, 8, 4, 64);
-    else if (bb == 2 && t == 8 && nw == 6) EOC_KS_LAUNCH(2, 8, 12, 4, 64);
-    else if (bb == 2 && t == 8 && nw == 8) EOC_KS_LAUNCH(2, 8, 8, 2, 128);
+    // basebit 2, t 8 (both default sets): waves per workgroup x indices per wave chosen so that 1024 gates give every SIMD
+    // its 3-4 waves: 4096 waves for n1p = 256 / 512 / 1024, 3072 (three 4-wave workgroups per CU) for n1p = 768
+    if (bb == 2 && t == 8 && ncb == 4) EOC_KS_LAUNCH(8, 8, 16);
+    else if (bb == 2 && t == 8 && ncb == 8) EOC_KS_LAUNCH(8, 8, 32);
+    else if (bb == 2 && t == 8 && ncb == 12) EOC_KS_LAUNCH(8, 4, 64);
+    else if (bb == 2 && t == 8 && ncb == 16) EOC_KS_LAUNCH(8, 8, 64);
     else // any other shape (no default set has one): the plain one-thread-per-word form
         hipLaunchKernelGGL(k_keyswitch_generic, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
 #undef EOC_KS_LAUNCH

@@ -919,11 +919,9 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 // K3: key switch (lweKeySwitch), two launches.
 //   k_ks_init      per ciphertext: ubarT[i][job] = u_i + 2^(31 - t*basebit)  (sum of the two extracted
 //                  samples + (0, mu) for MUX), out = (0, ..., 0, b')
-//   k_keyswitch    one workgroup = a tile of KS_GT ciphertexts x a slice of KS_IT indices i.  Each
-//                  (i, j) loads the base-1 candidate rows ONCE (16 B per lane, coalesced) and every
-//                  ciphertext of the tile picks its row by its digit (wave-uniform scalar), so key
-//                  traffic drops by KS_GT versus one pass per ciphertext.  Partial sums leave through
-//                  integer atomics (exact, order independent).
+//   k_keyswitch_waves   basebit 2, even t: 64 ciphertexts per workgroup (one per lane), two digits per LDS look-up
+//                  through a table of row sums, partial sums of the i-slices through LDS and a few integer atomics
+//   k_keyswitch_generic any other (basebit, t): the plain one-thread-per-output-word form
 // KSK device image: [N*t][base-1][n1p], rows padded with zeros to n1p (multiple of 256).
 // =================================================================================================
 constexpr int KS_GT = 64; // ciphertexts per workgroup (one per lane)
@@ -961,106 +959,107 @@ __global__ __launch_bounds__(256) void k_ks_init(const GateDesc *__restrict__ de
     }
 }
 
-// grid: x = ceil(S / 64) * (N / KS_IT), y = gates; block = 64 * NW threads, NW * CW = n1p
-// One workgroup = 64 ciphertexts (ONE PER LANE) x a slice of KS_IT indices i; wave w owns key columns
-// [CW w, CW w + CW), CW = 128 (accumulators = 128 VGPRs, two waves per SIMD) or 64 (four waves per SIMD).  The base-1 candidate rows of JB consecutive j are staged in LDS next to an
-// all-zero row (digit 0), and every lane reads the row ITS digit selects (lanes with equal digits
-// share an address = broadcast; rows are skewed by 16 B so that different digits hit different
-// banks).  Per (i, j) a wave issues 32 ds_read_b128 + 128 subtractions for 64 ciphertexts -- no
-// scalar selects.  Partial sums are transposed through LDS and leave as coalesced integer atomics.
-constexpr int KS_IT = 32;
-constexpr int KS_CW = 128; // unit of the key image's row padding (n1p = multiple of 2 * KS_CW) and default columns per wave
-
-template <int BASEBIT, int T, int NW, int JB, int CWV = KS_CW>
-struct KSCfg {
-    static constexpr int CW = CWV;                        // key columns per wave
-    static constexpr int BASE = 1 << BASEBIT;
-    static constexpr int NT = 64 * NW;                   // threads
-    static constexpr int N1P = CW * NW;
-    static constexpr int ROWI = N1P + 4;                 // LDS row stride in ints (16-B skew)
-    static constexpr int BUFI = JB * BASE * ROWI;        // one staging buffer, ints
-    static constexpr int TRANSPOSE_BYTES = NW * 64 * 36 * 4; // final 64 x 32 transposes, one per wave
-    static constexpr int LDS_BYTES = 2 * BUFI * 4 > TRANSPOSE_BYTES ? 2 * BUFI * 4 : TRANSPOSE_BYTES;
-    static constexpr int STAGE_I4 = JB * (BASE - 1) * N1P / 4; // int4 per stage
-    static constexpr int LD_PER_THREAD = (STAGE_I4 + NT - 1) / NT;
-};
-
 typedef int i4 __attribute__((ext_vector_type(4)));
 
-template <int BASEBIT, int T, int NW, int JB, int CWV = KS_CW>
-__global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void k_keyswitch(const GateDesc *__restrict__ descs, KSArgs A)
+// ---- k_keyswitch_waves<T, NWV, IW>: basebit 2, even t (both default sets) ------------------------------------------
+// One lane = one ciphertext.  A workgroup is (tile of 64 ciphertexts) x (ONE block of 64 key columns) x (a slice of
+// NWV * IW indices i); its NWV waves split the SLICE: wave w walks IW indices of its own.
+//   * Two digits per look-up.  For digits j, j + 1 of index i the wave first combines the 3 + 3 candidate key rows into
+//     the table of their 16 sums, S[d1][d2] = row_j[d1] + row_{j+1}[d2] (64 columns, 4.3 KB, double-buffered in LDS;
+//     d1 = d2 = 0 is the zero row), built by its own lanes: lane = (d1, 4-column chunk), 4 coalesced 16-byte key loads and
+//     4 ds_write_b128 per lane and stage.  Every lane then selects with the 4-bit nibble of its operand word that holds
+//     both digits of ITS ciphertext and does ONE look-up and ONE subtraction per column for the pair:
+//     acc -= S[nibble]  ==  acc -= row_j[d1]; acc -= row_{j+1}[d2]  in wrapping int32 arithmetic -- bit-identical, at half
+//     the subtractions and half the LDS reads per ciphertext of the one-digit form (rows are skewed by 16 B so that the 16
+//     table rows cover the 64 banks: lanes with equal nibbles share an address, others never share a bank).
+//   * No barrier in the stage loop: the table is the wave's own (a wave's LDS operations execute in order).
+//   * The NWV partial sums of a workgroup are added through LDS (tree: the upper half of the waves parks its
+//     accumulators, the lower half adds), so only the kN / (NWV IW) = 2...8 slices meet in the output row through integer
+//     atomics (exact, order independent), 256 contiguous bytes per atomic instruction.
+// History (Set A, 1024 gates): round 3's kernel -- one digit per look-up, the candidate rows of 4 digits staged per
+// workgroup barrier, one i-slice x all columns per workgroup, 32 atomics per output word -- took 0.212 ms: integer issue
+// and the LDS pipe were loaded exactly alike (4 bytes from LDS per subtraction) and 16.8 M atomics arrived together at the
+// end of the kernel (33 us, timing-only ablation).  Pair tables alone: 0.180 ms; with one i-range per wave: 0.133 ms
+// (Set B: 0.363 -> 0.304 -> 0.196 ms).  An XCD-aware workgroup order (all tiles of a slice on one XCD) changed nothing:
+// the 50 MB key image is served by the Infinity Cache either way.
+template <int T, int NWV, int IW>
+struct KS3Cfg {
+    static constexpr int NT = 64 * NWV;
+    static constexpr int ROWI = 64 + 4;                  // table row stride in ints (16-B skew: 16 rows cover the 64 banks)
+    static constexpr int TABI = 16 * ROWI;               // one table, ints
+    static constexpr int WAVE_I = 2 * TABI;              // two tables per wave
+    static constexpr int RED_I = 64 * ROWI;              // one wave's partial sums [64 ciphertexts][64 columns + 4]
+    static constexpr int TAB_BYTES = NWV * WAVE_I * 4, RED_BYTES = (NWV > 1 ? NWV / 2 : 1) * RED_I * 4;
+    static constexpr int LDS_BYTES = TAB_BYTES > RED_BYTES ? TAB_BYTES : RED_BYTES;
+    static constexpr int NPAIR = T / 2;
+    static constexpr int NSTAGE = IW * NPAIR;
+    static constexpr int SLICE_I = NWV * IW;             // indices i per workgroup
+    static constexpr int NS = kN / SLICE_I;              // slices (= atomics per output word)
+};
+
+// grid: x = ntiles * (n1p / 64) * NS, y = gates; block = 64 NWV
+template <int T, int NWV, int IW>
+__global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc *__restrict__ descs, KSArgs A)
 {
-    typedef KSCfg<BASEBIT, T, NW, JB, CWV> C;
-    static_assert(T % JB == 0, "JB must divide T");
+    typedef KS3Cfg<T, NWV, IW> C;
+    static_assert(T % 2 == 0 && kN % C::SLICE_I == 0 && (NWV & (NWV - 1)) == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *s_rows = reinterpret_cast<int *>(smem); // [2][JB][BASE][ROWI]
+    int *s_all = reinterpret_cast<int *>(smem);
 
     const GateDesc d = descs[blockIdx.y];
-    const uint32_t ntiles = (A.S + 63) / 64;
-    const uint32_t tile = blockIdx.x % ntiles, slice = blockIdx.x / ntiles;
+    const uint32_t ntiles = (A.S + 63) / 64, ncb = (uint32_t)A.n1p / 64u;
+    const uint32_t tile = blockIdx.x % ntiles, rest = blockIdx.x / ntiles;
+    const uint32_t cb = rest % ncb, slice = rest / ncb;
     const uint32_t s0 = tile * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool valid = s0 + lane < A.S;
     const uint32_t job = d.job_base + (valid ? s0 + lane : A.S - 1);
+    const int i0 = (int)slice * C::SLICE_I + w * IW; // this wave's indices: [i0, i0 + IW)
 
-    // zero rows (digit 0) of both buffers
-    for (int k = tid; k < 2 * JB * C::ROWI; k += C::NT) {
-        int buf = k / (JB * C::ROWI), rem = k % (JB * C::ROWI);
-        s_rows[buf * C::BUFI + (rem / C::ROWI) * C::BASE * C::ROWI + rem % C::ROWI] = 0;
-    }
-
-    constexpr int NSTAGE = KS_IT * (T / JB);
-    const size_t row_ints = (size_t)C::N1P;
-    // stage st covers i = slice*KS_IT + st / (T/JB), j = (st % (T/JB))*JB .. +JB-1: JB*(BASE-1) adjacent rows
-    auto stage_src = [&](int st) {
-        const int i = slice * KS_IT + st / (T / JB), j0 = (st % (T / JB)) * JB;
-        return reinterpret_cast<const i4 *>(A.ksk + ((size_t)i * T + j0) * (C::BASE - 1) * row_ints);
-    };
-    i4 pre[C::LD_PER_THREAD];
+    int *s_tab = s_all + w * C::WAVE_I; // this wave's two tables [2][16][ROWI]
+    // combination 0 (both digits zero) is the zero row of either table; the stage loop rewrites it with zeros
+    const int chunk = lane & 15, g = lane >> 4; // this lane builds columns [4 chunk, 4 chunk + 4) of the rows with first digit g
+    const int gsel = g ? g - 1 : 0, gmask = g ? -1 : 0;
+    const size_t n1p = (size_t)A.n1p;
+    i4 pa, pb[3];
+    // stage st covers i = i0 + st / NPAIR, digits j0 = 2 (st % NPAIR) and j0 + 1: six adjacent key rows, of which this
+    // wave needs the 256-byte strip of its column block.  Everything in the loop is unconditional (one basic block).
     auto stage_load = [&](int st) {
-        const i4 *src = stage_src(st);
+        const int i = i0 + st / C::NPAIR, j0 = 2 * (st % C::NPAIR);
+        const i4 *src = reinterpret_cast<const i4 *>(A.ksk + ((size_t)i * T + j0) * 3 * n1p + cb * 64) + chunk;
+        pa = src[gsel * (n1p / 4)];
 #pragma unroll
-        for (int k = 0; k < C::LD_PER_THREAD; k++) {
-            int e = tid + C::NT * k;
-            if (e < C::STAGE_I4) pre[k] = src[e];
-        }
+        for (int k = 0; k < 3; k++) pb[k] = src[(3 + k) * (n1p / 4)];
     };
     auto stage_store = [&](int buf) {
+        int *t = s_tab + buf * C::TABI + (g * 4) * C::ROWI + chunk * 4;
+        const i4 a = pa & (i4){gmask, gmask, gmask, gmask};
+        *reinterpret_cast<i4 *>(t) = a;
 #pragma unroll
-        for (int k = 0; k < C::LD_PER_THREAD; k++) {
-            int e = tid + C::NT * k;
-            if (e < C::STAGE_I4) {
-                int rowg = e / (C::N1P / 4), c4 = e % (C::N1P / 4); // rowg = jj*(BASE-1) + (dd-1)
-                int jj = rowg / (C::BASE - 1), dd = rowg % (C::BASE - 1) + 1;
-                *reinterpret_cast<i4 *>(&s_rows[buf * C::BUFI + (jj * C::BASE + dd) * C::ROWI + c4 * 4]) = pre[k];
-            }
-        }
+        for (int k = 0; k < 3; k++) *reinterpret_cast<i4 *>(t + (k + 1) * C::ROWI) = a + pb[k];
     };
 
-    i4 acc[C::CW / 4];
+    i4 acc[16];
 #pragma unroll
-    for (int c = 0; c < C::CW / 4; c++) acc[c] = (i4){0, 0, 0, 0};
+    for (int c = 0; c < 16; c++) acc[c] = (i4){0, 0, 0, 0};
 
     stage_load(0);
     stage_store(0);
-    __syncthreads();
-    uint32_t ub = 0;
+    wave_lds_fence();
+    const uint32_t *ubp = A.ubarT + (size_t)i0 * A.jstride + job;
 #pragma unroll 1
-    for (int st = 0; st < NSTAGE; st++) {
-        const int buf = st & 1;
-        if (st + 1 < NSTAGE) stage_load(st + 1);
-        const int jb = st % (T / JB);
-        if (jb == 0) ub = A.ubarT[(size_t)(slice * KS_IT + st / (T / JB)) * A.jstride + job];
-        const int *base = s_rows + buf * C::BUFI + w * C::CW;
+    for (int ii = 0; ii < IW; ii++) {
+        const uint32_t ub = ubp[(size_t)ii * A.jstride];
 #pragma unroll 1
-        for (int jj = 0; jj < JB; jj++) {
-            const int j = jb * JB + jj;
-            const uint32_t dg = (ub >> (32 - (j + 1) * BASEBIT)) & (uint32_t)(C::BASE - 1);
-            const i4 *row = reinterpret_cast<const i4 *>(base + (jj * C::BASE + (int)dg) * C::ROWI);
-            // 8 reads in flight at a time keeps the accumulators (128 VGPRs) and the reads under 256
+        for (int q = 0; q < C::NPAIR; q++) {
+            const int st = ii * C::NPAIR + q;
+            const int buf = st & 1;
+            stage_load(st + 1 < C::NSTAGE ? st + 1 : st);
+            const uint32_t nib = (ub >> (28 - 4 * q)) & 15u; // digits 2q and 2q + 1 of this lane's ciphertext
+            const i4 *row = reinterpret_cast<const i4 *>(s_tab + buf * C::TABI + (int)nib * C::ROWI);
 #pragma unroll
-            for (int c0 = 0; c0 < C::CW / 4; c0 += 8) {
+            for (int c0 = 0; c0 < 16; c0 += 8) {
                 i4 v[8];
 #pragma unroll
                 for (int c = 0; c < 8; c++) v[c] = row[c0 + c];
@@ -1068,31 +1067,45 @@ __global__ __launch_bounds__(64 * NW, (NW > 8 ? 1 : 2)) void k_keyswitch(const G
                 for (int c = 0; c < 8; c++) acc[c0 + c] -= v[c];
                 __builtin_amdgcn_sched_barrier(0);
             }
+            stage_store(buf ^ 1);
+            wave_lds_fence();
         }
-        if (st + 1 < NSTAGE) stage_store(buf ^ 1);
-        __syncthreads();
     }
 
-    // transpose 64 ciphertexts x 32 columns at a time through LDS, then coalesced atomics
-    int *tb = s_rows + w * (64 * 36); // per wave: 64 rows x 36 ints (32 + 4 pad)
+    // the workgroup's NWV partial sums -> one: the upper half of the waves parks its accumulators in LDS, the lower half adds
+    __syncthreads(); // every wave is done with its tables
 #pragma unroll
-    for (int piece = 0; piece < C::CW / 32; piece++) {
+    for (int h = NWV / 2; h >= 1; h /= 2) {
+        if (w >= h && w < 2 * h) {
+            int *r = s_all + (w - h) * C::RED_I + lane * C::ROWI;
 #pragma unroll
-        for (int q = 0; q < 8; q++) *reinterpret_cast<i4 *>(&tb[lane * 36 + q * 4]) = acc[piece * 8 + q];
-        wave_lds_fence();
-        const int colbase = w * C::CW + piece * 32 + (lane & 31);
-#pragma unroll 4
-        for (int rr = 0; rr < 32; rr++) {
-            const int rowi = rr * 2 + (lane >> 5);
-            const int v = tb[rowi * 36 + (lane & 31)];
-            if (v != 0 && s0 + rowi < A.S && colbase <= A.n)
-                atomicAdd(d.out + (size_t)(s0 + rowi) * (A.n + 1) + colbase, v);
+            for (int c = 0; c < 16; c++) *reinterpret_cast<i4 *>(r + 4 * c) = acc[c];
         }
-        wave_lds_fence();
+        __syncthreads();
+        if (w < h) {
+            const int *r = s_all + w * C::RED_I + lane * C::ROWI;
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc[c] += *reinterpret_cast<const i4 *>(r + 4 * c);
+        }
+        __syncthreads();
+    }
+    if (w == 0) {
+        int *r = s_all + lane * C::ROWI;
+#pragma unroll
+        for (int c = 0; c < 16; c++) *reinterpret_cast<i4 *>(r + 4 * c) = acc[c];
+    }
+    __syncthreads();
+    // output: wave w takes 64 / NWV ciphertexts, lane = column (256 contiguous bytes per atomic instruction)
+    const int col = (int)cb * 64 + lane;
+#pragma unroll 4
+    for (int k = 0; k < 64 / NWV; k++) {
+        const int ct = w * (64 / NWV) + k;
+        const int v = s_all[ct * C::ROWI + lane];
+        if (v != 0 && s0 + ct < A.S && col <= A.n) atomicAdd(d.out + (size_t)(s0 + ct) * (A.n + 1) + col, v);
     }
 }
 
-// Key switch for any (basebit <= 4, t) the tiled kernels above are not instantiated for (both default parameter sets use
+// Key switch for any (basebit <= 4, t) the kernel above is not instantiated for (both default parameter sets use
 // basebit 2, t 8 and never come here): one thread per output word, rows read straight from the key image.  A plain,
 // slow, exact form -- lweKeySwitchTranslate_fromArray as written.  The output row holds (0, ..., 0, b')
 // when it starts (k_ks_init or the blind rotate's epilogue wrote it).  grid: x = S, y = gates; block = 256
