@@ -194,7 +194,8 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
                                       "measured in this run)",
                           note="lds_wait_frac = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES: share of wave cycles in which an LDS "
                                "instruction is ready but the CU's LDS pipe is taken; the store path moves ~79 B/clk/CU "
-                               "(ds_write_b128 = 13.6 cycles), 56 such stores per wave-step (DESIGN.md 5.1)")
+                               f"(ds_write_b128 = 13.6 cycles), {cb.get('ds_write_b128_per_wave_step')} such stores per "
+                               "wave-step (DESIGN.md 5.1)")
     if traffic and br_ms > 0:
         gbps = traffic / ((traffic_launch_ms or br_ms) * 1e-3) / 1e9
         blk["hbm_measured"] = {"GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),

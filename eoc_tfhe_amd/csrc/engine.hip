@@ -192,6 +192,9 @@ static int upload_tables(eoc_engine *e)
     HIP_TRY(hipMalloc(&e->d_twist, twist.size() * 8));
     HIP_TRY(hipMemcpy(e->d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_twist, twist.data(), twist.size() * 8, hipMemcpyHostToDevice));
+    // NULL-stream audit: the tables are read by kernels on caller streams, which may be hipStreamNonBlocking
+    // and would not wait for NULL-stream work: drain once, here, at engine creation
+    HIP_TRY(hipDeviceSynchronize());
     return EOC_OK;
 }
 
@@ -294,6 +297,9 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
                       jobs, W.ws_jobs, descs, W.ws_descs, mixed, W.ws_mixed);
         return EOC_ERR_STATE;
     }
+    // Growth synchronises the DEVICE.  `st` is the only stream this call can test for capture; a capture in progress on
+    // another stream of the process would be invalidated by the synchronise: eoc_engine_reserve before capturing ANYWHERE
+    // in the process (include/eoc_tfhe_gpu.h, "Capture rules").
     HIP_TRY(hipDeviceSynchronize()); // nothing in flight may still use the buffers that are about to be replaced
     if (jobs > W.ws_jobs) {
         hipFree(W.d_bara);
@@ -308,6 +314,7 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         HIP_TRY(hipMalloc(&W.d_u, cap * (kN + 1) * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&W.d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
         HIP_TRY(hipMemset(W.d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        // NULL-stream audit: ordered by the hipDeviceSynchronize two lines below.
         // the memset runs on the NULL stream and callers may launch on hipStreamNonBlocking streams, which do not wait for
         // it: without this the fill could land on key-switch operands the first batch has already written (seen as 7
         // mismatches in 5 000 host-path cases of tools/soak_parity.py once the persistent workers removed the thread
@@ -448,6 +455,9 @@ static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_
         return EOC_ERR_HIP;
     }
     // the key image carries the inverse transform's 1/512 (exact power-of-two scaling)
+    // NULL-stream audit: the blocking hipMemcpy above has completed when it returns; the transform below
+    // runs on the NULL stream and is drained by the hipDeviceSynchronize that follows it, before any caller stream
+    // (blocking or hipStreamNonBlocking) can be handed the image.
     int rc = launch_fft_fwd(e, d_bk, d_bkfft, npoly, 0x1p-9, nullptr);
     hipError_t se = hipDeviceSynchronize();
     hipFree(d_bk);
@@ -455,6 +465,8 @@ static int build_cloud_key_images(eoc_engine *e, const int32_t *bk, const int32_
     HIP_TRY(se);
     // KSK: [N*t*(base-1)][n+1]  ->  same rows padded with zeros to n1p
     const size_t rows = (size_t)kN * p.ks_t * (((size_t)1 << p.ks_basebit) - 1);
+    // NULL-stream audit: fill and copy are both on the NULL stream (ordered among themselves), drained by the
+    // hipDeviceSynchronize below -- a non-blocking stream cannot see a half-written key image.
     HIP_TRY(hipMemset(d_ksk, 0, eoc_ksk_dev_bytes(&p)));
     HIP_TRY(hipMemcpy2D(d_ksk, e->n1p * 4, ksk, (size_t)(p.n + 1) * 4, (size_t)(p.n + 1) * 4, rows,
                         hipMemcpyHostToDevice));
@@ -670,7 +682,10 @@ static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, 
         return EOC_ERR_STATE;
     }
     if (W.desc_pos + count > W.ws_descs) {
-        HIP_TRY(hipStreamSynchronize(st));
+        // wrap (rare: the ring is sized for everything a call sends): an engine may have been driven from another stream
+        // before this call, whose descriptor copies out of the slots about to be rewritten could still be in flight --
+        // wait for the whole device, not only for `st`
+        HIP_TRY(hipDeviceSynchronize());
         W.desc_pos = 0;
     }
     memcpy(W.h_descs + W.desc_pos, src, count * sizeof(GateDesc));

@@ -163,8 +163,10 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  * eoc_engine_reserve sizes them once, after which the launch path neither allocates nor synchronises and a fixed
  * netlist / batch shape can be captured into a hipGraph.  eoc_engine_workspace_grows counts growths since the
  * last reserve (0 in steady state).
- * Capture rules: while hip_stream is being captured a call that would have to grow the workspace fails with
- * EOC_ERR_STATE (nothing may be allocated under capture); gate descriptors -- and the opcode permutation of a mixed
+ * Capture rules: call eoc_engine_reserve BEFORE any stream of the process starts capturing -- growth synchronises the
+ * whole device, which invalidates a global-mode capture in progress on ANY stream, and only the stream passed to the
+ * call can be tested for it.  While hip_stream itself is being captured a call that would have to grow the workspace
+ * fails with EOC_ERR_STATE (nothing may be allocated under capture); gate descriptors -- and the opcode permutation of a mixed
  * batch with more than 15 opcode runs -- are placed in an arena that is never re-used (4 x max_descs slots of 40 bytes;
  * a permutation takes count / 10 slots), because the captured copy nodes read their pinned sources again at every
  * replay; when the arena is exhausted the call fails with EOC_ERR_STATE.
