@@ -1,3 +1,4 @@
+#define _DEFAULT_SOURCE /* mkstemp */
 /* abi_smoke.c -- a plain-C host of libeoc_tfhe_gpu.so: proves include/eoc_tfhe_gpu.h is valid C and the
  * library is usable without Python or torch (this is what a Lua/Node binding sits on).
  *   gcc -std=c11 -Iinclude tests/c/abi_smoke.c -o abi_smoke -Leoc_tfhe_amd -leoc_tfhe_gpu -Wl,-rpath,...
@@ -7,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "FAILED: %s (line %d): %s\n", #c, __LINE__, eoc_last_error()); return 1; } } while (0)
 
@@ -43,7 +45,40 @@ int main(int argc, char **argv)
         const eoc_gate bad[2] = {{EOC_AND, 0, 1, -1, 2}, {EOC_OR, 0, 1, -1, 2}};
         CHECK(eoc_netlist_optimize(bad, 2, outs, 0, opt) == EOC_ERR_ARG);
     }
+    /* f2, server side: the cloud key alone as the process-global context (no secret in it) */
+    size_t ck_len = eoc_cloud_key_blob_bytes(&p);
+    void *ck = malloc(ck_len);
+    CHECK(eoc_cloud_key_export(sk, ck, ck_len) == EOC_OK);
+    {
+        CHECK(eoc_global_key_mode() == 0 && eoc_global_cloud_key_export(NULL, 0) == 0);
+        CHECK(eoc_global_import_cloud_key_blob(blob, need) == EOC_ERR_ARG);      /* a SECRET blob is refused */
+        CHECK(eoc_global_import_cloud_key_blob(ck, ck_len - 1) == EOC_ERR_ARG);  /* truncated */
+        CHECK(eoc_global_import_cloud_key_blob(ck, ck_len) == EOC_OK);
+        CHECK(eoc_global_key_mode() == 2);
+        CHECK(eoc_global_import_cloud_key_blob(ck, ck_len) == EOC_ERR_ARG);      /* one key per process */
+        eoc_params q;
+        CHECK(eoc_global_params(&q) == EOC_OK && q.n == p.n && q.l == p.l);
+        CHECK(encryptBit(1, "") == NULL && exportSecretKey() == NULL && decryptBit("AAAA", "") == -1);
+        CHECK(eoc_global_encrypt_bits(b0, 4, c0) == EOC_ERR_NO_KEY);
+        void *back = malloc(ck_len);
+        CHECK(eoc_global_cloud_key_export(back, ck_len) == ck_len && memcmp(back, ck, ck_len) == 0);
+        free(back);
+        const char *one = constantBit(1);                                         /* needs the parameters only */
+        CHECK(one != NULL);
+        free((void *)one);
+        char path[] = "/tmp/eoc_abi_smoke_XXXXXX";
+        int fd = mkstemp(path);
+        CHECK(fd >= 0);
+        close(fd);
+        CHECK(exportCloudKeyToFile(path) == 0);
+        resetGateKey();
+        CHECK(eoc_global_key_mode() == 0 && importCloudKeyFromFile("/nonexistent/cloud.key") == -1);
+        CHECK(importCloudKeyFromFile(path) == 0 && eoc_global_key_mode() == 2);
+        remove(path);
+        if (!gpu) resetGateKey();
+    }
     if (!gpu) {
+        free(ck);
         if (eoc_device_count() == 0) {
             CHECK(eoc_gate_batch(EOC_NAND, NULL, c0, c1, NULL, out, 4) == EOC_ERR_NO_DEVICE);
             eoc_engine *e = NULL;
@@ -54,6 +89,12 @@ int main(int argc, char **argv)
         eoc_secret_key_free(sk);
         return 0;
     }
+    /* the cloud-key-only context evaluates gates: the engine comes up behind the imported key on first use */
+    CHECK(eoc_global_gate_batch(EOC_NAND, NULL, c0, c1, NULL, out, 4) == EOC_OK);
+    CHECK(eoc_decrypt_bits(sk, out, 4, dec) == EOC_OK);                           /* decrypted by the key's owner */
+    for (int i = 0; i < 4; i++) CHECK(dec[i] == (uint8_t)(1 - (b0[i] & b1[i])));
+    resetGateKey();
+    free(ck);
     CHECK(eoc_gpu_init(0, &p) == EOC_OK);
     CHECK(eoc_upload_cloud_key(sk) == EOC_OK);
     CHECK(eoc_gate_batch(EOC_NAND, NULL, c0, c1, NULL, out, 4) == EOC_OK);

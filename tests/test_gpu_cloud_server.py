@@ -159,3 +159,48 @@ def test_client_server_split_bit_exact(built_lib, tmp_path):
     assert back["gates"] == expect.tolist()
     assert back["sums"] == (A + B).tolist()
     assert back["strs"] == {"nand": 0, "xor": 1, "mux": 0, "not_": 1, "one": 1}
+
+
+def test_cloud_only_server_on_several_engines(built_lib, tmp_path):
+    """the same secret-free context in front of THREE engines (EOC_TFHE_DEVICES=0,0,0: the one-GPU rehearsal of a
+    multi-GPU server): the imported cloud key is built once on engine 0 and replicated, the batch is cut into blocks,
+    every engine evaluates its block with its own replica -- bytes equal the oracle's"""
+    import eoc_tfhe_amd as eoc
+    p = eoc.default_params(1)                      # Set B shape, small LWE dimension: l = 3, Bgbit = 7
+    p.n = 48
+    sk = eoc.SecretKey(p, 21)
+    orc = ol.Oracle(1, 21, n_override=48)
+    rng = np.random.default_rng(3)
+    total = 41
+    ops = rng.choice(np.array([ol.OPS["NAND"], ol.OPS["XOR"], ol.OPS["MUX"], ol.OPS["ORNY"]], np.uint8), total)
+    bits = rng.integers(0, 2, (3, total)).astype(np.uint8)
+    c = [sk.encrypt_bits(bits[k], 70 + k, 0) for k in range(3)]
+    sk.export_cloud_key().tofile(str(tmp_path / "cloud.key"))
+    for k in range(3):
+        np.save(tmp_path / ("in%d.npy" % k), c[k])
+    np.save(tmp_path / "ops.npy", ops)
+    env = dict(os.environ, EOC_TFHE_DEVICES="0,0,0")
+    code = textwrap.dedent("""
+        import sys, json
+        import numpy as np
+        sys.path.insert(0, %r)
+        import eoc_tfhe_amd as eoc
+        from eoc_tfhe_amd import Tfhe
+        assert Tfhe.importCloudKeyFromFile('cloud.key') == 0 and Tfhe.keyMode() == 2
+        out = eoc.global_gate_batch(0, np.load('in0.npy'), np.load('in1.npy'), np.load('in2.npy'), ops=np.load('ops.npy'))
+        np.save('out.npy', out)
+        st = eoc.stats_multi()
+        print('RESULT' + json.dumps(dict(engines=len(st['engines']), per=[e['bootstraps'] for e in st['engines']],
+                                         method=st['key_broadcast_method'], enc=Tfhe.encryptBit(1))))
+        Tfhe.resetGateKey()
+    """ % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][len("RESULT"):])
+    assert res["engines"] == 3 and all(x > 0 for x in res["per"]) and res["method"] == "peer-copy" and res["enc"] is None
+    got = np.load(tmp_path / "out.npy")
+    assert np.array_equal(got, orc.gate_batch(0, c[0], c[1], c[2], ops=ops))
+    b0, b1, b2 = bits.astype(np.int64)
+    want = np.where(ops == ol.OPS["NAND"], 1 - (b0 & b1), np.where(ops == ol.OPS["XOR"], b0 ^ b1,
+                    np.where(ops == ol.OPS["MUX"], np.where(b0 == 1, b1, b2), (1 - b0) | b1)))
+    assert np.array_equal(sk.decrypt_bits(got), want)
