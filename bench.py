@@ -609,7 +609,7 @@ def main():
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "in_library_multi.py"), "--steps", "10",
                                 "--devices", inlib_devices],
-                               capture_output=True, text=True, timeout=180)
+                               capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             in_library = json.loads(line[-1]) if line else {"error": f"rc={r.returncode}", "stderr_tail": r.stderr[-600:]}
         except Exception as e:  # noqa: BLE001 -- time-out, missing interpreter, bad JSON: reported, never fatal

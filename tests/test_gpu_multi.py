@@ -407,6 +407,45 @@ def test_async_submit_wait_pipeline(eoc, devices):
         eoc.gpu_shutdown()
 
 
+def test_freeing_a_pinned_buffer_drains_pending_submissions(eoc):
+    """eoc_host_free (a Node Buffer finalizer, a PinnedArray going out of scope) must not release memory under
+    a DMA in flight -- it first completes what is pending; a key re-upload drains too.  Two submissions in flight, the
+    operand buffer of the second is freed at once; both results must still be the oracle's, and the engine stays usable"""
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    orc = ol.Oracle(0, 9, n_override=40)
+    eoc.gpu_shutdown()
+    eoc.gpu_init(p, devices=[0, 0])
+    eoc.upload_cloud_key(sk)
+    try:
+        rng = np.random.default_rng(6)
+        w = 1500
+        pins = [[eoc.PinnedArray((w, p.n + 1)) for _ in range(3)] for _ in range(2)]
+        wants = []
+        for b in range(2):
+            for j in range(2):
+                pins[b][j].array[:] = sk.encrypt_bits(rng.integers(0, 2, w).astype(np.uint8), 300 + 10 * b + j, 0)
+            wants.append(orc.gate_batch(eoc.OPS["XOR"], pins[b][0].array, pins[b][1].array))
+        t0 = eoc.gate_batch_submit(eoc.OPS["XOR"], pins[0][0].array, pins[0][1].array, out=pins[0][2].array)
+        t1 = eoc.gate_batch_submit(eoc.OPS["XOR"], pins[1][0].array, pins[1][1].array, out=pins[1][2].array)
+        pins[1][0].free()                                  # operand of the batch that was queued a moment ago
+        assert np.array_equal(pins[0][2].array, wants[0]) and np.array_equal(pins[1][2].array, wants[1])
+        eoc.gate_batch_wait(t0)
+        eoc.gate_batch_wait(t1)
+        t2 = eoc.gate_batch_submit(eoc.OPS["XOR"], pins[0][0].array, pins[0][1].array, out=pins[0][2].array)
+        eoc.upload_cloud_key(sk)                           # re-upload under a pending submission: drains first
+        assert np.array_equal(pins[0][2].array, wants[0])
+        eoc.gate_batch_wait(t2)
+        c = sk.encrypt_bits(np.ones(5, np.uint8), 5, 0)
+        assert np.array_equal(eoc.gate_batch(eoc.OPS["NAND"], c, c), orc.gate_batch(ol.OPS["NAND"], c, c))
+        for pb in pins:
+            for a in pb:
+                a.free()
+    finally:
+        eoc.gpu_shutdown()
+
+
 def test_error_from_a_worker_block_reaches_the_caller(eoc, ctx3):
     """an error raised while engine 2's persistent thread evaluates its block comes back with ITS message
     (eoc_last_error is per thread: the worker hands the text over), and the context stays usable"""
