@@ -10,6 +10,7 @@ import pytest
 import oracle_lib as ol
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+NH = 512
 N = 1024
 
 
@@ -81,6 +82,61 @@ def test_transform_golden_and_properties(golden):
     want = np.concatenate([[-x[-1]], x[:-1]]).astype(np.int32)
     d = ol.fft_inv(sp).astype(np.int64) - want
     assert set(np.unique(d * np.sign(want))) <= {0, -1}  # truncation toward zero
+
+
+def test_forward_transform_is_the_evaluation_map_by_direct_summation():
+    """An anchor that shares nothing with the implementation (no twiddle table, no butterfly graph): SURVEY.md A.7
+    defines the forward map as P_m = p(zeta^(4m+1)), zeta = e^(i pi / N).  Every one of the 512 bins of the oracle's
+    spectrum -- bin e holds the root index m = bitrev9(e) and is stored at sigma(e) = (e & 7) * 64 + (e >> 3) -- is
+    compared with the polynomial evaluated by plain summation in extended precision, for a full-range torus polynomial
+    and a digit-range one; and the inverse map returns the coefficients (truncated toward zero)."""
+    rng = np.random.default_rng(12)
+    j = np.arange(N, dtype=np.longdouble)
+    pi = np.longdouble("3.14159265358979323846264338327950288")
+    for lo, hi in ((-2**31, 2**31), (-512, 512)):
+        poly = rng.integers(lo, hi, N).astype(np.int32)
+        spec = ol.fft_fwd(poly).view(np.complex128)
+        pl = poly.astype(np.longdouble)
+        scale = float(np.abs(pl).sum())
+        worst = 0.0
+        for e in range(NH):
+            m = int(format(e, "09b")[::-1], 2)
+            ang = pi * (4 * m + 1) / np.longdouble(N)
+            want = complex(float((pl * np.cos(ang * j)).sum()), float((pl * np.sin(ang * j)).sum()))
+            worst = max(worst, abs(complex(spec[(e & 7) * 64 + (e >> 3)]) - want) / scale)
+        assert worst < 1e-13, worst                      # binary64 round-off of a 1024-term sum, nothing structural
+        back = ol.fft_inv(spec.view(np.float64)).astype(np.int64) - poly
+        assert set(np.unique(back * np.sign(poly))) <= {0, -1}
+
+
+def test_keyswitch_and_extract_by_a_numpy_restatement():
+    """A second, independently written statement of SURVEY.md A.5 / A.6 (numpy, vectorised over the 8192 (i, j) pairs; it
+    shares no code with oracle/tfhe_oracle.c): lweKeySwitch is  res = (0, b') - sum over (i, j) with digit d != 0 of
+    KSK[i][j][d],  digit d = ((a'_i + 2^(31 - t basebit)) >> (32 - (j + 1) basebit)) & (base - 1);  and the key-switched
+    sample decrypts, under the LWE key, to the phase the extracted sample has under the extracted TLWE key."""
+    o = ol.Oracle(0, 5, n_override=24)
+    p = o.p
+    t, bb = p.ks_t, p.ks_basebit
+    base = 1 << bb
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        u = rng.integers(-2**31, 2**31, N + 1).astype(np.int32)
+        abar = (u[:N].astype(np.int64) + (1 << (31 - t * bb))) & 0xFFFFFFFF
+        jj = np.arange(t)
+        dig = (abar[:, None] >> (32 - (jj[None, :] + 1) * bb)) & (base - 1)               # [N][t]
+        ksk = o.ksk.reshape(N, t, base - 1, p.n + 1).astype(np.int64)                     # rows d = 1 .. base-1
+        res = np.zeros(p.n + 1, np.int64)
+        res[p.n] = int(u[N])
+        ii, jx = np.nonzero(dig)
+        res -= ksk[ii, jx, dig[ii, jx] - 1].sum(axis=0)
+        want = (res & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        got = o.keyswitch(u)
+        assert np.array_equal(got, want)
+        # phases: <a', s'> under the extracted key (s'_j = tlwe_key[j]) against the key-switched sample under the LWE key
+        ph_in = (int(u[N]) - int((u[:N].astype(np.int64) * o.tlwe_key).sum())) & 0xFFFFFFFF
+        ph_out = (int(got[p.n]) - int((got[:p.n].astype(np.int64) * o.lwe_key).sum())) & 0xFFFFFFFF
+        d = (ph_out - ph_in + 2**31) % 2**32 - 2**31
+        assert abs(d) < 2**27, d      # rounding of the t-digit decomposition (2^15 per index) + key-switch noise, far below 1/8
 
 
 def _schoolbook(a, b):
@@ -183,6 +239,47 @@ def test_fft_step_close_to_exact_step(orc_a):
     a3 = acc.copy()
     o.L.orc_blind_rotate_step(C.byref(o.p), bkfft_i.ctypes.data, None, 0, a3, 1)
     assert np.array_equal(a3, acc)
+
+
+def test_exact_cmux_step_by_a_numpy_restatement(orc_a):
+    """SURVEY.md A.3 / A.4 written a second time, in numpy, sharing no code with the oracle's C: negacyclic rotation by
+    X^a (a in [0, 2N)), the signed gadget decomposition with its offset, the row order (all p for q = 0, then q = 1) and
+    the external product as exact integer convolutions mod 2^32 -- equal BIT FOR BIT to the oracle's exact-integer step,
+    which in turn bounds the FP64 step (test above) that the GPU reproduces bit for bit."""
+    import ctypes as C
+    o = orc_a
+    l, Bgbit = o.l, o.p.Bgbit
+    Bg, half = 1 << Bgbit, 1 << (Bgbit - 1)
+    offset = sum(half << (32 - pp * Bgbit) for pp in range(1, l + 1))
+    rng = np.random.default_rng(14)
+
+    def mul_xai(poly, a):                      # X^a * poly in Z[X]/(X^N + 1), int64 in, int64 out
+        a %= 2 * N
+        sign = 1
+        if a >= N:
+            a, sign = a - N, -1
+        return sign * np.concatenate([-poly[N - a:], poly[:N - a]])
+
+    def negacyclic(d, b):                      # exact: |d| <= 2^9, |b| <= 2^31, 1024 terms: < 2^51, fits int64
+        full = np.convolve(d, b)
+        return full[:N] - np.concatenate([full[N:], [0]])
+
+    for i, abar in ((5, 777), (0, 1), (17, 1024), (499, 2047), (250, 1500)):
+        acc = rng.integers(-2**31, 2**31, 2 * N).astype(np.int32)
+        got = acc.copy()
+        o.L.orc_blind_rotate_step(C.byref(o.p), None, np.ascontiguousarray(o.bk[i]).ctypes.data, abar, got, 0)
+        A = acc.astype(np.int64).reshape(2, N)
+        out = A.copy()
+        for q in range(2):
+            x = (mul_xai(A[q], abar) - A[q]) & 0xFFFFFFFF            # (X^a - 1) * ACC_q as uint32
+            u = (x + offset) & 0xFFFFFFFF
+            for pp in range(1, l + 1):
+                digit = ((u >> (32 - pp * Bgbit)) & (Bg - 1)) - half    # in [-Bg/2, Bg/2)
+                row = o.bk[i][q * l + (pp - 1)].astype(np.int64)         # TLWE row (q, p): two polynomials
+                for c in range(2):
+                    out[c] += negacyclic(digit, row[c])
+        want = (out & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(-1)
+        assert np.array_equal(got, want), (i, abar)
 
 
 def test_bootstrap_noise_and_truth_many(orc_a):
