@@ -241,6 +241,37 @@ def test_fft_step_close_to_exact_step(orc_a):
     assert np.array_equal(a3, acc)
 
 
+def test_gate_linear_stage_and_modswitch_by_a_numpy_restatement():
+    """SURVEY.md 8a a1 / A.1 restated in numpy: the ten two-input gates' linear stage  t = (0, c) + s0 ca + s1 cb  with the
+    constants of the published boots* family (1/8 = 2^29), and modSwitchFromTorus32(., 2N) as round(phi 2N / 2^32).
+    Bit for bit against the oracle; and the sign of the phase of t IS the gate (what the bootstrap then refreshes)."""
+    import ctypes as C
+    o = ol.Oracle(0, 3, n_override=64, with_bk=False)
+    table = {  # name: (constant in eighths of the torus, s0, s1)
+        "NAND": (1, -1, -1), "AND": (-1, 1, 1), "OR": (1, 1, 1), "NOR": (-1, -1, -1), "XOR": (2, 2, 2), "XNOR": (-2, -2, -2),
+        "ANDNY": (-1, -1, 1), "ANDYN": (-1, 1, -1), "ORNY": (1, -1, 1), "ORYN": (1, 1, -1)}
+    sem = {"NAND": lambda a, b: 1 - (a & b), "AND": lambda a, b: a & b, "OR": lambda a, b: a | b, "NOR": lambda a, b: 1 - (a | b),
+           "XOR": lambda a, b: a ^ b, "XNOR": lambda a, b: 1 - (a ^ b), "ANDNY": lambda a, b: (1 - a) & b,
+           "ANDYN": lambda a, b: a & (1 - b), "ORNY": lambda a, b: (1 - a) | b, "ORYN": lambda a, b: a | (1 - b)}
+    for a in (0, 1):
+        for b in (0, 1):
+            ca, cb = o.encrypt_bits([a], 40 + a, 0)[0], o.encrypt_bits([b], 50 + b, 0)[0]
+            for name, (c8, s0, s1) in table.items():
+                want = (s0 * ca.astype(np.int64) + s1 * cb.astype(np.int64))
+                want[o.n] += c8 * (1 << 29)
+                want = (want & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+                got = o.gate_linear(ol.OPS[name], ca, cb)
+                assert np.array_equal(got, want), name
+                phase = (int(got[o.n]) - int((got[:o.n].astype(np.int64) * o.lwe_key).sum()) + 2**31) % 2**32 - 2**31
+                assert (phase > 0) == bool(sem[name](a, b)), (name, a, b)
+                # mod-switch of the whole sample to [0, 2N): round(phi * 2N / 2^32)
+                bara = np.zeros(o.n, np.int32)
+                barb = np.zeros(1, np.int32)
+                o.L.orc_modswitch_sample(C.byref(o.p), got, bara, barb)
+                ms = ((got.astype(np.int64) & 0xFFFFFFFF) + (1 << 20) >> 21) & 2047
+                assert np.array_equal(bara, ms[:o.n]) and barb[0] == ms[o.n], name
+
+
 def test_exact_cmux_step_by_a_numpy_restatement(orc_a):
     """SURVEY.md A.3 / A.4 written a second time, in numpy, sharing no code with the oracle's C: negacyclic rotation by
     X^a (a in [0, 2N)), the signed gadget decomposition with its offset, the row order (all p for q = 0, then q = 1) and
