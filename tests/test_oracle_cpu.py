@@ -272,6 +272,39 @@ def test_gate_linear_stage_and_modswitch_by_a_numpy_restatement():
                 assert np.array_equal(bara, ms[:o.n]) and barb[0] == ms[o.n], name
 
 
+def test_blind_rotate_frame_by_a_numpy_restatement(orc_a):
+    """SURVEY.md A.4 / A.5 around the CMux steps, restated in numpy: ACC_0 = (0, X^(2N - barb) * (mu, ..., mu)), the loop
+    over i with rotation amount bara[i] (a zero amount is the identity), and tLweExtractLweSample at index 0:
+    a'[0] = ACC_0[0], a'[j] = -ACC_0[N - j], b' = ACC_1[0].  The steps themselves are the oracle's FP64 steps; the frame
+    around them must reproduce orc_blind_rotate_extract bit for bit."""
+    import ctypes as C
+    o = orc_a
+    mu = 1 << 29
+    t = o.gate_linear(ol.OPS["NAND"], o.encrypt_bits([1], 61, 0)[0], o.encrypt_bits([0], 62, 0)[0])
+    want = o.blind_rotate_extract(t, mu)
+    ms = ((t.astype(np.int64) & 0xFFFFFFFF) + (1 << 20) >> 21) & 2047            # modSwitchFromTorus32(., 2N)
+    bara, barb = ms[:o.n], int(ms[o.n])
+    tv = np.full(N, mu, np.int64)
+    a = (2 * N - barb) % (2 * N)
+    sign = 1
+    if a >= N:
+        a, sign = a - N, -1
+    body = sign * np.concatenate([-tv[N - a:], tv[:N - a]]) if a else sign * tv
+    acc = np.concatenate([np.zeros(N, np.int64), body]).astype(np.int32)
+    for i in range(o.n):
+        if bara[i] == 0:
+            continue
+        o.L.orc_blind_rotate_step(C.byref(o.p), np.ascontiguousarray(o.bkfft[i]).ctypes.data, None, int(bara[i]), acc, 1)
+    u = np.empty(N + 1, np.int32)
+    u[0] = acc[0]
+    u[1:N] = (-acc[N - 1:0:-1].astype(np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    u[N] = acc[N]
+    assert np.array_equal(u, want)
+    # and the refreshed sample carries NAND(1, 0) = 1: phase under the extracted key close to +1/8
+    ph = (int(u[N]) - int((u[:N].astype(np.int64) * o.tlwe_key).sum()) + 2**31) % 2**32 - 2**31
+    assert abs(ph - mu) < 2**26, ph
+
+
 def test_exact_cmux_step_by_a_numpy_restatement(orc_a):
     """SURVEY.md A.3 / A.4 written a second time, in numpy, sharing no code with the oracle's C: negacyclic rotation by
     X^a (a in [0, 2N)), the signed gadget decomposition with its offset, the row order (all p for q = 0, then q = 1) and
