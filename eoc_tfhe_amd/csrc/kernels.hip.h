@@ -966,8 +966,12 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 // NWV * IW indices i); its NWV waves split the SLICE: wave w walks IW indices of its own.
 //   * Two digits per look-up.  For digits j, j + 1 of index i the wave first combines the 3 + 3 candidate key rows into
 //     the table of their 16 sums, S[d1][d2] = row_j[d1] + row_{j+1}[d2] (64 columns, 4.3 KB, double-buffered in LDS;
-//     d1 = d2 = 0 is the zero row), built by its own lanes: lane = (d1, 4-column chunk), 4 coalesced 16-byte key loads and
-//     4 ds_write_b128 per lane and stage.  Every lane then selects with the 4-bit nibble of its operand word that holds
+//     d1 = d2 = 0 is the zero row), built by its own lanes with lane = COLUMN: six coalesced dword loads (exactly the
+//     wave's 256-byte strips of the six rows), nine additions, and the fifteen non-zero rows leave through
+//     ds_write_addtid_b32 -- the LDS store whose address is M0 + offset + 4 * lane, no address register: a 256-byte row
+//     in 2 cycles of the CU's store path against 13.6 for a ds_write_b128 (tools/ubench_addtid.hip pins its addressing:
+//     lane within the wave, no 16-bit wrap of the sum, one wait state after the SALU write of M0).
+//     Every lane then selects with the 4-bit nibble of its operand word that holds
 //     both digits of ITS ciphertext and does ONE look-up and ONE subtraction per column for the pair:
 //     acc -= S[nibble]  ==  acc -= row_j[d1]; acc -= row_{j+1}[d2]  in wrapping int32 arithmetic -- bit-identical, at half
 //     the subtractions and half the LDS reads per ciphertext of the one-digit form (rows are skewed by 16 B so that the 16
@@ -979,8 +983,8 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 // History (Set A, 1024 gates): round 3's kernel -- one digit per look-up, the candidate rows of 4 digits staged per
 // workgroup barrier, one i-slice x all columns per workgroup, 32 atomics per output word -- took 0.212 ms: integer issue
 // and the LDS pipe were loaded exactly alike (4 bytes from LDS per subtraction) and 16.8 M atomics arrived together at the
-// end of the kernel (33 us, timing-only ablation).  Pair tables alone: 0.180 ms; with one i-range per wave: 0.133 ms
-// (Set B: 0.363 -> 0.304 -> 0.196 ms).  An XCD-aware workgroup order (all tiles of a slice on one XCD) changed nothing:
+// end of the kernel (33 us, timing-only ablation).  Pair tables alone: 0.180 ms; with one i-range per wave: 0.133 ms; tables
+// built through ds_write_addtid_b32 instead of ds_write_b128: 0.122 ms (Set B: 0.363 -> 0.304 -> 0.196 -> 0.178 ms).  An XCD-aware workgroup order (all tiles of a slice on one XCD) changed nothing:
 // the 50 MB key image is served by the Infinity Cache either way.
 template <int T, int NWV, int IW>
 struct KS3Cfg {
@@ -1003,6 +1007,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
 {
     typedef KS3Cfg<T, NWV, IW> C;
     static_assert(T % 2 == 0 && kN % C::SLICE_I == 0 && (NWV & (NWV - 1)) == 0, "shape");
+    static_assert((NWV * C::WAVE_I - C::TABI) * 4 < 65536, "ds_write_addtid_b32 takes its base from M0[15:0]");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *s_all = reinterpret_cast<int *>(smem);
 
@@ -1018,27 +1023,54 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
     const int i0 = (int)slice * C::SLICE_I + w * IW; // this wave's indices: [i0, i0 + IW)
 
     int *s_tab = s_all + w * C::WAVE_I; // this wave's two tables [2][16][ROWI]
-    // combination 0 (both digits zero) is the zero row of either table; the stage loop rewrites it with zeros
-    const int chunk = lane & 15, g = lane >> 4; // this lane builds columns [4 chunk, 4 chunk + 4) of the rows with first digit g
-    const int gsel = g ? g - 1 : 0, gmask = g ? -1 : 0;
     const size_t n1p = (size_t)A.n1p;
-    i4 pa, pb[3];
-    // stage st covers i = i0 + st / NPAIR, digits j0 = 2 (st % NPAIR) and j0 + 1: six adjacent key rows, of which this
-    // wave needs the 256-byte strip of its column block.  Everything in the loop is unconditional (one basic block).
+    // Table building, lane = column.  Stage st covers i = i0 + st / NPAIR, digits j0 = 2 (st % NPAIR) and j0 + 1: six
+    // adjacent key rows, of which this wave needs the 256-byte strip of its column block.  Everything in the stage loop is
+    // unconditional (the last stage re-loads itself): one basic block, so that look-ups and subtractions stay in the order
+    // written.  M0 is saved and restored around the add-TID stores (the compiler does not expect it to change).
+    int kr[6];
+    for (int k = lane; k < 2 * C::ROWI; k += 64) s_tab[(k / C::ROWI) * C::TABI + k % C::ROWI] = 0; // the two zero rows
+    const uint32_t tab_lds = (uint32_t)(uintptr_t)s_tab;
     auto stage_load = [&](int st) {
         const int i = i0 + st / C::NPAIR, j0 = 2 * (st % C::NPAIR);
-        const i4 *src = reinterpret_cast<const i4 *>(A.ksk + ((size_t)i * T + j0) * 3 * n1p + cb * 64) + chunk;
-        pa = src[gsel * (n1p / 4)];
+        const int *src = A.ksk + ((size_t)i * T + j0) * 3 * n1p + cb * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 3; k++) pb[k] = src[(3 + k) * (n1p / 4)];
+        for (int k = 0; k < 6; k++) kr[k] = src[k * n1p];
     };
+#define EOC_KS_ROW(BUF, D1, D2) ((BUF) * C::TABI * 4 + ((D1) * 4 + (D2)) * C::ROWI * 4)
     auto stage_store = [&](int buf) {
-        int *t = s_tab + buf * C::TABI + (g * 4) * C::ROWI + chunk * 4;
-        const i4 a = pa & (i4){gmask, gmask, gmask, gmask};
-        *reinterpret_cast<i4 *>(t) = a;
-#pragma unroll
-        for (int k = 0; k < 3; k++) *reinterpret_cast<i4 *>(t + (k + 1) * C::ROWI) = a + pb[k];
+        const int a1 = kr[0], a2 = kr[1], a3 = kr[2], b1 = kr[3], b2 = kr[4], b3 = kr[5];
+        const uint32_t base = tab_lds + (uint32_t)buf * (C::TABI * 4);
+        uint32_t m0_saved;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %1\n\t"
+                     "s_nop 1\n\t" /* an SALU write of M0 needs a wait state before an add-TID LDS instruction reads it */
+                     "ds_write_addtid_b32 %2 offset:%17\n\t"
+                     "ds_write_addtid_b32 %3 offset:%18\n\t"
+                     "ds_write_addtid_b32 %4 offset:%19\n\t"
+                     "ds_write_addtid_b32 %5 offset:%20\n\t"
+                     "ds_write_addtid_b32 %6 offset:%21\n\t"
+                     "ds_write_addtid_b32 %7 offset:%22\n\t"
+                     "ds_write_addtid_b32 %8 offset:%23\n\t"
+                     "ds_write_addtid_b32 %9 offset:%24\n\t"
+                     "ds_write_addtid_b32 %10 offset:%25\n\t"
+                     "ds_write_addtid_b32 %11 offset:%26\n\t"
+                     "ds_write_addtid_b32 %12 offset:%27\n\t"
+                     "ds_write_addtid_b32 %13 offset:%28\n\t"
+                     "ds_write_addtid_b32 %14 offset:%29\n\t"
+                     "ds_write_addtid_b32 %15 offset:%30\n\t"
+                     "ds_write_addtid_b32 %16 offset:%31\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(m0_saved)
+                     : "s"(base), "v"(b1), "v"(b2), "v"(b3), "v"(a1), "v"(a1 + b1), "v"(a1 + b2), "v"(a1 + b3), "v"(a2),
+                       "v"(a2 + b1), "v"(a2 + b2), "v"(a2 + b3), "v"(a3), "v"(a3 + b1), "v"(a3 + b2), "v"(a3 + b3),
+                       "n"(EOC_KS_ROW(0, 0, 1)), "n"(EOC_KS_ROW(0, 0, 2)), "n"(EOC_KS_ROW(0, 0, 3)), "n"(EOC_KS_ROW(0, 1, 0)),
+                       "n"(EOC_KS_ROW(0, 1, 1)), "n"(EOC_KS_ROW(0, 1, 2)), "n"(EOC_KS_ROW(0, 1, 3)), "n"(EOC_KS_ROW(0, 2, 0)),
+                       "n"(EOC_KS_ROW(0, 2, 1)), "n"(EOC_KS_ROW(0, 2, 2)), "n"(EOC_KS_ROW(0, 2, 3)), "n"(EOC_KS_ROW(0, 3, 0)),
+                       "n"(EOC_KS_ROW(0, 3, 1)), "n"(EOC_KS_ROW(0, 3, 2)), "n"(EOC_KS_ROW(0, 3, 3))
+                     : "memory");
     };
+#undef EOC_KS_ROW
 
     i4 acc[16];
 #pragma unroll
