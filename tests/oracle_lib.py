@@ -24,7 +24,8 @@ class OrcParams(C.Structure):
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tfhe_oracle.c", "tfhe_oracle.h", "canon_twiddles.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tfhe_oracle.c", "tfhe_oracle.h")]
+    srcs.append(os.path.join(ROOT, "eoc_tfhe_amd", "csrc", "canon_twiddles.h"))   # the Makefile copies it into oracle/
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so

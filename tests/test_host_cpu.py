@@ -26,11 +26,17 @@ def test_library_exports_every_declared_symbol(eoc):
     assert [s for s in syms if not hasattr(lib, s)] == []
 
 
-def test_twiddle_tables_identical_and_pinned():
+def test_twiddle_table_is_pinned_and_the_oracle_builds_from_a_copy_of_it():
+    """one committed copy of the generated table (eoc_tfhe_amd/csrc/canon_twiddles.h); oracle/Makefile copies it next to
+    the oracle's source, so the two sides of every parity test read the same constants; the values are checked against
+    cos / sin and pinned by their SHA-256"""
     import hashlib
-    a = open(os.path.join(ROOT, "oracle", "canon_twiddles.h")).read()
-    b = open(os.path.join(ROOT, "eoc_tfhe_amd", "csrc", "canon_twiddles.h")).read()
-    assert a == b
+    import subprocess
+    a = open(os.path.join(ROOT, "eoc_tfhe_amd", "csrc", "canon_twiddles.h")).read()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "canon_twiddles.h"])
+    assert open(os.path.join(ROOT, "oracle", "canon_twiddles.h")).read() == a
+    tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "oracle/canon_twiddles.h"], capture_output=True, text=True)
+    assert tracked.returncode != 0 or tracked.stdout.strip() == ""      # generated, never committed
     vals = re.findall(r"\{(\S+), (\S+)\}", a)
     assert len(vals) == 1024
     tab = np.array([[float.fromhex(c), float.fromhex(s)] for c, s in vals])

@@ -387,6 +387,7 @@ def test_oracle_under_asan_ubsan(tmp_path):
     import subprocess
     root = os.path.dirname(HERE)
     exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "canon_twiddles.h"])  # the generated table copy
     subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-I" + os.path.join(root, "oracle"),
                            os.path.join(root, "tests", "c", "oracle_sanitize.c"), os.path.join(root, "oracle", "tfhe_oracle.c"),
