@@ -1,0 +1,136 @@
+"""Predicted output noise of one gate bootstrap, for a GIVEN key (pure numpy; no GPU, no oracle).
+
+This is the quantitative anchor of the parity statement: upstream libtfhe is absent from the
+reference tree, so what ties this path to TFHE as published is (a) bit-exact agreement with the CPU restatement and
+(b) agreement of the measured output noise -- mean AND variance, before and after the key switch -- with what the
+CGGI analysis predicts for the conventions of SURVEY.md Appendix A.  A wrong gadget offset, a rounding instead of
+upstream's truncating decomposition, a wrong key-switch precision offset or a mis-scaled key row moves one of the four
+numbers below by tens of per cent while every gate still decrypts.
+
+All quantities are in torus units (int32 / 2^32).  N = 1024, k = 1.
+
+Blind rotation (tfhe_blindRotateAndExtract_FFT), error of the extracted sample under the
+extracted key, over many input ciphertexts and ONE key:
+
+  V_BR = n * 2l * N * E[d^2] * sigma_bk^2                (the TLWE-zero rows of BK_i, every step; E[d^2] = (Bg^2 + 2)/12:
+                                                          digits uniform on [-Bg/2, Bg/2), mean -1/2)
+       + w * (1 + |s'|) * q^2 / 12                        (w = Hamming weight of the LWE key, |s'| of the TLWE key:
+                                                          the decomposition's remainder, q = Bg^-l)
+       + w * (q/2)^2 * G(s')                              (the remainder is a TRUNCATION: upstream's offset
+                                                          sum_p (Bg/2) 2^(32 - p Bgbit) centres the digits, not the
+                                                          remainder, which is uniform on [0, q) with mean q/2)
+
+The third term is what CGGI's worst-case bound hides and the average-case textbook formula omits.  At a step with
+s_i = 1 the update adds  -(low_b - low_a * s')  to the accumulator, low_x[j] in [0, q).  Its mean is the polynomial
+-(q/2) J*(1 - s'), J = 1 + X + ... + X^(N-1); later steps multiply it by X^rho with rho uniform on [0, 2N) (the
+remaining rotation), so coefficient 0 of the result picks +-((q/2) (J*(1 - s'))[r]) for a uniform r:
+G(s') = mean_r ((J*(1-s'))[r])^2, about N^2/12 -- N/2 times the variance term next to it.  For the LAST step with
+s_i = 1 nothing rotates any more (rho = 0): a deterministic bias
+
+  M_BR = -(q/2) * (1 + |s'| - 2 s'_0).
+
+Key switch (lweKeySwitch; A.6), added error for ONE key whose rows have noises e[i][j][d]
+(d = 1..base-1; d = 0 is "no row", e = 0), digits uniform:
+
+  V_KS = sum_{i,j} ( mean_d e^2 - (mean_d e)^2 )  +  |s'| * 2^(-2 (t basebit + 1)) / 3
+  M_KS = - sum_{i,j} mean_d e[i][j][d]            (res = (0, b') - sum of rows: the phase loses msg + e per row)
+
+The textbook average over keys, kN t (1 - 1/base) sigma_ks^2, is ~ 4/3 of V_KS for a fixed key: a quarter of the
+rows' second moment is the per-key constant M_KS, not spread.
+"""
+import numpy as np
+
+N = 1024
+
+
+def _wrap32(x):
+    return ((np.asarray(x, np.int64) + 2**31) % 2**32) - 2**31
+
+
+def ksk_noise(ksk, lwe_key, tlwe_key, ks_t, ks_basebit):
+    """e[i*t + j][d-1]: noise of key-switch row (i, j, d) in torus units (phase minus message)."""
+    base = 1 << ks_basebit
+    ksk = np.asarray(ksk, np.int64).reshape(N * ks_t * (base - 1), -1)
+    s = np.asarray(lwe_key, np.int64)
+    s1 = np.asarray(tlwe_key, np.int64)
+    ph = _wrap32(ksk[:, -1] - ksk[:, :-1] @ s)
+    r = np.arange(ksk.shape[0])
+    d = r % (base - 1) + 1
+    j = (r // (base - 1)) % ks_t
+    i = r // ((base - 1) * ks_t)
+    msg = _wrap32(s1[i] * (d << (32 - (j + 1) * ks_basebit)))
+    return (_wrap32(ph - msg) / 2.0**32).reshape(N * ks_t, base - 1)
+
+
+def predict(params, lwe_key, tlwe_key, ksk=None):
+    """dict of predicted means / variances (torus units) for this key; `ksk` = [N t (base-1)][n+1] torus rows
+    (None: the key-switch part uses the average-key textbook formula and a zero mean)."""
+    n, l, Bgbit = int(params.n), int(params.l), int(params.Bgbit)
+    t, bb = int(params.ks_t), int(params.ks_basebit)
+    Bg, base = 1 << Bgbit, 1 << bb
+    s = np.asarray(lwe_key, np.int64)
+    s1 = np.asarray(tlwe_key, np.int64)
+    w, hw = int(s.sum()), int(s1.sum())
+    q = 2.0 ** (-l * Bgbit)
+    # J * (1 - s') in Z[X]/(X^N + 1): coefficient r = sum_{m <= r} v_m - sum_{m > r} v_m
+    v = -s1.astype(np.float64)
+    v[0] += 1.0
+    pre = np.cumsum(v)
+    Jv = 2.0 * pre - pre[-1]
+    out = {}
+    out["br_var_rows"] = n * (1.0 - 1.0 / (2 * N)) * 2 * l * N * ((Bg * Bg + 2) / 12.0) * float(params.bk_stdev) ** 2
+    out["br_var_remainder"] = w * (1 + hw) * q * q / 12.0
+    out["br_var_truncation_bias"] = w * (q / 2) ** 2 * float((Jv**2).mean())
+    out["br_var"] = out["br_var_rows"] + out["br_var_remainder"] + out["br_var_truncation_bias"]
+    out["br_mean"] = -(q / 2) * float(Jv[0])
+    out["br_var_textbook"] = (n * 2 * l * N * (Bg * Bg / 12.0) * float(params.bk_stdev) ** 2
+                              + n * (1 + N / 2) * q * q / 12.0)        # the average-case formula WITHOUT the truncation term
+    ks_round = hw * 2.0 ** (-2 * (t * bb + 1)) / 3.0
+    out["ks_var_textbook"] = N * t * (1 - 1.0 / base) * float(params.ks_stdev) ** 2 + ks_round
+    if ksk is not None:
+        e = ksk_noise(ksk, s, s1, t, bb)
+        m1 = e.sum(1) / base
+        m2 = (e**2).sum(1) / base
+        out["ks_var"] = float((m2 - m1**2).sum()) + ks_round
+        # res = (0, b') - sum of rows: phase(res) = b' - sum (msg + e) = phase(u) + rounding - sum e
+        out["ks_mean"] = -float(m1.sum())
+    else:
+        out["ks_var"] = out["ks_var_textbook"]
+        out["ks_mean"] = 0.0
+    out["total_var"] = out["br_var"] + out["ks_var"]
+    out["total_mean"] = out["br_mean"] + out["ks_mean"]
+    return out
+
+
+def measure(u, out, lwe_key, tlwe_key):
+    """errors of blind-rotation outputs `u` [count][N+1] under the extracted key and of the key-switched
+    samples `out` [count][n+1] under the LWE key, against the nearest of +-1/8.  Returns (e_br, e_ks, e_total) in
+    torus units; e_ks = e_total - e_br is the key switch's own contribution, sample by sample."""
+    s = np.asarray(lwe_key, np.int64)
+    s1 = np.asarray(tlwe_key, np.int64)
+    u = np.asarray(u, np.int64).reshape(-1, N + 1)
+    out = np.asarray(out, np.int64).reshape(u.shape[0], -1)
+    phu = _wrap32(u[:, N] - u[:, :N] @ s1)
+    pho = _wrap32(out[:, -1] - out[:, :-1] @ s)
+    sign = np.where(phu > 0, 1, -1)
+    e_br = (phu - sign * 2**29) / 2.0**32
+    e_tot = (pho - sign * 2**29) / 2.0**32
+    return e_br, e_tot - e_br, e_tot
+
+
+def compare(pred, e_br, e_ks, e_tot):
+    """measured / predicted summary (what the tests assert on and bench.py prints)"""
+    cnt = len(e_br)
+    return {
+        "count": int(cnt),
+        "br_var": float(e_br.var()), "br_var_pred": pred["br_var"], "br_ratio": float(e_br.var() / pred["br_var"]),
+        "br_ratio_textbook": float(e_br.var() / pred["br_var_textbook"]),
+        "br_mean": float(e_br.mean()), "br_mean_pred": pred["br_mean"],
+        "br_mean_z": float((e_br.mean() - pred["br_mean"]) / (e_br.std() / np.sqrt(cnt))),
+        "ks_var": float(e_ks.var()), "ks_var_pred": pred["ks_var"], "ks_ratio": float(e_ks.var() / pred["ks_var"]),
+        "ks_ratio_textbook": float(e_ks.var() / pred["ks_var_textbook"]),
+        "ks_mean": float(e_ks.mean()), "ks_mean_pred": pred["ks_mean"],
+        "ks_mean_z": float((e_ks.mean() - pred["ks_mean"]) / (e_ks.std() / np.sqrt(cnt))),
+        "total_std": float(e_tot.std()), "total_std_pred": float(np.sqrt(pred["total_var"])),
+        "max_abs_err": float(np.abs(e_tot).max()),
+    }

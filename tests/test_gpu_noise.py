@@ -1,0 +1,69 @@
+"""Noise anchor on the HIP path (VERDICT r4 task 1): 16 384 fresh encryptions per set through
+eoc_blind_rotate_device and eoc_keyswitch_device; the measured mean and variance of the phase error, before and after
+the key switch, against the per-key CGGI prediction of eoc_tfhe_amd/noise.py (derivation: DESIGN.md 2.3).
+CPU twin on the oracle: tests/test_noise_cpu.py.  This replaces the old `err.std() < max_stdev` checks, which a wrong
+gadget offset or precision offset would have passed."""
+import numpy as np
+import pytest
+
+from eoc_tfhe_amd import noise
+from gpu_util import dev_empty, sync, to_dev, torch_cuda
+
+pytestmark = pytest.mark.gpu
+N = 1024
+COUNT = 16384         # variance estimate +-1.1 % (1 sigma)
+
+
+@pytest.fixture(scope="module")
+def eoc(built_lib):
+    torch_cuda()
+    import eoc_tfhe_amd
+    return eoc_tfhe_amd
+
+
+def run_noise(eoc, pset, count=COUNT, seed=1):
+    """-> noise.compare() dict for `count` NAND inputs on fresh encryptions (also used by bench.py's secondary leg)"""
+    torch = torch_cuda()
+    p = eoc.default_params(pset)
+    sk = eoc.SecretKey(p, seed)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    rng = np.random.default_rng(100 + pset)
+    b0, b1 = rng.integers(0, 2, count), rng.integers(0, 2, count)
+    c0, c1 = sk.encrypt_bits(b0, 4001 + pset), sk.encrypt_bits(b1, 4101 + pset)
+    # bootsNAND's linear stage: t = (0, 1/8) - c0 - c1, wrapping
+    t = (-(c0.astype(np.int64) + c1.astype(np.int64)))
+    t[:, -1] += 1 << 29
+    t = (t & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    d_t = to_dev(t)
+    d_u = dev_empty((count, N + 1), torch.int32)
+    d_o = dev_empty((count, p.n + 1), torch.int32)
+    eng.blind_rotate_device(d_t.data_ptr(), d_u.data_ptr(), count)
+    eng.keyswitch_device(d_u.data_ptr(), d_o.data_ptr(), count)
+    sync()
+    u, out = d_u.cpu().numpy(), d_o.cpu().numpy()
+    assert np.array_equal(sk.decrypt_bits(out), 1 - (b0 & b1))
+    # the two-call path is the gate: same bytes as eoc_gate_batch_device
+    d_g = dev_empty((count, p.n + 1), torch.int32)
+    d_c0, d_c1 = to_dev(c0), to_dev(c1)
+    eng.gate_batch_device(eoc.OPS["NAND"], d_c0.data_ptr(), d_c1.data_ptr(), None, d_g.data_ptr(), count)
+    sync()
+    assert np.array_equal(d_g.cpu().numpy(), out)
+    pred = noise.predict(p, sk.lwe_key, sk.tlwe_key, sk.ksk)
+    return noise.compare(pred, *noise.measure(u, out, sk.lwe_key, sk.tlwe_key))
+
+
+@pytest.mark.parametrize("pset", [0, 1], ids=["setA", "setB"])
+def test_gpu_noise_matches_prediction(eoc, pset):
+    r = run_noise(eoc, pset)
+    print({k: (f"{v:.4e}" if isinstance(v, float) else v) for k, v in r.items()})
+    assert 0.8 < r["br_ratio"] < 1.25, r
+    assert 0.8 < r["ks_ratio"] < 1.25, r
+    assert abs(r["br_mean_z"]) < 5 and abs(r["ks_mean_z"]) < 5, r
+    # both predicted means are resolvably non-zero at this sample size: a sign slip fails, not just a scale slip
+    assert abs(r["br_mean"]) > 4 * np.sqrt(r["br_var"] / r["count"]), r
+    assert abs(r["ks_mean"]) > 4 * np.sqrt(r["ks_var"] / r["count"]), r
+    assert r["max_abs_err"] < 1 / 16
+    # the nearest neighbours are excluded: rounding decomposition (textbook formula) 1.53x (A) / 1.33x (B),
+    # average-over-keys key switch 0.75x
+    assert r["br_ratio_textbook"] > 1.2 and r["ks_ratio_textbook"] < 0.82, r

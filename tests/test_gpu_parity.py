@@ -327,7 +327,10 @@ def test_properties_at_bench_size(eoc, rig_a):
 
 def test_truth_tables_16k_random_encryptions_per_gate(eoc, rig_a):
     """every gate decrypts to its truth table over >= 10^4 random encryptions with zero
-    failures; output noise of bootstrap + key switch stays within the set's max_stdev (0.012467)."""
+    failures; the output noise of bootstrap + key switch has the variance eoc_tfhe_amd/noise.py predicts for this key
+    (the full before / after key switch anchor, means included: tests/test_gpu_noise.py)."""
+    from eoc_tfhe_amd import noise
+    pred = noise.predict(rig_a.p, rig_a.sk.lwe_key, rig_a.sk.tlwe_key, rig_a.sk.ksk)
     r = rig_a
     cnt = 16384
     b0, c0 = _rand_cts(r, cnt, 81)
@@ -342,8 +345,9 @@ def test_truth_tables_16k_random_encryptions_per_gate(eoc, rig_a):
         if name in ("NAND", "XOR"):
             g = got.astype(np.int64)
             phase = ((g[:, -1] - g[:, :-1] @ lwe) + 2**31) % 2**32 - 2**31
-            err = (np.abs(phase) - 2**29) / 2**32
-            assert np.abs(err).max() < 1 / 16 and err.std() < 0.012467, (name, err.std())
+            err = (phase - np.sign(phase) * 2**29) / 2**32
+            assert np.abs(err).max() < 1 / 16 and 0.8 < err.var() / pred["total_var"] < 1.25, (name, err.var(), pred)
+            assert abs(err.mean() - pred["total_mean"]) < 5 * err.std() / np.sqrt(cnt), (name, err.mean(), pred)
     got = r.gate(eoc.OPS["MUX"], c0, c1, c2)
     assert np.array_equal(r.sk.decrypt_bits(got), np.where(b0 == 1, b1, b2))
 

@@ -347,8 +347,10 @@ def test_exact_cmux_step_by_a_numpy_restatement(orc_a):
 
 
 def test_bootstrap_noise_and_truth_many(orc_a):
-    """64 random NANDs: every output decrypts correctly and sits within 1/16 of +-1/8
-    (output noise stdev ~ 4e-3 of the torus)."""
+    """64 random NANDs: every output decrypts correctly and sits within 1/16 of +-1/8; the noise has the stdev
+    eoc_tfhe_amd/noise.py predicts for this key (4.1e-3 of the torus; 64 samples resolve it to +-9 % -- the tight
+    measured-vs-predicted anchor, before and after the key switch, is tests/test_noise_cpu.py)."""
+    from eoc_tfhe_amd import noise
     o = orc_a
     rng = np.random.default_rng(77)
     b0, b1 = rng.integers(0, 2, 64), rng.integers(0, 2, 64)
@@ -356,8 +358,9 @@ def test_bootstrap_noise_and_truth_many(orc_a):
     out = o.gate_batch(ol.OPS["NAND"], c0, c1)
     assert np.array_equal(o.decrypt_bits(out), 1 - (b0 & b1))
     ph = o.phases(out) / 2**32
-    err = np.abs(np.abs(ph) - 0.125)
-    assert err.max() < 1 / 16 and err.std() < 0.012467
+    err = ph - np.sign(ph) * 0.125
+    pred = noise.predict(o.p, o.lwe_key, o.tlwe_key, o.ksk)
+    assert np.abs(err).max() < 1 / 16 and 0.65 < err.std() / np.sqrt(pred["total_var"]) < 1.45, (err.std(), pred)
     # a second level of gates on bootstrapped outputs still decrypts (noise does not accumulate)
     out2 = o.gate_batch(ol.OPS["XOR"], out, np.roll(out, 1, axis=0))
     w = 1 - (b0 & b1)
