@@ -152,6 +152,7 @@ def lib():
         "eoc_engine_reserve": (C.c_int, [vp, sz, sz, sz]),
         "eoc_engine_workspace_grows": (u64, [vp]),
         "eoc_engine_blind_rotate_launches": (u64, [vp]),
+        "eoc_engine_blind_rotate_wide_launches": (u64, [vp]),
         "eoc_engine_device": (C.c_int, [vp]),
         "eoc_engine_params": (PP, [vp]),
         "eoc_engine_adopt_cloud_key_device": (C.c_int, [vp, vp, vp]),
@@ -480,7 +481,9 @@ class Engine:
     def stats(self):
         out = (C.c_uint64 * 3)()
         _check(self.L.eoc_engine_stats(self.h, C.byref(out)), "eoc_engine_stats")
-        return dict(batches=out[0], bootstraps=out[1], keyswitches=out[2])
+        return dict(batches=out[0], bootstraps=out[1], keyswitches=out[2],
+                    br_launches=int(self.L.eoc_engine_blind_rotate_launches(self.h)),
+                    br_wide_launches=int(self.L.eoc_engine_blind_rotate_wide_launches(self.h)))
 
 
 def circuit_bootstraps(gates):

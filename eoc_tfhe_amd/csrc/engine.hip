@@ -70,10 +70,12 @@ struct eoc_engine {
     int br_slice = 0;                       // jobs per blind-rotate launch: 0 = resident set, < 0 = unlimited (EOC_TFHE_BR_SLICE)
     bool no_fold = false;                   // EOC_TFHE_NO_FOLD: keep k_ks_init as its own launch
     int br_parts = 0;                       // consecutive launches per blind rotation (EOC_TFHE_BR_PARTS); 0 = by key-row size
+    int br_wide = -1;                       // one-wave-per-ciphertext kernel: -1 = by launch width, 0 = never, 1 = whenever l = 2 (EOC_TFHE_BR_WIDE)
     int bara_stride = 0;
     uint64_t stats[3] = {0, 0, 0};
     uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
     uint64_t br_launches = 0; // k_blind_rotate kernel launches (a wide level is several, a cut blind rotation too)
+    uint64_t br_wide_launches = 0; // ... of which k_blind_rotate_wide
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
     bool profiling = false;
     struct Span { hipEvent_t a, b; int kind; };
@@ -231,6 +233,7 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (const char *s = getenv("EOC_TFHE_BR_SLICE")) e->br_slice = atoi(s);
         if (getenv("EOC_TFHE_NO_FOLD")) e->no_fold = true;
         if (const char *s = getenv("EOC_TFHE_BR_PARTS")) e->br_parts = atoi(s);
+        if (const char *s = getenv("EOC_TFHE_BR_WIDE")) e->br_wide = atoi(s);
     }
     // the key-switch kernel uses > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
 #define EOC_KS_ATTR(TT, NWV, IWV)                                                                   \
@@ -550,22 +553,41 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
                                const GateDesc *fold_descs = nullptr, uint32_t fold_S = 0)
 {
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
-    const uint32_t resident = 4u * (uint32_t)e->num_cus;
-    uint32_t slice = e->br_slice > 0 ? (uint32_t)e->br_slice : (e->br_slice == 0 ? resident : njobs_total);
-    {   // even slices: 1536 jobs run as 768 + 768, not 1024 + 512
-        const uint32_t nsl = (njobs_total + slice - 1) / slice;
-        slice = (njobs_total + nsl - 1) / nsl;
-    }
-    // The n steps of a blind rotation may run as several consecutive launches (the accumulators travel through
-    // d_acc_state): every launch boundary brings all workgroups of an XCD back to the same step.  With 96 KB of key
-    // rows per step and ciphertext (gadget length 3) the 128 resident ciphertexts of an XCD drift far enough apart for
-    // their rows to overflow the 4 MB L2 share (rows re-fetched 3.6x, profiles/traffic.json): two parts -2.5 % on
-    // Set B; with 64 KB per step (Set A) the rows fit and every extra part costs 0.8 %.
+    // Two kernel shapes (kernels.hip.h).  The pair kernel (one ciphertext = one wave pair) fills the chip with 4 x CUs
+    // ciphertexts; the wide kernel (one ciphertext = one wave, gadget length 2 only) with 8 x CUs, and saves the partial-chain
+    // exchange and its barriers.  A level wider than the pair kernel's resident set runs as full wide launches plus a
+    // remainder: on the pair kernel when it fits its resident set (a half-empty wide launch has one wave per SIMD and runs
+    // at 0.7 of the pair kernel's rate), on the wide kernel otherwise (tools/wide_sweep.py).
+    const uint32_t resident_pair = 4u * (uint32_t)e->num_cus, resident_wide = 8u * (uint32_t)e->num_cus;
+    const bool can_wide = e->p.l == 2 && e->br_wide != 0;
+    const bool force_wide = can_wide && e->br_wide > 0;
+    struct Seg { uint32_t off, njobs; bool wide; };
+    std::vector<Seg> segs;
     const int auto_parts = e->kpl * 2 * kNH * 16 > 80 * 1024 ? 2 : 1;
     const int parts = std::max(1, std::min(e->br_parts > 0 ? e->br_parts : auto_parts, e->p.n));
-    if (parts > 1 && slice > 16u * (uint32_t)e->num_cus) slice = 16u * (uint32_t)e->num_cus; // acc_state capacity
-    for (uint32_t off = 0; off < njobs_total; off += slice) {
-        const uint32_t njobs = std::min(slice, njobs_total - off);
+    {
+        auto even = [&](uint32_t off, uint32_t total, uint32_t slice, bool wide) { // even slices: 1536 jobs as 768 + 768
+            if (parts > 1 && slice > 16u * (uint32_t)e->num_cus) slice = 16u * (uint32_t)e->num_cus; // acc_state capacity
+            const uint32_t nsl = (total + slice - 1) / slice;
+            slice = (total + nsl - 1) / nsl;
+            for (uint32_t o = 0; o < total; o += slice) segs.push_back({off + o, std::min(slice, total - o), wide});
+        };
+        if (e->br_slice != 0) // diagnostics: fixed slice (> 0) or one launch (< 0), one kernel shape
+            even(0, njobs_total, e->br_slice > 0 ? (uint32_t)e->br_slice : njobs_total, force_wide);
+        else if (force_wide)
+            even(0, njobs_total, resident_wide, true);
+        else if (!can_wide || njobs_total <= resident_pair)
+            even(0, njobs_total, resident_pair, false);
+        else {
+            const uint32_t full = njobs_total / resident_wide * resident_wide, rem = njobs_total - full;
+            if (full) even(0, full, resident_wide, true);
+            if (rem) even(full, rem, rem <= resident_pair ? resident_pair : resident_wide, rem > resident_pair);
+        }
+    }
+    for (const Seg &sg : segs) {
+        const uint32_t off = sg.off, njobs = sg.njobs;
+        const bool wide = sg.wide;
+        const uint32_t resident = wide ? resident_wide : resident_pair;
         for (int part = 0; part < parts; part++) {
             BRArgs a;
             a.bkfft = e->bkfft;
@@ -590,7 +612,15 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
             a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
                           : (njobs <= resident ? kPrioDuty : e->prio_multi);
             dim3 grid(njobs), block(128);
-            if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
+            if (wide) {
+                grid = dim3((njobs + kBRWideJobsPerWG - 1) / kBRWideJobsPerWG);
+                block = dim3(64 * kBRWideJobsPerWG);
+                if (e->p.Bgbit == 10) // Set A
+                    hipLaunchKernelGGL((k_blind_rotate_wide<10>), grid, block, kBRWideLds, st, a, e->d_tw, e->d_twist);
+                else
+                    hipLaunchKernelGGL((k_blind_rotate_wide<0>), grid, block, kBRWideLds, st, a, e->d_tw, e->d_twist);
+                e->br_wide_launches++;
+            } else if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
                 hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
             else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
                 hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
@@ -1078,5 +1108,6 @@ extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])
 }
 extern "C" uint64_t eoc_engine_workspace_grows(eoc_engine *e) { return e ? e->ws_grows : 0; }
 extern "C" uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e) { return e ? e->br_launches : 0; }
+extern "C" uint64_t eoc_engine_blind_rotate_wide_launches(eoc_engine *e) { return e ? e->br_wide_launches : 0; }
 extern "C" int eoc_engine_device(eoc_engine *e) { return e ? e->device : -1; }
 extern "C" const eoc_params *eoc_engine_params(eoc_engine *e) { return e ? &e->p : nullptr; }

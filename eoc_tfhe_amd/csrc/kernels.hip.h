@@ -916,6 +916,297 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
 }
 
 // =================================================================================================
+// K2w: blind rotate + sample extract, WIDE form (gadget length 2): ONE WAVE = ONE CIPHERTEXT.  For launches of at
+// least twice the pair kernel's resident set, two waves per SIMD can come from two ciphertexts instead of one wave
+// pair: the wave owns both accumulator polynomials, runs the four forward transforms of a step as two skewed pairs and
+// the two inverse transforms as a third, and needs no partner -- no exchange of partial chains through LDS (16 of 112
+// ds_write_b128 and 16 of 144 ds_read_b128 per ciphertext-step), no s_barrier in the step loop, no wait for a partner on
+// another SIMD (timing-only ablation on the pair kernel, tools/patches/abl_noexchange.patch: -14 %).
+// Results are bit-identical to k_blind_rotate: the same transforms, and the accumulation of output polynomial c runs
+// in the canonical order (oracle/tfhe_oracle.c) -- terms (q_in = 1 - c, p = 1, 2) first, then (q_in = c, p = 1, 2) --
+// which needs all four spectra live when the chains start (128 registers): the key rows are therefore streamed bin
+// block by bin block (r = 0..7: eight 16-byte loads, one per row, then the eight chain steps of that block), so that
+// a chain value replaces two spectrum values as the loop advances.  Gadget length 3 would need six live spectra and
+// stays on the pair kernel.
+// Workgroup = two independent ciphertexts (128 threads, the pair kernel's 35.6 KB of LDS: tables + one scratch per wave).
+// =================================================================================================
+// two inverse transforms skewed on one scratch (a's transposes under b's register passes and vice versa); the un-twist
+// factors are read once for both.  Arithmetic per transform identical to fft_inv_wave.
+__device__ __forceinline__ void fft_inv_x2(d2 (&xa)[8], d2 (&xb)[8], d2 (&ut)[8], const d2 *tw, const d2 *s_twist, d2 *scr,
+                                           int lane)
+{
+    d2 t1[4], t0[4];
+    const int hi = lane >> 3, lo = lane & 7;
+    EOC_SB();
+    tw_load(t1, tw + kTwI1 + (lane & 7), 8);
+    inv_pass2(xa);
+    EOC_SB();
+    // region B: register-constant pass of b, a's first transpose spread through it
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = xa[r];
+    wave_lds_fence();
+    inv_pass2(xb);
+    t21_read(xa, scr, lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 5);
+    }
+    EOC_SGB(EOC_M_VALU, 16);
+    EOC_SGB(EOC_M_DSR, 8);
+    EOC_SB();
+    // region C: middle pass of a, b's first transpose spread through it; then b's reads and the last twiddle set
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[f12(lane * 8 + r)] = xb[r];
+    wave_lds_fence();
+    t21_read(xb, scr, lane);
+    tw_load(t0, tw + kTwI0 + lane, 64);
+    wave_lds_fence();
+    inv_pass10(xa, t1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 4);
+    }
+    EOC_SGB(EOC_M_DSR, 12);
+    EOC_SGB(EOC_M_VALU, 40);
+    EOC_SB();
+    // region D: middle pass of b under a's second transpose
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = xa[r];
+    wave_lds_fence();
+    t10_read(xa, scr, lane);
+    inv_pass10(xb, t1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 4);
+    }
+    EOC_SGB(EOC_M_DSR, 8);
+    EOC_SGB(EOC_M_VALU, 40);
+    EOC_SB();
+    // region E: last pass of a under b's second transpose; the un-twist factors
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[72 * hi + 8 * r + lo] = xb[r];
+    wave_lds_fence();
+    t10_read(xb, scr, lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) ut[r] = s_twist[lane + 64 * r];
+    wave_lds_fence();
+    inv_pass10(xa, t0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        EOC_SGB(EOC_M_DSW, 1);
+        EOC_SGB(EOC_M_VALU, 4);
+    }
+    EOC_SGB(EOC_M_DSR, 16);
+    EOC_SGB(EOC_M_VALU, 40);
+    EOC_SB();
+    inv_pass10(xb, t0);
+}
+
+constexpr int kBRWideJobsPerWG = 2;
+constexpr int kBRWideLds = (kTwEntries + kNH + kBRWideJobsPerWG * kScr) * 16;
+
+template <int BGBIT = 0>
+__global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(BRArgs A, const d2 *__restrict__ g_tw,
+                                                              const d2 *__restrict__ g_twist)
+{
+    constexpr int L = 2, KPL = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    d2 *s_tw = reinterpret_cast<d2 *>(smem);
+    d2 *s_twist = s_tw + kTwEntries;
+    d2 *s_scr_all = s_twist + kNH;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    d2 *scr = s_scr_all + h * kScr;
+    int32_t *ext = reinterpret_cast<int32_t *>(scr);
+
+    const uint32_t job = blockIdx.x * kBRWideJobsPerWG + (uint32_t)h; // grid = ceil(jobs / waves per workgroup)
+    load_tables(s_tw, s_twist, g_tw, g_twist, tid, 64 * kBRWideJobsPerWG);
+    __syncthreads();
+    if (job >= A.njobs) return; // the idle wave of an odd last workgroup (the only barrier is behind it)
+
+    typedef const __attribute__((address_space(4))) uint32_t *cu32p;
+    const cu32p bara32 = (cu32p)(uintptr_t)(A.bara + (size_t)job * A.bara_stride);
+    auto load_abar = [&](int idx) __attribute__((always_inline)) {
+        return (int)((bara32[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu);
+    };
+
+    // ACC = (0, X^(2N - barb) * testvect): coefficient lane + 64 r of polynomial q in racc_q[r] (r < 8), + 512 in racc_q[8 + r]
+    uint32_t racc0[16], racc1[16];
+    {
+        const int barb = load_abar(A.n);
+        const int rot = (2 * kN - barb) & (2 * kN - 1);
+        const int32_t *st = A.acc_state + (size_t)job * 2 * kN;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = lane + 64 * (r & 7) + (r >> 3) * kNH;
+            const int idx = (j - rot) & (2 * kN - 1);
+            int32_t v0 = 0, v1 = (idx & kN) ? -A.mu : A.mu;
+            if (A.step_begin > 0) { // continue a blind rotation started by an earlier launch
+                v0 = st[j];
+                v1 = st[kN + j];
+            }
+            racc0[r] = (uint32_t)v0;
+            racc1[r] = (uint32_t)v1;
+        }
+    }
+
+    const int Bgbit = BGBIT > 0 ? BGBIT : A.Bgbit;
+    const uint32_t Bg = 1u << Bgbit, maskBg = Bg - 1, halfBg = Bg >> 1;
+    uint32_t offset = 0;
+#pragma unroll
+    for (int p = 1; p <= L; p++) offset += halfBg << (32 - p * Bgbit);
+    const __amdgpu_buffer_rsrc_t bk_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.bkfft), 0, (int)((size_t)A.n * KPL * 2 * kNH * 16), 0x00020000);
+    const double bias1 = 4503599627370496.0 + (double)halfBg, bias2 = 4503599627370496.0 + (double)Bg;
+    const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
+
+    int abar_next = load_abar(A.step_begin);
+    for (int i = A.step_begin; i < A.step_end; i++) {
+        if (A.prio_duty >= 0) { // see k_blind_rotate: the two waves of a SIMD alternate the issue priority
+            const bool first_part = (i & 15) < A.prio_duty;
+            if (first_part == ((prio_slot & 1) != 0))
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
+        const int abar = __builtin_amdgcn_readfirstlane(abar_next);
+        abar_next = load_abar(i + 1);
+        // (X^abar - 1) * ACC_q, q = 0, 1, as biased digit words (see k_blind_rotate)
+        uint32_t d0[16], d1[16];
+        {
+            const int s = abar & 63;
+            const int src = ((lane - s) & 63) << 2;
+            uint32_t t0[16], t1[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) t0[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)racc0[r]);
+#pragma unroll
+            for (int r = 0; r < 16; r++) t1[r] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)racc1[r]);
+            const bool borrow = lane < s;
+#define EOC_RQ(q) case q: rot_digits<q>(t0, racc0, borrow, offset, d0); rot_digits<q>(t1, racc1, borrow, offset, d1); break;
+            switch (abar >> 6) {
+                EOC_RQ(0) EOC_RQ(1) EOC_RQ(2) EOC_RQ(3) EOC_RQ(4) EOC_RQ(5) EOC_RQ(6) EOC_RQ(7)
+                EOC_RQ(8) EOC_RQ(9) EOC_RQ(10) EOC_RQ(11) EOC_RQ(12) EOC_RQ(13) EOC_RQ(14) EOC_RQ(15)
+                EOC_RQ(16) EOC_RQ(17) EOC_RQ(18) EOC_RQ(19) EOC_RQ(20) EOC_RQ(21) EOC_RQ(22) EOC_RQ(23)
+                EOC_RQ(24) EOC_RQ(25) EOC_RQ(26) EOC_RQ(27) EOC_RQ(28) EOC_RQ(29) EOC_RQ(30)
+                default: rot_digits<31>(t0, racc0, borrow, offset, d0); rot_digits<31>(t1, racc1, borrow, offset, d1); break;
+            }
+#undef EOC_RQ
+        }
+        // digit p of the 16 coefficients of this lane (digit words d[0..7] = low half, d[8..15] = high half), first pass
+        auto make_x0 = [&](const uint32_t (&d)[16], int p, d2 (&x)[8]) __attribute__((always_inline)) {
+            const int shift = 32 - p * Bgbit;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t ua = (d[r] >> shift) & maskBg, ub = (d[8 + r] >> shift) & maskBg;
+                const uint32_t up = (d[r + 4] >> shift) & maskBg, uq = (d[12 + r] >> shift) & maskBg;
+                const double a = __hiloint2double(0x43300000, (int)ua) - bias1;
+                const double b = __hiloint2double(0x43300000, (int)ub) - bias1;
+                const double dm = __hiloint2double(0x43300000, (int)(up - uq + Bg)) - bias2;
+                const double dp = __hiloint2double(0x43300000, (int)(up + uq)) - bias2;
+                fwd_stage0(x[r], x[r + 4], a, b, dm, dp);
+            }
+            fwd_pass0_tail(x);
+        };
+        d2 xs0[2][8], xs1[2][8];
+        make_x0(d0, 1, xs0[0]);
+        fft_fwd_rest_x2(xs0[0], xs0[1], [&]() __attribute__((always_inline)) { make_x0(d0, 2, xs0[1]); }, s_tw, scr, lane);
+        make_x0(d1, 1, xs1[0]);
+        fft_fwd_rest_x2(xs1[0], xs1[1], [&]() __attribute__((always_inline)) { make_x0(d1, 2, xs1[1]); }, s_tw, scr, lane);
+
+        // the two chains, bin block by bin block; row (q, p, c) of BK_i sits at ((i KPL + q L + p - 1) 2 + c) * 8 KiB
+        d2 S0[8], S1[8];
+        const uint32_t step_off = (uint32_t)((size_t)i * KPL * 2 * kNH * 16);
+        auto ld = [&](int q, int p, int c, int r) __attribute__((always_inline)) {
+            const uint32_t off = step_off + (uint32_t)((((q * L) + (p - 1)) * 2 + c) * kNH * 16 + r * 1024);
+            return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(bk_rsrc, lane * 16, (int)off, 0));
+        };
+        auto mul0 = [](d2 x, d2 b) __attribute__((always_inline)) {
+            d2 o;
+            o.x = EOC_FMA(-x.y, b.y, x.x * b.x);
+            o.y = EOC_FMA(x.y, b.x, x.x * b.y);
+            return o;
+        };
+        auto mac1 = [](d2 x, d2 b, d2 a) __attribute__((always_inline)) {
+            d2 o;
+            o.x = EOC_FMA(-x.y, b.y, EOC_FMA(x.x, b.x, a.x));
+            o.y = EOC_FMA(x.y, b.x, EOC_FMA(x.x, b.y, a.y));
+            return o;
+        };
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const d2 b110 = ld(1, 1, 0, r), b120 = ld(1, 2, 0, r), b010 = ld(0, 1, 0, r), b020 = ld(0, 2, 0, r);
+            const d2 b011 = ld(0, 1, 1, r), b021 = ld(0, 2, 1, r), b111 = ld(1, 1, 1, r), b121 = ld(1, 2, 1, r);
+            d2 a0 = mul0(xs1[0][r], b110);
+            a0 = mac1(xs1[1][r], b120, a0);
+            a0 = mac1(xs0[0][r], b010, a0);
+            a0 = mac1(xs0[1][r], b020, a0);
+            d2 a1 = mul0(xs0[0][r], b011);
+            a1 = mac1(xs0[1][r], b021, a1);
+            a1 = mac1(xs1[0][r], b111, a1);
+            a1 = mac1(xs1[1][r], b121, a1);
+            S0[r] = a0;
+            S1[r] = a1;
+        }
+        d2 ut[8];
+        fft_inv_x2(S0, S1, ut, s_tw, s_twist, scr, lane);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const d2 y0 = cmulc(S0[r], ut[r]), y1 = cmulc(S1[r], ut[r]); // 1/512 is in the key image
+            racc0[r] += wrap_trunc(y0.x);
+            racc0[8 + r] += wrap_trunc(y0.y);
+            racc1[r] += wrap_trunc(y1.x);
+            racc1[8 + r] += wrap_trunc(y1.y);
+        }
+        wave_lds_fence();
+    }
+
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (A.step_end < A.n) { // not the last part: park the accumulators for the next launch
+        int32_t *st = A.acc_state + (size_t)job * 2 * kN;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            st[lane_e + 64 * (r & 7) + (r >> 3) * kNH] = (int32_t)racc0[r];
+            st[kN + lane_e + 64 * (r & 7) + (r >> 3) * kNH] = (int32_t)racc1[r];
+        }
+        return;
+    }
+    // tLweExtractLweSample, index 0: u_0 = ACC_0[0], u_j = -ACC_0[N - j]; b = ACC_1[0].  The signed periodic image of
+    // ACC_0 goes through the scratch once (read by index); register r holds coefficient lane + 64 (r & 7) + 512 (r >> 3)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int j = lane_e + 64 * r;
+        ext[j] = (int32_t)racc0[r];
+        ext[j + kN] = (int32_t)(0u - racc0[r]);
+    }
+    wave_lds_fence();
+    const int32_t bval = (int32_t)__builtin_amdgcn_readfirstlane((int)racc1[0]); // ACC_1[0]: lane 0, register 0
+    if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit) (transposed), out = (0, ..., 0, b)
+        const uint32_t gjob = A.job0 + job;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = lane_e + 64 * r;
+            A.ubarT[(size_t)j * A.ks_jstride + gjob] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
+        }
+        const uint32_t g = gjob / A.ks_S, si = gjob - g * A.ks_S;
+        int32_t *o = A.ks_descs[g].out + (size_t)si * (A.n + 1);
+        for (int m = lane_e; m < A.n; m += 64) o[m] = 0;
+        if (lane_e == 0) o[A.n] = bval;
+    } else {
+        int32_t *u = A.u + (size_t)job * (kN + 1);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = lane_e + 64 * r;
+            u[j] = ext[(2 * kN - j) & (2 * kN - 1)];
+        }
+        if (lane_e == 0) u[kN] = bval;
+    }
+}
+
+// =================================================================================================
 // K3: key switch (lweKeySwitch), two launches.
 //   k_ks_init      per ciphertext: ubarT[i][job] = u_i + 2^(31 - t*basebit)  (sum of the two extracted
 //                  samples + (0, mu) for MUX), out = (0, ..., 0, b')

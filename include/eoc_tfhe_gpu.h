@@ -178,6 +178,9 @@ uint64_t eoc_engine_workspace_grows(eoc_engine *e);
 /* k_blind_rotate kernel launches so far (eoc_engine_kernel_times counts one span per blind-rotate CALL; a wide level is
  * cut into single-round launches and a gadget-length-3 blind rotation into two parts, so launches >= spans) */
 uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e);
+/* ... of which launches of the one-wave-per-ciphertext kernel (k_blind_rotate_wide: gadget length 2, levels of at least
+ * 6 blind rotations per compute unit -- 1 536 on MI355X; bit-identical to the pair kernel, tests/test_gpu_parity.py) */
+uint64_t eoc_engine_blind_rotate_wide_launches(eoc_engine *e);
 int eoc_engine_device(eoc_engine *e);
 const eoc_params *eoc_engine_params(eoc_engine *e);
 /*

@@ -450,10 +450,13 @@ def test_deep_chain_bit_exact_set_a(eoc, rig_a):
 
 
 @pytest.mark.parametrize("env", [{"EOC_TFHE_BR_PARTS": "3"}, {"EOC_TFHE_BR_PARTS": "1", "EOC_TFHE_BR_SLICE": "5"},
-                                 {"EOC_TFHE_NO_FOLD": "1"}, {"EOC_TFHE_PRIO_DUTY": "-1", "EOC_TFHE_BR_SLICE": "-1"}])
+                                 {"EOC_TFHE_NO_FOLD": "1"}, {"EOC_TFHE_PRIO_DUTY": "-1", "EOC_TFHE_BR_SLICE": "-1"},
+                                 {"EOC_TFHE_BR_WIDE": "1"}, {"EOC_TFHE_BR_WIDE": "1", "EOC_TFHE_BR_PARTS": "3", "EOC_TFHE_NO_FOLD": "1"},
+                                 {"EOC_TFHE_BR_WIDE": "1", "EOC_TFHE_BR_SLICE": "5"}, {"EOC_TFHE_BR_WIDE": "0"}])
 def test_launch_shapes_do_not_change_results(eoc, monkeypatch, env):
     """the launch-shape knobs of the engine -- a blind rotation cut into consecutive launches (accumulators parked in
-    between), job slices, the separate k_ks_init launch, wave priorities off -- give the oracle's bits, all of them"""
+    between), job slices, the separate k_ks_init launch, wave priorities off, the one-wave-per-ciphertext kernel forced
+    on narrow launches (gadget length 2; odd job counts leave an idle wave) or off -- give the oracle's bits, all of them"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for pset in (0, 1):
@@ -466,3 +469,37 @@ def test_launch_shapes_do_not_change_results(eoc, monkeypatch, env):
         ops = np.array([0, 4, 10, 11, 10, 0, 2, 13, 4, 12, 10, 14, 0], np.uint8)
         assert np.array_equal(r.gate(0, c0, c1, c2, ops=ops), r.orc.gate_batch(0, c0, c1, c2, ops=ops))
         r.eng.close()
+
+
+def test_wide_kernel_full_width_bit_exact(eoc, rig_a):
+    """k_blind_rotate_wide (one wave per ciphertext; levels wider than the pair kernel's resident set, gadget length 2)
+    against the oracle and against the pair kernel.  3 400 NAND gates = one full wide launch (2 048) + a 1 352-job wide
+    remainder; 2 304 = a full wide launch + a 256-job remainder on the pair kernel; both compared row for row with the pair
+    kernel's output for the same operands (narrow calls) and on a seeded sample with the oracle; plus a 1 100-gate MUX
+    level (2 200 blind rotations, unfolded key-switch set-up)."""
+    r = rig_a
+    cnt = 3400
+    b0, c0 = _rand_cts(r, cnt, 91)
+    b1, c1 = _rand_cts(r, cnt, 92)
+    st0 = r.eng.stats()
+    got = r.gate(eoc.OPS["NAND"], c0, c1)
+    st1 = r.eng.stats()
+    assert st1["br_wide_launches"] - st0["br_wide_launches"] == 2 and st1["br_launches"] - st0["br_launches"] == 2, (st0, st1)
+    assert np.array_equal(r.sk.decrypt_bits(got), 1 - (b0 & b1))
+    pick = np.random.default_rng(3).choice(cnt, 96, replace=False)
+    assert np.array_equal(got[pick], r.orc.gate_batch(ol.OPS["NAND"], c0[pick], c1[pick]))
+    narrow = np.concatenate([r.gate(eoc.OPS["NAND"], c0[a:a + 1000], c1[a:a + 1000]) for a in range(0, cnt, 1000)])
+    st2 = r.eng.stats()
+    assert st2["br_wide_launches"] == st1["br_wide_launches"]                     # the pair kernel ran those
+    assert np.array_equal(got, narrow)
+    got2 = r.gate(eoc.OPS["NAND"], c0[:2304], c1[:2304])
+    st3 = r.eng.stats()
+    assert st3["br_wide_launches"] - st2["br_wide_launches"] == 1 and st3["br_launches"] - st2["br_launches"] == 2
+    assert np.array_equal(got2, narrow[:2304])
+    m = 1100
+    b2, c2 = _rand_cts(r, m, 93)
+    gm = r.gate(eoc.OPS["MUX"], c0[:m], c1[:m], c2)
+    assert r.eng.stats()["br_wide_launches"] == st3["br_wide_launches"] + 1
+    assert np.array_equal(r.sk.decrypt_bits(gm), np.where(b0[:m] == 1, b1[:m], b2))
+    pm = pick[pick < m][:24]
+    assert np.array_equal(gm[pm], r.orc.gate_batch(ol.OPS["MUX"], c0[pm], c1[pm], c2[pm]))

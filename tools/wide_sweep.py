@@ -1,0 +1,58 @@
+"""Pair kernel against the one-wave-per-ciphertext kernel over launch widths (Set A, device-pointer API, NAND).
+Usage (GPU box): python tools/wide_sweep.py [duty ...]   -- each duty is an EOC_TFHE_PRIO_DUTY value for the wide kernel
+(default: the built-in alternation).  Prints ms per call and bootstraps/s; every result is decrypt-checked and the two
+kernels' outputs are compared bit for bit."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import eoc_tfhe_amd as eoc  # noqa: E402
+
+p = eoc.default_params(0)
+sk = eoc.SecretKey(p, 1)
+WIDTHS = [int(x) for x in os.environ.get("WIDTHS", "1024,1280,1536,2048,3072,4096,6144,8192,16384").split(",")]
+G = max(WIDTHS)
+bits = np.random.default_rng(0).integers(0, 2, G).astype(np.uint8)
+c0 = torch.from_numpy(sk.encrypt_bits(bits, 2, 0)).cuda()
+c1 = torch.from_numpy(sk.encrypt_bits(bits, 3, 0)).cuda()
+ref = {}
+modes = [("pair", {"EOC_TFHE_BR_WIDE": "0"}), ("auto (shipped policy)", {})]
+duties = sys.argv[1:] or [""]
+for d in duties:
+    env = {"EOC_TFHE_BR_WIDE": "1"}
+    if d:
+        env["EOC_TFHE_PRIO_DUTY"] = d
+    modes.append((f"wide duty={d or 'default'}", env))
+for name, env in modes:
+    for k in ("EOC_TFHE_BR_WIDE", "EOC_TFHE_PRIO_DUTY"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    eng.set_profiling(True)
+    line = []
+    for cnt in WIDTHS:
+        out = torch.empty_like(c0[:cnt])
+        for _ in range(6):
+            eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), None, out.data_ptr(), cnt)
+        torch.cuda.synchronize()
+        eng.kernel_times(reset=True)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), None, out.data_ptr(), cnt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        kt = eng.kernel_times(reset=True)
+        o = out.cpu().numpy()
+        ok = np.array_equal(sk.decrypt_bits(o), 1 - bits[:cnt])
+        if name == "pair":
+            ref[cnt] = o
+        same = np.array_equal(o, ref[cnt])
+        line.append(f"{cnt}: {dt * 1e3:.3f} ms {cnt / dt / 1e3:.1f}k{'' if ok else ' WRONG'}{'' if same else ' DIFFERS'}")
+    print(f"{name:24s} " + " | ".join(line), flush=True)
+    eng.close()
