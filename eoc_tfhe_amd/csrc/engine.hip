@@ -48,11 +48,14 @@ struct eoc_engine {
     struct Workspace {
         uint16_t *d_bara = nullptr;
         int32_t *d_u = nullptr;
-        uint32_t *d_ubarT = nullptr; // [N][ws_jobs + 64] key-switch operand, transposed
+        uint32_t *d_ubar = nullptr;  // [ws_jobs][N] key-switch operand u + 2^(31 - t basebit), row-major
         int32_t *d_acc_state = nullptr; // [resident jobs][2][N]: accumulators between the parts of a cut blind rotation
         size_t ws_jobs = 0;
         GateDesc *d_descs = nullptr, *h_descs = nullptr; // device ring + pinned host ring, same capacity
         size_t ws_descs = 0, desc_pos = 0;
+        // recorded behind the consumers of the ring's last quarter (ring_mark): what the wrap-around waits for
+        hipEvent_t ring_ev = nullptr;
+        bool ring_ev_set = false;
         // descriptors sent while the stream is being captured into a hipGraph live in blocks that are never re-used:
         // the captured copy node reads its pinned source again at every replay
         // (allocated with the ring -- nothing may be allocated while a stream captures -- four times its size)
@@ -72,6 +75,7 @@ struct eoc_engine {
     int br_parts = 0;                       // consecutive launches per blind rotation (EOC_TFHE_BR_PARTS); 0 = by key-row size
     int br_wide = -1;                       // one-wave-per-ciphertext kernel: -1 = by launch width, 0 = never, 1 = whenever l = 2 (EOC_TFHE_BR_WIDE)
     int bara_stride = 0;
+    bool ks_waves_ok = true;                // the > 64 KiB dynamic-LDS attribute of k_keyswitch_waves was granted
     uint64_t stats[3] = {0, 0, 0};
     uint64_t ws_grows = 0; // times a workspace had to grow inside a call (0 after eoc_engine_reserve)
     uint64_t br_launches = 0; // k_blind_rotate kernel launches (a wide level is several, a cut blind rotation too)
@@ -236,14 +240,17 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (const char *s = getenv("EOC_TFHE_BR_WIDE")) e->br_wide = atoi(s);
     }
     // the key-switch kernel uses > 64 KiB of dynamic LDS: raise the limit once, here, not on the launch path
-#define EOC_KS_ATTR(TT, NWV, IWV)                                                                   \
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&k_keyswitch_waves<TT, NWV, IWV>),           \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, KS3Cfg<TT, NWV, IWV>::LDS_BYTES)
+    // (a device that refuses it -- 64 KiB of LDS per workgroup -- sends every shape to k_keyswitch_generic: slow, exact)
+#define EOC_KS_ATTR(TT, NWV, IWV)                                                                              \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_keyswitch_waves<TT, NWV, IWV>),                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, KS3Cfg<TT, NWV, IWV>::LDS_BYTES) != hipSuccess) \
+        e->ks_waves_ok = false
     EOC_KS_ATTR(8, 8, 16);
     EOC_KS_ATTR(8, 8, 32);
     EOC_KS_ATTR(8, 4, 64);
     EOC_KS_ATTR(8, 8, 64);
 #undef EOC_KS_ATTR
+    if (!e->ks_waves_ok) (void)hipGetLastError();
     *out = e;
     return EOC_OK;
 }
@@ -252,13 +259,14 @@ static void free_ws(eoc_engine::Workspace &W)
 {
     hipFree(W.d_bara);
     hipFree(W.d_u);
-    hipFree(W.d_ubarT);
+    hipFree(W.d_ubar);
     hipFree(W.d_acc_state);
     hipFree(W.d_descs);
     hipFree(W.d_mixed);
     if (W.h_descs) hipHostFree(W.h_descs);
     if (W.h_perm) hipHostFree(W.h_perm);
     if (W.perm_ev) hipEventDestroy(W.perm_ev);
+    if (W.ring_ev) hipEventDestroy(W.ring_ev);
     hipFree(W.d_persist);
     if (W.h_persist) hipHostFree(W.h_persist);
     W = eoc_engine::Workspace();
@@ -307,16 +315,16 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
     if (jobs > W.ws_jobs) {
         hipFree(W.d_bara);
         hipFree(W.d_u);
-        hipFree(W.d_ubarT);
+        hipFree(W.d_ubar);
         W.d_bara = nullptr;
         W.d_u = nullptr;
-        W.d_ubarT = nullptr;
+        W.d_ubar = nullptr;
         W.ws_jobs = 0;
         size_t cap = (std::max<size_t>(jobs, 1024) + 63) / 64 * 64;
         HIP_TRY(hipMalloc(&W.d_bara, cap * e->bara_stride * sizeof(uint16_t)));
         HIP_TRY(hipMalloc(&W.d_u, cap * (kN + 1) * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&W.d_ubarT, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(W.d_ubarT, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&W.d_ubar, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(W.d_ubar, 0, (cap + KS_GT) * (size_t)kN * sizeof(uint32_t)));
         // NULL-stream audit: ordered by the hipDeviceSynchronize two lines below.
         // the memset runs on the NULL stream and callers may launch on hipStreamNonBlocking streams, which do not wait for
         // it: without this the fill could land on key-switch operands the first batch has already written (seen as 7
@@ -337,6 +345,8 @@ static int ensure_ws(eoc_engine *e, eoc_engine::Workspace &W, size_t jobs, size_
         HIP_TRY(hipMalloc(&W.d_descs, cap * sizeof(GateDesc)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&W.h_descs), cap * sizeof(GateDesc), hipHostMallocDefault));
         W.ws_descs = cap;
+        if (!W.ring_ev) HIP_TRY(hipEventCreateWithFlags(&W.ring_ev, hipEventDisableTiming));
+        W.ring_ev_set = false;
         if (W.persist_pos == 0) { // no captured graph refers to the arena yet: it may grow with the ring
             hipFree(W.d_persist);
             if (W.h_persist) hipHostFree(W.h_persist);
@@ -600,8 +610,8 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
             a.mu = (int32_t)(1u << 29);
             a.stamps = e->d_stamps;
             a.ks_descs = fold_descs;
-            a.ubarT = W.d_ubarT;
-            a.ks_jstride = (uint32_t)W.ws_jobs + KS_GT;
+            a.prep = fold_descs != nullptr;
+            a.ubar = W.d_ubar;
             a.ks_S = fold_S ? fold_S : 1;
             a.ks_prec_offset = 1u << (32 - (1 + e->p.ks_basebit * e->p.ks_t));
             a.job0 = off;
@@ -645,13 +655,12 @@ static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint3
     KSArgs a;
     a.ksk = e->ksk;
     a.u = W.d_u;
-    a.ubarT = W.d_ubarT;
+    a.ubar = W.d_ubar;
     a.n = e->p.n;
     a.n1p = (int)e->n1p;
     a.t = e->p.ks_t;
     a.basebit = e->p.ks_basebit;
     a.S = S;
-    a.jstride = (uint32_t)W.ws_jobs + KS_GT;
     a.mu = (int32_t)(1u << 29);
     SpanGuard span(e, st, KIND_KEYSWITCH);
     if (!init_done) { // levels with MUX (two extracted samples are summed) and the stand-alone key switch
@@ -670,10 +679,11 @@ static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint3
     } while (0)
     // basebit 2, t 8 (both default sets): waves per workgroup x indices per wave chosen so that 1024 gates give every SIMD
     // its 3-4 waves: 4096 waves for n1p = 256 / 512 / 1024, 3072 (three 4-wave workgroups per CU) for n1p = 768
-    if (bb == 2 && t == 8 && ncb == 4) EOC_KS_LAUNCH(8, 8, 16);
-    else if (bb == 2 && t == 8 && ncb == 8) EOC_KS_LAUNCH(8, 8, 32);
-    else if (bb == 2 && t == 8 && ncb == 12) EOC_KS_LAUNCH(8, 4, 64);
-    else if (bb == 2 && t == 8 && ncb == 16) EOC_KS_LAUNCH(8, 8, 64);
+    const bool fast = bb == 2 && t == 8 && e->ks_waves_ok;
+    if (fast && ncb == 4) EOC_KS_LAUNCH(8, 8, 16);
+    else if (fast && ncb == 8) EOC_KS_LAUNCH(8, 8, 32);
+    else if (fast && ncb == 12) EOC_KS_LAUNCH(8, 4, 64);
+    else if (fast && ncb == 16) EOC_KS_LAUNCH(8, 8, 64);
     else // any other shape (no default set has one): the plain one-thread-per-word form
         hipLaunchKernelGGL(k_keyswitch_generic, dim3(S, ngates), dim3(256), 0, st, d_descs, a);
 #undef EOC_KS_LAUNCH
@@ -712,10 +722,14 @@ static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, 
         return EOC_ERR_STATE;
     }
     if (W.desc_pos + count > W.ws_descs) {
-        // wrap (rare: the ring is sized for everything a call sends): an engine may have been driven from another stream
-        // before this call, whose descriptor copies out of the slots about to be rewritten could still be in flight --
-        // wait for the whole device, not only for `st`
-        HIP_TRY(hipDeviceSynchronize());
+        // wrap (rare: the ring is sized for everything a call sends).  The slots about to be rewritten were read by copies
+        // and kernels of earlier calls: wait for the event ring_mark recorded behind the LAST consumers of the ring's final
+        // quarter.  An engine's kernels run on one stream at a time (the workspace is shared: callers order their streams),
+        // so that event is behind every earlier consumer too; only the engine's own work is waited for, not the device --
+        // a neighbouring batch's copy streams and captures elsewhere in the process are left alone.
+        if (W.ring_ev_set) HIP_TRY(hipEventSynchronize(W.ring_ev));
+        else HIP_TRY(hipDeviceSynchronize()); // one push filled three quarters of the ring by itself: no mark yet
+        W.ring_ev_set = false;
         W.desc_pos = 0;
     }
     memcpy(W.h_descs + W.desc_pos, src, count * sizeof(GateDesc));
@@ -724,6 +738,15 @@ static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, 
     *d_out = W.d_descs + W.desc_pos;
     W.desc_pos += count;
     return EOC_OK;
+}
+
+// called behind the kernels that consume pushed descriptors: marks the stream position the next wrap-around waits for
+// (only once the ring is three quarters full: one event record per ~thousand launches; never under capture -- captured
+// descriptors live in the arena)
+static void ring_mark(WS &W, hipStream_t st)
+{
+    if (!W.ring_ev || W.desc_pos * 4 < W.ws_descs * 3 || stream_is_capturing(st)) return;
+    if (hipEventRecord(W.ring_ev, st) == hipSuccess) W.ring_ev_set = true;
 }
 
 // One "level": a set of gates that all run over the same S instances.  descs are host-side and
@@ -764,15 +787,17 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
         GateDesc *dd = nullptr;
         int rc = push_descs(W, boot.data() + g0, cnt, st, &dd);
         if (rc) return rc;
-        {
+        // without MUX every gate has S jobs (job = gate * S + instance): the blind rotation's prologue derives its own
+        // rotation amounts from the operand rows (k_prepare folded away) and its epilogue sets the key switch up
+        // (k_ks_init folded away) -- one launch per level besides the key switch; EOC_TFHE_NO_FOLD=1 keeps the separate
+        // launches (diagnostics)
+        const bool fold = !any_mux && !e->no_fold;
+        if (!fold) {
             dim3 grid((unsigned)(S * (any_mux ? 2 : 1)), (unsigned)((n + 1 + 255) / 256), (unsigned)cnt);
             SpanGuard span(e, st, KIND_PREPARE);
             hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, W.d_bara, e->bara_stride);
             HIP_TRY(hipGetLastError());
         }
-        // without MUX every gate has S jobs (job = gate * S + instance) and the blind rotate's epilogue sets the key
-        // switch up itself (k_ks_init folded away); EOC_TFHE_NO_FOLD=1 keeps the separate launch (diagnostics)
-        const bool fold = !any_mux && !e->no_fold;
         rc = launch_blind_rotate(e, W, jobs, st, fold ? dd : nullptr, (uint32_t)S);
         if (rc) return rc;
         rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st, fold);
@@ -782,6 +807,7 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
         e->stats[2] += S * cnt;
         g0 = g1;
     }
+    ring_mark(W, st);
     return EOC_OK;
 }
 
@@ -1024,6 +1050,7 @@ extern "C" int eoc_blind_rotate_device(eoc_engine *e, const int32_t *d_t, int32_
     rc = launch_blind_rotate(e, W, (uint32_t)count, st);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_u, W.d_u, count * (kN + 1) * 4, hipMemcpyDeviceToDevice, st));
+    ring_mark(W, st);
     return EOC_OK;
 }
 
@@ -1043,7 +1070,9 @@ extern "C" int eoc_keyswitch_device(eoc_engine *e, const int32_t *d_u, int32_t *
     GateDesc d{OP_RAW, 0, nullptr, nullptr, nullptr, d_out}, *dd = nullptr;
     rc = push_descs(W, &d, 1, st, &dd);
     if (rc) return rc;
-    return launch_keyswitch(e, W, dd, 1, (uint32_t)count, st);
+    rc = launch_keyswitch(e, W, dd, 1, (uint32_t)count, st);
+    ring_mark(W, st);
+    return rc;
 }
 
 extern "C" int eoc_engine_set_profiling(eoc_engine *e, int on)

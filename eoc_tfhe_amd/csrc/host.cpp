@@ -463,13 +463,18 @@ std::string b64_encode(const unsigned char *d, size_t len)
 // stops at the first non-alphabet byte, like the reference decoder (eoc-tfhe-run.cpp:77-80)
 std::string b64_decode(const char *s)
 {
-    static int8_t T[256];
-    static bool init = false;
-    if (!init) {
-        memset(T, -1, sizeof T);
-        for (int i = 0; i < 64; i++) T[(unsigned char)kB64[i]] = int8_t(i);
-        init = true;
-    }
+    // built once by the thread-safe initialisation of a function-local static (two threads may make their first
+    // string-API call together)
+    struct Table {
+        int8_t t[256];
+        Table()
+        {
+            memset(t, -1, sizeof t);
+            for (int i = 0; i < 64; i++) t[(unsigned char)kB64[i]] = int8_t(i);
+        }
+    };
+    static const Table table;
+    const int8_t *T = table.t;
     std::string o;
     uint32_t acc = 0;
     int bits = 0;
@@ -540,6 +545,20 @@ int ensure_engine_locked()
     if (!eoc_global_engine()) { // EOC_TFHE_DEVICES = "all" | "0,1,..." puts several GPUs behind the one global key
         int rc = eoc_gpu_init_from_env(p);
         if (rc) return rc;
+    } else {
+        // an engine brought up earlier by eoc_gpu_init sizes every copy and stride from ITS parameters: a key of another
+        // shape (e.g. a Set A cloud-key blob imported behind a Set B engine) would be read out of bounds or evaluate
+        // garbage -- refuse it by name
+        const eoc_params *ep = eoc_engine_params(eoc_global_engine());
+        if (!ep || ep->n != p->n || ep->l != p->l || ep->Bgbit != p->Bgbit || ep->ks_t != p->ks_t ||
+            ep->ks_basebit != p->ks_basebit) {
+            eoc_set_error("the global engine was initialised for n=%d l=%d Bgbit=%d ks_t=%d ks_basebit=%d but the key is "
+                          "n=%d l=%d Bgbit=%d ks_t=%d ks_basebit=%d; eoc_gpu_shutdown() first or import a matching key",
+                          ep ? ep->n : -1, ep ? ep->l : -1, ep ? ep->Bgbit : -1, ep ? ep->ks_t : -1,
+                          ep ? ep->ks_basebit : -1, p->n, p->l, p->Bgbit, p->ks_t, p->ks_basebit);
+            fprintf(stderr, "%s\n", eoc_last_error());
+            return EOC_ERR_ARG;
+        }
     }
     int rc = eoc_upload_cloud_key_arrays(bk.data(), ksk.data());
     if (rc) return rc;

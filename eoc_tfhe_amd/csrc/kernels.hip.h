@@ -528,6 +528,21 @@ __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ de
     bara[(size_t)(d.job_base + y) * bara_stride + m] = (uint16_t)(((t + (1u << 20)) >> 21) & 2047u);
 }
 
+// the same for ONE job inside the blind rotation (levels without MUX): thread `t` of `nt` writes entries t, t + nt, ... of
+// the job's row; the caller orders the stores before its scalar loads of the row (release fence + barrier + s_dcache_inv)
+__device__ __forceinline__ void prepare_row(const GateDesc &d, uint32_t inst, int n, uint16_t *row, int t, int nt)
+{
+    int cst8, s0, s1;
+    gate_lin(d.op, cst8, s0, s1);
+    const size_t base = (size_t)inst * (n + 1);
+    for (int m = t; m <= n; m += nt) {
+        uint32_t v = (uint32_t)s0 * (uint32_t)d.in0[base + m];
+        if (s1) v += (uint32_t)s1 * (uint32_t)d.in1[base + m];
+        if (m == n) v += (uint32_t)cst8 << 29;
+        row[m] = (uint16_t)(((v + (1u << 20)) >> 21) & 2047u);
+    }
+}
+
 // NOT / COPY: no bootstrap.  grid: x = ceil(S*(n+1)/256), y = gates
 __global__ __launch_bounds__(256) void k_free_gates(const GateDesc *__restrict__ descs, size_t total, int rowlen, int32_t mu)
 {
@@ -592,7 +607,7 @@ constexpr int kPrioDuty = 11;
 // =================================================================================================
 struct BRArgs {
     const double *bkfft;  // [n][2l][2][512] complex, bin order sigma, scaled by 2^-9
-    const uint16_t *bara; // [jobs][stride], entry n = barb
+    uint16_t *bara;       // [jobs][stride], entry n = barb (written by k_prepare, or by this kernel's prologue: `prep`)
     int32_t *u;           // [jobs][N+1]
     uint32_t njobs;
     int n, Bgbit, bara_stride;
@@ -602,8 +617,10 @@ struct BRArgs {
     // folded key-switch set-up (levels without MUX): the epilogue writes the key-switch operand and the output row
     // itself, k_ks_init is not launched and the extracted sample never goes to memory
     const GateDesc *ks_descs;   // non-null = fold; gate of job j is j / ks_S (jobs are [gate][instance])
-    uint32_t *ubarT;            // [N][ks_jstride]
-    uint32_t ks_jstride, ks_S, ks_prec_offset, job0; // job0: first job of this launch within the level
+    int prep;                   // fold only: the prologue derives the job's rotation amounts from the gate's operand rows
+                                // itself (bootsNAND... linear stage + modSwitchFromTorus32), k_prepare is not launched
+    uint32_t *ubar;             // [jobs][N], row-major: the epilogue's stores are lane-contiguous (256 B per instruction)
+    uint32_t ks_S, ks_prec_offset, job0; // job0: first job of this launch within the level
     // step range of this launch: the n steps of a blind rotation may be cut into consecutive launches; every boundary
     // brings all workgroups of the chip back to the same step (the accumulator travels through `acc_state`)
     int step_begin, step_end;
@@ -669,6 +686,13 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     };
 
     load_tables(s_tw, s_twist, g_tw, g_twist, tid, 128);
+    if (A.prep && A.step_begin == 0) { // folded k_prepare: this workgroup's row of rotation amounts
+        const uint32_t gjob = A.job0 + job, g = gjob / A.ks_S;
+        prepare_row(A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, tid, 128);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the row is read back through the scalar cache
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();
+    }
 
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
     uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8), lane + 64 r + 512 in racc[8 + r]
@@ -887,13 +911,13 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         return;
     }
     // tLweExtractLweSample, index 0: u_0 = ACC_0[0], u_j = -ACC_0[N - j] = ext[2N - j]; b = ACC_1[0]
-    if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit) (transposed), out = (0, ..., 0, b)
+    if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit), out = (0, ..., 0, b)
         const uint32_t gjob = A.job0 + job;
         if (h == 0) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int j = lane + 64 * r;
-                A.ubarT[(size_t)j * A.ks_jstride + gjob] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
+                A.ubar[(size_t)gjob * kN + j] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
             }
         } else {
             const uint32_t g = gjob / A.ks_S, si = gjob - g * A.ks_S;
@@ -1025,7 +1049,13 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
 
     const uint32_t job = blockIdx.x * kBRWideJobsPerWG + (uint32_t)h; // grid = ceil(jobs / waves per workgroup)
     load_tables(s_tw, s_twist, g_tw, g_twist, tid, 64 * kBRWideJobsPerWG);
+    if (A.prep && A.step_begin == 0 && job < A.njobs) { // folded k_prepare: this wave's row of rotation amounts
+        const uint32_t gjob = A.job0 + job, g = gjob / A.ks_S;
+        prepare_row(A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, lane, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the row is read back through the scalar cache
+    }
     __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
     if (job >= A.njobs) return; // the idle wave of an odd last workgroup (the only barrier is behind it)
 
     typedef const __attribute__((address_space(4))) uint32_t *cu32p;
@@ -1184,12 +1214,12 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
     }
     wave_lds_fence();
     const int32_t bval = (int32_t)__builtin_amdgcn_readfirstlane((int)racc1[0]); // ACC_1[0]: lane 0, register 0
-    if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit) (transposed), out = (0, ..., 0, b)
+    if (A.ks_descs) { // + lweKeySwitch set-up: ubar_j = u_j + 2^(31 - t basebit), out = (0, ..., 0, b)
         const uint32_t gjob = A.job0 + job;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int j = lane_e + 64 * r;
-            A.ubarT[(size_t)j * A.ks_jstride + gjob] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
+            A.ubar[(size_t)gjob * kN + j] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
         }
         const uint32_t g = gjob / A.ks_S, si = gjob - g * A.ks_S;
         int32_t *o = A.ks_descs[g].out + (size_t)si * (A.n + 1);
@@ -1208,7 +1238,7 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
 
 // =================================================================================================
 // K3: key switch (lweKeySwitch), two launches.
-//   k_ks_init      per ciphertext: ubarT[i][job] = u_i + 2^(31 - t*basebit)  (sum of the two extracted
+//   k_ks_init      per ciphertext: ubar[job][i] = u_i + 2^(31 - t*basebit)  (sum of the two extracted
 //                  samples + (0, mu) for MUX), out = (0, ..., 0, b')
 //   k_keyswitch_waves   basebit 2, even t: 64 ciphertexts per workgroup (one per lane), two digits per LDS look-up
 //                  through a table of row sums, partial sums of the i-slices through LDS and a few integer atomics
@@ -1220,9 +1250,9 @@ constexpr int KS_GT = 64; // ciphertexts per workgroup (one per lane)
 struct KSArgs {
     const int32_t *ksk;
     const int32_t *u;   // [jobs][N+1]
-    uint32_t *ubarT;    // [N][jstride]
+    uint32_t *ubar;     // [jobs][N] row-major
     int n, n1p, t, basebit;
-    uint32_t S, jstride;
+    uint32_t S;
     int32_t mu;
 };
 
@@ -1239,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_ks_init(const GateDesc *__restrict__ de
     for (int j = threadIdx.x; j < kN; j += 256) {
         uint32_t v = (uint32_t)u1[j];
         if (mux) v += (uint32_t)u2[j];
-        A.ubarT[(size_t)j * A.jstride + job] = v + prec_offset;
+        A.ubar[(size_t)job * kN + j] = v + prec_offset;
     }
     int32_t *o = d.out + (size_t)s * (A.n + 1);
     for (int m = threadIdx.x; m < A.n; m += 256) o[m] = 0;
@@ -1301,6 +1331,9 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
     static_assert((NWV * C::WAVE_I - C::TABI) * 4 < 65536, "ds_write_addtid_b32 takes its base from M0[15:0]");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *s_all = reinterpret_cast<int *>(smem);
+    // ds_write_addtid_b32 adds M0[15:0]: the static_assert above bounds the largest base ONLY IF the dynamic block starts at
+    // LDS offset 0, i.e. the kernel has no static __shared__ object -- trap instead of silently wrapping if that ever changes
+    if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();
 
     const GateDesc d = descs[blockIdx.y];
     const uint32_t ntiles = (A.S + 63) / 64, ncb = (uint32_t)A.n1p / 64u;
@@ -1359,7 +1392,9 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
                        "n"(EOC_KS_ROW(0, 1, 1)), "n"(EOC_KS_ROW(0, 1, 2)), "n"(EOC_KS_ROW(0, 1, 3)), "n"(EOC_KS_ROW(0, 2, 0)),
                        "n"(EOC_KS_ROW(0, 2, 1)), "n"(EOC_KS_ROW(0, 2, 2)), "n"(EOC_KS_ROW(0, 2, 3)), "n"(EOC_KS_ROW(0, 3, 0)),
                        "n"(EOC_KS_ROW(0, 3, 1)), "n"(EOC_KS_ROW(0, 3, 2)), "n"(EOC_KS_ROW(0, 3, 3))
-                     : "memory");
+                     : "memory"); // (an "m0" clobber is refused -- "reserved register" -- so M0 is saved and restored by
+                                  // hand inside the block; the trailing s_mov m0 is followed by the block's own consumers
+                                  // only after a wave_lds_fence, never by an M0-reading instruction of the compiler's)
     };
 #undef EOC_KS_ROW
 
@@ -1370,10 +1405,17 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
     stage_load(0);
     stage_store(0);
     wave_lds_fence();
-    const uint32_t *ubp = A.ubarT + (size_t)i0 * A.jstride + job;
+    // this lane's IW operand words are IW * 4 contiguous bytes of its ciphertext's row (the blind rotation's epilogue
+    // writes rows, coalesced): read 16 bytes every fourth index -- the tile is transposed on load, one lane per row
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 *ubp = reinterpret_cast<const u4 *>(A.ubar + (size_t)job * kN + i0);
+    u4 ub4 = ubp[0];
 #pragma unroll 1
     for (int ii = 0; ii < IW; ii++) {
-        const uint32_t ub = ubp[(size_t)ii * A.jstride];
+        const int k4 = ii & 3;
+        const uint32_t ub = k4 == 0 ? ub4.x : (k4 == 1 ? ub4.y : (k4 == 2 ? ub4.z : ub4.w));
+        u4 ub4n = ub4;
+        if (k4 == 3 && ii + 1 < IW) ub4n = ubp[(ii + 1) >> 2];
 #pragma unroll 1
         for (int q = 0; q < C::NPAIR; q++) {
             const int st = ii * C::NPAIR + q;
@@ -1393,6 +1435,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
             stage_store(buf ^ 1);
             wave_lds_fence();
         }
+        ub4 = ub4n;
     }
 
     // the workgroup's NWV partial sums -> one: the upper half of the waves parks its accumulators in LDS, the lower half adds
@@ -1441,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_generic(const GateDesc *__res
     for (int m = threadIdx.x; m <= A.n; m += 256) {
         uint32_t acc = (uint32_t)o[m];
         for (int i = 0; i < kN; i++) {
-            const uint32_t ub = A.ubarT[(size_t)i * A.jstride + job];
+            const uint32_t ub = A.ubar[(size_t)job * kN + i];
             for (int j = 0; j < A.t; j++) {
                 const uint32_t dg = (ub >> (32 - (j + 1) * A.basebit)) & (uint32_t)base1;
                 if (dg) acc -= (uint32_t)A.ksk[(((size_t)i * A.t + j) * base1 + (dg - 1)) * A.n1p + m];

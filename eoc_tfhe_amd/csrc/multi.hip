@@ -69,7 +69,8 @@ struct Worker {
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             cv.wait(lk, [&] { return has_job || stop; });
-            if (stop) return;
+            if (!has_job) return; // stop, and nothing posted: a posted job is finished first, so that a thread inside
+                                  // wait() always sees has_job cleared (a slot destroyed under a live caller)
             std::function<int()> j = std::move(job);
             lk.unlock();
             const int r = j();
@@ -929,6 +930,18 @@ extern "C" int eoc_upload_cloud_key_arrays(const int32_t *bk, const int32_t *ksk
 extern "C" int eoc_upload_cloud_key(const eoc_secret_key *sk)
 {
     if (!sk || !eoc_sk_bk(sk) || !eoc_sk_ksk(sk)) return EOC_ERR_NO_KEY;
+    {   // the arrays are read with the ENGINE's shape: a key set of another shape is refused, not read out of bounds
+        std::lock_guard<std::mutex> g(G.mu);
+        const eoc_params *kp = eoc_sk_params(sk);
+        if (!G.slots.empty() && kp &&
+            (kp->n != G.p.n || kp->l != G.p.l || kp->Bgbit != G.p.Bgbit || kp->ks_t != G.p.ks_t ||
+             kp->ks_basebit != G.p.ks_basebit)) {
+            eoc_set_error("eoc_upload_cloud_key: key shape (n=%d l=%d Bgbit=%d ks %d x %d bits) differs from the engines' "
+                          "(n=%d l=%d Bgbit=%d ks %d x %d bits)", kp->n, kp->l, kp->Bgbit, kp->ks_t, kp->ks_basebit,
+                          G.p.n, G.p.l, G.p.Bgbit, G.p.ks_t, G.p.ks_basebit);
+            return EOC_ERR_ARG;
+        }
+    }
     return eoc_upload_cloud_key_arrays(eoc_sk_bk(sk), eoc_sk_ksk(sk));
 }
 

@@ -160,9 +160,13 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  * driven from ONE stream at a time (launches of successive calls on the same stream are ordered; use one
  * engine per stream, or synchronise, if several streams are needed).  Workspaces (device buffers and the pinned
  * host ring that carries gate descriptors) grow on demand outside the kernels (device synchronise + hipMalloc);
- * eoc_engine_reserve sizes them once, after which the launch path neither allocates nor synchronises and a fixed
+ * eoc_engine_reserve sizes them once, after which the launch path does not allocate and a fixed
  * netlist / batch shape can be captured into a hipGraph.  eoc_engine_workspace_grows counts growths since the
- * last reserve (0 in steady state).
+ * last reserve (0 in steady state).  It synchronises in ONE place: when the descriptor ring (max_descs slots, at least
+ * 1 024) wraps around -- once per ~thousand single-gate-kind batches -- the call waits, on an event recorded behind the
+ * engine's own most recent kernels, until the slots it is about to rewrite have been consumed.  Only this engine's
+ * earlier work is waited for (no device-wide synchronise: a neighbouring batch's copy streams and captures on other
+ * streams are not touched); a call on a capturing stream never wraps (its descriptors go to the arena below).
  * Capture rules: call eoc_engine_reserve BEFORE any stream of the process starts capturing -- growth synchronises the
  * whole device, which invalidates a global-mode capture in progress on ANY stream, and only the stream passed to the
  * call can be tested for it.  While hip_stream itself is being captured a call that would have to grow the workspace

@@ -1,11 +1,20 @@
-/* eoc-tfhe-gate-bindings.c -- text to merge into ao-tfhe/eoc-tfhe-bindings.c (pattern of l_addCiphertexts, :12-24:
- * read the arguments, call the extern "C" function, lua_pushstring the heap result, free() it, return 1).
- * NOT compiled in this repository: the build image has no Lua 5.3 SDK (lua.h); it is written against the Lua 5.3 C API
- * the reference uses.  The equivalent Node binding, integration/node/eoc_tfhe_node.c, is built and GPU-tested and has
- * the same entry points.  Needs <lua.h>, <lauxlib.h>, <stdlib.h>, <string.h>.
+/* eoc-tfhe-gate-bindings.c -- Lua 5.3 binding of the gate API, in the pattern of ao-tfhe/eoc-tfhe-bindings.c
+ * (l_addCiphertexts, :12-24: read the arguments, call the extern "C" function, lua_pushstring the heap result, free() it,
+ * return 1).  A maintainer of the reference either merges the l_* functions and the entries of eoc_gate_functions[] into
+ * luaopen_tfhe's luaL_Reg table (ao-tfhe/eoc-tfhe-bindings.c:130-144), or builds this file as a module of its own
+ * (luaopen_tfhe_gates below; require("tfhe_gates")).
+ *
+ * Status: COMPILED AND EXECUTED AGAINST A TEST DOUBLE of the Lua C API (tests/lua_double/: a value stack with the dozen
+ * calls used here) -- every l_* entry is driven from C under ASan/UBSan (tests/c/lua_binding_driver.c, CPU legs) and from
+ * Python on the GPU against the oracle (tests/test_lua_binding.py).  NEVER against liblua: the build image has no Lua SDK.
+ * The equivalent Node binding, integration/node/eoc_tfhe_node.c, is built against the real N-API and has the same entries.
  *
  * Raw-buffer calls take and return Lua strings holding binary data (lua_pushlstring / luaL_checklstring): LWE samples
  * are int32 little-endian [count][n+1], bit arrays one byte per bit, netlists int32 [5 per gate: op, in0, in1, in2, out]. */
+#include <lua.h>
+#include <lauxlib.h>
+#include <stdlib.h>
+#include <string.h>
 #include "eoc_tfhe_gpu.h"
 
 static int l_generateGateKey(lua_State *L) {          /* like l_generateSecretKey, :38-48 */
@@ -187,7 +196,8 @@ static int l_engineCount(lua_State *L) { lua_pushinteger(L, eoc_gpu_engine_count
  * gateBatchWait -- the asynchronous batch path works on pinned, MUTABLE host buffers the caller keeps alive, which a
  * Lua string (immutable, garbage collected) cannot be. */
 
-/* appended to the luaL_Reg table of luaopen_tfhe (ao-tfhe/eoc-tfhe-bindings.c:130-144) */
+/* the entries to append to the luaL_Reg table of luaopen_tfhe (ao-tfhe/eoc-tfhe-bindings.c:130-144) */
+static const luaL_Reg eoc_gate_functions[] = {
   {"generateGateKey", l_generateGateKey}, {"resetGateKey", l_resetGateKey}, {"setDevices", l_setDevices},
   {"encryptBit", l_encryptBit},
   {"constantBit", l_constantBit}, {"decryptBit", l_decryptBit},
@@ -200,3 +210,10 @@ static int l_engineCount(lua_State *L) { lua_pushinteger(L, eoc_gpu_engine_count
   {"sampleInts", l_sampleInts}, {"encryptBits", l_encryptBits}, {"decryptBits", l_decryptBits},
   {"gateBatch", l_gateBatch}, {"circuitRun", l_circuitRun}, {"netlistOptimize", l_netlistOptimize},
   {"circuitBootstraps", l_circuitBootstraps}, {"deviceCount", l_deviceCount}, {"engineCount", l_engineCount},
+  {NULL, NULL}
+};
+/* the same functions as a module of their own, like luaopen_tfhe (:128-148) */
+int luaopen_tfhe_gates(lua_State *L) {
+  luaL_newlib(L, eoc_gate_functions);
+  return 1;
+}

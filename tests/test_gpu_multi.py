@@ -456,3 +456,28 @@ def test_error_from_a_worker_block_reaches_the_caller(eoc, ctx3):
     with pytest.raises(eoc.EocError, match="bad opcode 99"):
         eoc.gate_batch(0, c, c, ops=ops)
     assert np.array_equal(eoc.gate_batch(eoc.OPS["OR"], c, c), orc.gate_batch(ol.OPS["OR"], c, c))
+
+
+def test_key_of_another_shape_is_refused_by_the_engines(eoc):
+    """the global engines size every copy and stride from THEIR parameters.  A key set or an imported cloud-key
+    blob of another shape (Set A behind Set B engines and the reverse) must be refused by name -- before this check the
+    first order read host memory out of bounds in hipMemcpy2D and the second evaluated garbage."""
+    pa, pb = eoc.default_params(0), eoc.default_params(1)
+    pa.n, pb.n = 24, 20
+    ska, skb = eoc.SecretKey(pa, 3), eoc.SecretKey(pb, 3)
+    for eng_p, other in ((pb, ska), (pa, skb)):
+        eoc.gpu_shutdown()
+        eoc.Tfhe.resetGateKey()
+        eoc.gpu_init(eng_p, devices=[0])
+        with pytest.raises(eoc.EocError) as ei:
+            eoc.upload_cloud_key(other)
+        assert "differs from the engines'" in str(ei.value)
+        # the string / global surface: a cloud-key-only context of the other shape, engines already up
+        eoc.global_import_cloud_key_blob(other.export_cloud_key())
+        assert eoc.global_key_mode() == 2
+        z = np.zeros((2, other.params.n + 1), np.int32)
+        with pytest.raises(eoc.EocError) as ei:
+            eoc.global_gate_batch(eoc.OPS["NAND"], z, z)
+        assert "global engine was initialised for" in str(ei.value)
+        eoc.Tfhe.resetGateKey()
+    eoc.gpu_shutdown()
