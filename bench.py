@@ -140,7 +140,44 @@ class ClockSampler:
         return s[len(s) // 2], s[-1], len(s)
 
 
-def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_launch_ms=None):
+# Per wave-step instruction mix of the blind-rotate kernels (static: read off the ISA, confirmed by the PMC passes of
+# profiles/*_pmc_summary*.txt -- SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 + the truncations; SQ_INSTS_LDS) and the measured cost of
+# each LDS instruction on the CU's one LDS pipe at 8 waves per CU (tools/ubench_lds*.hip, profiles/r02_lds_forms.txt):
+# (FP64 instructions, ds_write_b128, ds_read_b128, ds_bpermute_b32).  "pair" = one ciphertext per wave PAIR
+# (k_blind_rotate), "wide" = one ciphertext per wave (k_blind_rotate_wide): a wave-step of the wide kernel is a whole
+# ciphertext-step.
+PIPE_MIX = {("A", "pair"): (836, 56, 72, 16), ("B", "pair"): (1124, 72, 104, 16), ("A", "wide"): (1672, 96, 128, 32)}
+LDS_CYCLES = {"ds_write_b128": 13.6, "ds_read_b128": 4.2, "ds_bpermute_b32": 6.2}
+FP64_ISSUE_CYCLES = 4       # one v_fma_f64 occupies its SIMD's FP64 pipe four cycles (16 lanes x 4 passes)
+WAVES_PER_SIMD, WAVES_PER_CU = 2, 8
+
+
+def pipe_busy(pset, shape, launch_ms, steps_per_launch, sclk_mhz):
+    """which pipe binds (VERDICT r4 task 6): busy fractions of the SIMD's FP64 pipe and of the CU's LDS pipe over a
+    blind-rotate launch, from this run's launch time and sampled shader clock and the stored instruction mix"""
+    mix = PIPE_MIX.get((pset, shape))
+    if not mix or not launch_ms or not sclk_mhz:
+        return None
+    fp64, w, r, b = mix
+    cyc_step = launch_ms * 1e-3 / steps_per_launch * sclk_mhz * 1e6
+    lds_cyc = w * LDS_CYCLES["ds_write_b128"] + r * LDS_CYCLES["ds_read_b128"] + b * LDS_CYCLES["ds_bpermute_b32"]
+    return {"fp64_pipe_busy": round(fp64 * FP64_ISSUE_CYCLES * WAVES_PER_SIMD / cyc_step, 3),
+            "lds_pipe_busy": round(lds_cyc * WAVES_PER_CU / cyc_step, 3),
+            "lds_store_share_of_lds_pipe": round(w * LDS_CYCLES["ds_write_b128"] / lds_cyc, 3),
+            "bound_primary": "lds_store_path",
+            "cycles_per_step": round(cyc_step), "sclk_mhz": sclk_mhz, "kernel_shape": shape,
+            "per_wave_step": {"fp64_insts": fp64, "ds_write_b128": w, "ds_read_b128": r, "ds_bpermute_b32": b,
+                              "lds_pipe_cycles": round(lds_cyc)},
+            "note": "fp64_pipe_busy = FP64 instructions per wave-step x 4 cycles x 2 waves per SIMD / cycles per step; "
+                    "lds_pipe_busy = (ds_write_b128 x 13.6 + ds_read_b128 x 4.2 + ds_bpermute_b32 x 6.2 cycles) x 8 waves per "
+                    "CU / cycles per step, at the shader clock sampled during the timed steps.  The CU's LDS STORE path "
+                    "(~79 B/clk: address + data VGPRs of a ds_write_b128 take 13.6 cycles per KiB) is the busier of the two "
+                    "and the one the ablations move most (DESIGN.md 5.1): bound_primary.  `bound` keeps naming the FP64 "
+                    "roofline the fraction is quoted against"}
+
+
+def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_launch_ms=None, sclk_mhz=None,
+                   shape="pair", steps_per_launch=None):
     """FP64-issue roofline of k_blind_rotate from this run's HIP-event launch duration (+ the stored PMC byte count).
     br_ms = blind-rotate time of `jobs_per_launch` whole blind rotations; traffic_launch_ms = duration of ONE kernel
     launch when a blind rotation runs as several (Set B: two parts), since the stored byte count is per launch."""
@@ -158,7 +195,7 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
             tsrc = f"profiles/traffic.json ({tj.get('collected', 'stored rocprofv3 PMC figure')}; not measured in this run)"
         except Exception:
             traffic = None
-    blk = {"bound": "fp64_valu", "kernel": "k_blind_rotate", "achieved": round(tf, 2),
+    blk = {"bound": "fp64_valu", "kernel": "k_blind_rotate_wide" if shape == "wide" else "k_blind_rotate", "achieved": round(tf, 2),
            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
            "traffic": traffic, "traffic_unit": "HBM/fabric bytes per launch (rocprofv3 PMC, stored profile figure)",
            "traffic_source": tsrc,
@@ -196,6 +233,10 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
                                "instruction is ready but the CU's LDS pipe is taken; the store path moves ~79 B/clk/CU "
                                f"(ds_write_b128 = 13.6 cycles), {cb.get('ds_write_b128_per_wave_step')} such stores per "
                                "wave-step (DESIGN.md 5.1)")
+    pb_ = pipe_busy(pset, shape, traffic_launch_ms or br_ms, steps_per_launch or p.n, sclk_mhz)
+    if pb_:
+        blk["pipes"] = pb_
+        blk["bound_primary"] = pb_["bound_primary"]
     if traffic and br_ms > 0:
         gbps = traffic / ((traffic_launch_ms or br_ms) * 1e-3) / 1e9
         blk["hbm_measured"] = {"GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
@@ -369,6 +410,50 @@ def main():
             return bool(np.array_equal(sk.decrypt_bits(mout.cpu().numpy()), want))
         return wstep, boots, desc, check
 
+    def make_wide_leg(S=16384):
+        """a level far wider than the resident set (every BASELINE config except [1], and each rank of the 8-GPU legs, is
+        one): S independent NAND gates, operands resident -- runs on k_blind_rotate_wide (one wave per ciphertext)"""
+        wrng = np.random.default_rng(7100 + rank)
+        wb = [wrng.integers(0, 2, S).astype(np.uint8) for _ in range(2)]
+        wc = [torch.from_numpy(sk.encrypt_bits(wb[k], 9700 + k, 0)).to(dev) for k in range(2)]
+        wout = torch.empty_like(wc[0])
+
+        def wstep():
+            eng.gate_batch_device(eoc.OPS["NAND"], wc[0].data_ptr(), wc[1].data_ptr(), None, wout.data_ptr(), S, stream=stream)
+
+        def check():
+            return bool(np.array_equal(sk.decrypt_bits(wout.cpu().numpy()), 1 - (wb[0] & wb[1])))
+        return wstep, S, f"{S} independent bootsNAND gates in ONE call, operands resident (Set A)", check
+
+    def noise_leg(engine, key, params, seed):
+        """VERDICT r4 task 1: measured vs predicted output noise (mean and variance of the phase error before and after
+        the key switch, 16 384 fresh encryptions) -- the quantitative anchor of the parity statement"""
+        from eoc_tfhe_amd import noise
+        cnt = 16384
+        nrng = np.random.default_rng(seed)
+        nb = [nrng.integers(0, 2, cnt) for _ in range(2)]
+        nc = [key.encrypt_bits(nb[k], 9800 + seed + k, 0) for k in range(2)]
+        t = -(nc[0].astype(np.int64) + nc[1].astype(np.int64))          # bootsNAND's linear stage: (0, 1/8) - c0 - c1
+        t[:, -1] += 1 << 29
+        d_t = torch.from_numpy((t & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(dev)
+        d_u = torch.empty((cnt, 1025), dtype=torch.int32, device=dev)
+        d_o = torch.empty((cnt, params.n + 1), dtype=torch.int32, device=dev)
+        engine.blind_rotate_device(d_t.data_ptr(), d_u.data_ptr(), cnt, stream=stream)
+        engine.keyswitch_device(d_u.data_ptr(), d_o.data_ptr(), cnt, stream=stream)
+        torch.cuda.synchronize()
+        pred = noise.predict(params, key.lwe_key, key.tlwe_key, key.ksk)
+        r = noise.compare(pred, *noise.measure(d_u.cpu().numpy(), d_o.cpu().numpy(), key.lwe_key, key.tlwe_key))
+        keep = ("count", "br_var", "br_var_pred", "br_ratio", "br_mean", "br_mean_pred", "ks_var", "ks_var_pred", "ks_ratio",
+                "ks_mean", "ks_mean_pred", "total_std", "total_std_pred", "br_ratio_textbook", "ks_ratio_textbook")
+        out = {k: (float(f"{r[k]:.4g}") if isinstance(r[k], float) else r[k]) for k in keep}
+        out["within_window"] = bool(0.8 < r["br_ratio"] < 1.25 and 0.8 < r["ks_ratio"] < 1.25 and abs(r["br_mean_z"]) < 5
+                                    and abs(r["ks_mean_z"]) < 5)
+        out["note"] = ("variance of the phase error of the blind rotation's output under the extracted key (br_*) and of what "
+                       "the key switch adds (ks_*), torus units, against the per-key CGGI prediction of eoc_tfhe_amd/noise.py; "
+                       "*_ratio_textbook = against the average-case formula with a ROUNDING decomposition / the average-over-"
+                       "keys key switch, which this algorithm is NOT (upstream truncates: 1.5x / 0.75x)")
+        return out
+
     def make_config3_block():
         """BASELINE configs[3] for THIS run's world size: the seed-4 op stream over `config3_total` gates, this rank's
         contiguous block (distributed.shard) -- exactly tests/test_gpu_baseline_configs.py's construction"""
@@ -439,6 +524,8 @@ def main():
     if single_nand and not args.no_secondary:
         for wname, inst in (("adder8", 0), ("streq32", 256), ("mixed", 32768)):
             sec_runs.append((wname,) + make_workload(wname, inst))
+        if args.pset == "A":
+            sec_runs.append(("nand16384_wide",) + make_wide_leg())
     multi_legs = []
     if dist is not None and headline_nand and not args.no_secondary:   # world > 1, or the forced one-rank RCCL smoke
         multi_legs.append(("config3_mixed_1M",) + make_config3_block())
@@ -463,11 +550,28 @@ def main():
         # the other single-GPU configurations of BASELINE.json, one timed pass each (same metric, decrypt-checked below)
         wstep()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        wstep()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        sec[wname] = {"bootstraps_per_s": round(wboots / dt, 1), "bootstraps": wboots, "workload": wdesc}
+        eng.set_profiling(True)
+        eng.kernel_times(reset=True)
+        st_w = eng.stats()
+        with ClockSampler(clk_files) as wclk:
+            t0 = time.perf_counter()
+            wstep()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        wkt = eng.kernel_times(reset=True)
+        eng.set_profiling(False)
+        st_w2 = eng.stats()
+        sec[wname] = {"bootstraps_per_s": round(wboots / dt, 1), "bootstraps": wboots, "workload": wdesc,
+                      "blind_rotate_launches": st_w2["br_launches"] - st_w["br_launches"],
+                      "of_which_wide": st_w2["br_wide_launches"] - st_w["br_wide_launches"]}
+        if wname == "nand16384_wide" and st_w2["br_wide_launches"] > st_w["br_wide_launches"]:
+            nl = st_w2["br_launches"] - st_w["br_launches"]
+            launch_ms = wkt["blind_rotate"]["ms"] / max(1, nl)
+            sec[wname]["kernels_ms"] = {"blind_rotate_total": round(wkt["blind_rotate"]["ms"], 4),
+                                        "blind_rotate_per_launch": round(launch_ms, 4),
+                                        "keyswitch": round(wkt["keyswitch"]["ms"], 4)}
+            sec[wname]["roofline"] = roofline_block(p, "A", wboots, wboots / max(1, nl), launch_ms, False,
+                                                    sclk_mhz=wclk.summary()[0], shape="wide")
 
     # pre-flight (set-up, untimed, not one of the W warm-up steps; reported as `preflight_steps`): the key images just
     # built/received are exercised so that a bad broadcast or key load fails here, before anything is measured -- and
@@ -481,6 +585,7 @@ def main():
     torch.cuda.synchronize()
     eng.set_profiling(True)
     eng.kernel_times(reset=True)
+    wide_launches_before_timed = eng.stats()["br_wide_launches"]
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -495,6 +600,7 @@ def main():
         elapsed = time.perf_counter() - t0
     kt = eng.kernel_times(reset=True)
     eng.set_profiling(False)
+    wide_headline = eng.stats()["br_wide_launches"] > wide_launches_before_timed
 
     # the same K steps through the host-buffer call (PCIe inclusive: SURVEY.md 8(d)'s wording of the metric, round 3's
     # `value`), its asynchronous two-deep form, and the host-buffer call on ordinary pageable arrays
@@ -553,14 +659,22 @@ def main():
         eb.set_profiling(True)
         eb.kernel_times(reset=True)
         lb0 = int(eoc.lib().eoc_engine_blind_rotate_launches(eb.h))
-        tb0 = time.perf_counter()
-        for _ in range(args.steps):
-            stepb()
-        torch.cuda.synchronize()
-        tb = time.perf_counter() - tb0
+        with ClockSampler(clk_files) as clkb:
+            tb0 = time.perf_counter()
+            for _ in range(args.steps):
+                stepb()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb0
+        setb_clk = clkb.summary()[0]
         ktb = eb.kernel_times(reset=True)
         eb.set_profiling(False)
         setb_res = (tb, ktb, int(eoc.lib().eoc_engine_blind_rotate_launches(eb.h)) - lb0)
+
+    noise_res = None
+    if single_nand and not args.no_secondary and rank == 0:
+        noise_res = {f"set{args.pset}": noise_leg(eng, sk, p, 1)}
+        if setb:
+            noise_res["setB"] = noise_leg(setb["eng"], setb["sk"], setb["p"], 2)
 
     # N > 1: BASELINE configs[3] and [4], the two configurations that ARE multi-GPU, cut into this run's blocks.
     # One warm pass, one timed pass between barriers; the run lasts as long as its slowest rank.
@@ -650,7 +764,8 @@ def main():
                        "key_broadcast_s": round(t_bcast, 4)},
             "decrypt_ok": decrypt_ok,
             "kernels_ms": {"prepare": round(pr_ms, 4), "blind_rotate": round(br_ms, 4), "keyswitch": round(ks_ms, 4)},
-            "roofline": roofline_block(p, args.pset, G, jobs_per_launch, br_ms, args.workload == "nand"),
+            "roofline": roofline_block(p, args.pset, G, jobs_per_launch, br_ms, args.workload == "nand",
+                                       sclk_mhz=clk.summary()[0], shape="wide" if wide_headline else "pair"),
             "clock": {"sclk_mhz_under_load": clk.summary()[0], "sclk_mhz_max_seen": clk.summary()[1],
                       "samples": clk.summary()[2], "matched_by_pci_address": clk_matched,
                       "source": "sysfs hwmon freq1_input of this process's GPU, sampled every 4 ms during the timed "
@@ -669,7 +784,8 @@ def main():
             brb_ms = brb["ms"] / max(1, nlaunch_b)            # a Set B blind rotation runs as two launches
             bb0, bb1 = setb["bits"]
             okb = bool(np.array_equal(setb["sk"].decrypt_bits(setb["d"][2].cpu().numpy()), 1 - (bb0 & bb1)))
-            rb = roofline_block(pb, "B", G, G, per_batch_ms, True, traffic_launch_ms=brb_ms)
+            rb = roofline_block(pb, "B", G, G, per_batch_ms, True, traffic_launch_ms=brb_ms, sclk_mhz=setb_clk,
+                                steps_per_launch=pb.n * args.steps / max(1, nlaunch_b))
             rb["launches_per_blind_rotation"] = round(nlaunch_b / args.steps, 2)
             rb["avg_single_launch_ms"] = round(brb_ms, 4)
             sec["nand1024_setB"] = {
@@ -682,6 +798,8 @@ def main():
                 "workload": f"{G} independent bootsNAND gates per step on the parameter set the reference's keygen selects "
                             f"(minimum_lambda = 128, eoc-tfhe-run.cpp:34,230), operands resident, {args.steps} timed steps"}
         sec.update(multi)
+        if noise_res:
+            sec["noise_measured_vs_predicted"] = noise_res
         if in_library is not None:
             sec["in_library_all_devices"] = in_library
         if sec:
