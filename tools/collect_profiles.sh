@@ -22,7 +22,14 @@ echo "pmc A done"
 bash tools/pmc_passes.sh "$O/pmcB" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --pset B > "$O/pmcB_passes.log" 2>&1
 cp "$O/pmcB/summary.txt" "$O/pmc_summary_B.txt"
 echo "pmc B done"
-python3 tools/traffic_json.py "$O/pmc_summary.txt" "$O/pmc_summary_B.txt" > "$O/traffic.json"
+# the one-wave-per-ciphertext kernel (levels wider than the pair kernel's resident set): 16 384 gates per step
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_wide" -- python3 bench.py --gpus 1 --steps 5 --warmup 2 --gates 16384 --no-cpu-baseline --no-secondary > "$O/bench_wide_under_rocprof.json" 2> "$O/trace_wide.err"
+cp "$O"/trace_wide/*/*kernel_stats.csv "$O/kernel_stats_wide.csv"
+echo "trace wide done"
+bash tools/pmc_passes.sh "$O/pmcW" --steps 2 --warmup 1 --gates 16384 --no-cpu-baseline --no-secondary > "$O/pmcW_passes.log" 2>&1
+cp "$O/pmcW/summary.txt" "$O/pmc_summary_wide.txt"
+echo "pmc wide done"
+python3 tools/traffic_json.py "$O/pmc_summary.txt" "$O/pmc_summary_B.txt" "$O/pmc_summary_wide.txt" > "$O/traffic.json"
 (rocm-smi --showclocks --showpower --showmaxpower 2>/dev/null || true) > "$O/rocm_smi.txt"
 head -5 "$O/kernel_stats.csv"
 cat "$O/bench_A.json"

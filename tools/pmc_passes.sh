@@ -15,5 +15,6 @@ run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CO
 run sq3 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VMEM_WR
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_REQ_sum
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt"
 cat "$OUT/summary.txt"
