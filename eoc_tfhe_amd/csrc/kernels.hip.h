@@ -528,8 +528,22 @@ __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ de
     bara[(size_t)(d.job_base + y) * bara_stride + m] = (uint16_t)(((t + (1u << 20)) >> 21) & 2047u);
 }
 
+// Ordering between prepare_row's vector stores and the scalar loads that read the row back (same workgroup, hence same
+// CU and same XCD).  The vector L1 is write-through: a store is complete -- vmcnt decremented -- when this XCD's L2 has
+// it; the scalar cache fills from that same L2 and is emptied by s_dcache_inv behind the barrier.  So: compiler-level
+// release fence, an explicit s_waitcnt vmcnt(0) (a workgroup-scope fence alone emits none outside threadgroup-split mode:
+// it assumes the reader shares the vector L1, which a scalar load does not), the workgroup barrier, s_dcache_inv.  An
+// agent-scope release would also be correct but emits buffer_wbl2 -- an L2 write-back per workgroup -- for a reader that
+// sits behind the same L2 (measured: +18 us per 1024-job launch, more than the folded launch saves).
+__device__ __forceinline__ void eoc_row_stores_to_l2()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // the same for ONE job inside the blind rotation (levels without MUX): thread `t` of `nt` writes entries t, t + nt, ... of
-// the job's row; the caller orders the stores before its scalar loads of the row (release fence + barrier + s_dcache_inv)
+// the job's row; the caller orders the stores before its scalar loads of the row (eoc_row_stores_to_l2 + barrier +
+// s_dcache_inv)
 __device__ __forceinline__ void prepare_row(const GateDesc &d, uint32_t inst, int n, uint16_t *row, int t, int nt)
 {
     int cst8, s0, s1;
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     if (A.prep && A.step_begin == 0) { // folded k_prepare: this workgroup's row of rotation amounts
         const uint32_t gjob = A.job0 + job, g = gjob / A.ks_S;
         prepare_row(A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, tid, 128);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the row is read back through the scalar cache
+        eoc_row_stores_to_l2();
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
     }
@@ -1052,7 +1066,7 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
     if (A.prep && A.step_begin == 0 && job < A.njobs) { // folded k_prepare: this wave's row of rotation amounts
         const uint32_t gjob = A.job0 + job, g = gjob / A.ks_S;
         prepare_row(A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, lane, 64);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the row is read back through the scalar cache
+        eoc_row_stores_to_l2();
     }
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();

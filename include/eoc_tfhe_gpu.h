@@ -223,6 +223,16 @@ int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_
 /* building blocks exposed for parity tests and profiling (device pointers, async) */
 int eoc_dbg_fft_fwd_device(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count,
                            void *hip_stream);
+/* CONVERSION CONTRACT of the inverse transform -- here and inside every blind rotation (tLweFromFFTConvert /
+ * TorusPolynomial_fft): each value v is converted as Torus32(int64(v)), truncation toward zero then
+ * wrap mod 2^32, FOR |v| < 2^51.  The device uses two exact operations (trunc, then + 1.5 * 2^52 and the low dword),
+ * which equal the int64 conversion on that range only; for 2^51 <= |v| < 2^52 the result is the two-operation form's
+ * (defined, pinned by tests/test_gpu_parity.py::test_conversion_contract_pinned_around_2_pow_51), not int64's.
+ * Reach: an external-product coefficient is bounded by l * Bg * 2^41 -- below 2^51, i.e. the contract holds
+ * UNCONDITIONALLY, iff l * Bg < 1024 (Set B: 384; every shape with l * Bg that small).  Set A (l * Bg = 2048) has the
+ * exact bound 2^52; |v| >= 2^51 there needs all 4096 digit x key products aligned and has probability <= 2 e^-512 per
+ * coefficient for any digit vector (Hoeffding on the independent uniform mask coefficients); real
+ * bootstraps stay near 2^45. */
 int eoc_dbg_fft_inv_device(eoc_engine *e, const double *d_specs, int32_t *d_polys, size_t count,
                            void *hip_stream);
 /* t[count][n+1] -> u[count][N+1]  (tfhe_blindRotateAndExtract_FFT, mu = 1/8) */

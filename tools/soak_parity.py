@@ -50,7 +50,10 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
             if time.time() >= t_end:
                 break
             kind = kinds[cases % len(kinds)] if round_robin else str(rng.choice(list(kinds)))
-            count = int(rng.choice([1, 2, 63, 64, 65, 127, 1023, 1024, 1025, int(rng.integers(1, 2600))]))
+            # widths around every launch-shape seam: the pair kernel's resident set (1024), the wide kernel's (2048), a full
+            # wide launch + a pair-kernel remainder (2049 ... 3072), + a wide remainder (3073 ...)
+            count = int(rng.choice([1, 2, 63, 64, 65, 127, 1023, 1024, 1025, 2047, 2048, 2049, 3073, int(rng.integers(1, 2600)),
+                                    int(rng.integers(2600, 5200))]))
             c = [sk.encrypt_bits(rng.integers(0, 2, count).astype(np.uint8), int(rng.integers(1, 1 << 30)), 0) for _ in range(3)]
             if kind == "circuit":
                 S = int(rng.choice([1, 3, 17, 64, 130]))
