@@ -548,10 +548,11 @@ __device__ __forceinline__ void prepare_row(const GateDesc &d, uint32_t inst, in
 {
     int cst8, s0, s1;
     gate_lin(d.op, cst8, s0, s1);
-    const size_t base = (size_t)inst * (n + 1);
+    typedef const __attribute__((address_space(1))) int32_t *gi32p; // operand rows are global memory (device or mapped host)
+    const gi32p a = (gi32p)(uintptr_t)(d.in0 + (size_t)inst * (n + 1)), b = (gi32p)(uintptr_t)(d.in1 + (size_t)inst * (n + 1));
     for (int m = t; m <= n; m += nt) {
-        uint32_t v = (uint32_t)s0 * (uint32_t)d.in0[base + m];
-        if (s1) v += (uint32_t)s1 * (uint32_t)d.in1[base + m];
+        uint32_t v = (uint32_t)s0 * (uint32_t)a[m];
+        if (s1) v += (uint32_t)s1 * (uint32_t)b[m];
         if (m == n) v += (uint32_t)cst8 << 29;
         row[m] = (uint16_t)(((v + (1u << 20)) >> 21) & 2047u);
     }
@@ -694,10 +695,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     // the rotation amounts of this job are wave-uniform and constant during the kernel: read as dwords through the
     // constant address space (rows are 16-byte aligned: bara_stride is a multiple of 8), i.e. by scalar loads
     typedef const __attribute__((address_space(4))) uint32_t *cu32p;
-    const cu32p bara32 = (cu32p)(uintptr_t)(A.bara + (size_t)job * A.bara_stride);
-    auto load_abar = [&](int idx) __attribute__((always_inline)) {
-        return (int)((bara32[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu);
-    };
+    unsigned long long bara_addr = (unsigned long long)(uintptr_t)(A.bara + (size_t)job * A.bara_stride);
 
     load_tables(s_tw, s_twist, g_tw, g_twist, tid, 128);
     if (A.prep && A.step_begin == 0) { // folded k_prepare: this workgroup's row of rotation amounts
@@ -707,6 +705,14 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
     }
+    // loads through the constant address space may be moved freely by the compiler (the memory is assumed invariant): the
+    // row's address is made opaque HERE, behind the prologue that may just have written the row, so that no load of it can
+    // be scheduled above this point
+    asm volatile("" : "+s"(bara_addr));
+    const cu32p bara32 = (cu32p)bara_addr;
+    auto load_abar = [&](int idx) __attribute__((always_inline)) {
+        return (int)((bara32[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu);
+    };
 
     // ACC = (0, X^(2N - barb) * testvect), testvect = (mu, ..., mu)
     uint32_t racc[16]; // register copy of ACC_h: coefficient lane + 64 r in racc[r] (r < 8), lane + 64 r + 512 in racc[8 + r]
@@ -1073,7 +1079,9 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
     if (job >= A.njobs) return; // the idle wave of an odd last workgroup (the only barrier is behind it)
 
     typedef const __attribute__((address_space(4))) uint32_t *cu32p;
-    const cu32p bara32 = (cu32p)(uintptr_t)(A.bara + (size_t)job * A.bara_stride);
+    unsigned long long bara_addr = (unsigned long long)(uintptr_t)(A.bara + (size_t)job * A.bara_stride);
+    asm volatile("" : "+s"(bara_addr)); // opaque behind the prologue: see k_blind_rotate
+    const cu32p bara32 = (cu32p)bara_addr;
     auto load_abar = [&](int idx) __attribute__((always_inline)) {
         return (int)((bara32[idx >> 1] >> ((idx & 1) * 16)) & 0xffffu);
     };

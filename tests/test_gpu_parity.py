@@ -522,3 +522,25 @@ def test_descriptor_ring_wraps_without_a_device_synchronise(eoc, rig_small):
     want = [r.orc.gate_batch(ol.OPS[n], c0, c1) for n in ("NAND", "XOR", "OR")]
     for k in list(range(0, 1300, 97)) + list(range(1015, 1035)) + [1299]:
         assert np.array_equal(got[k], want[k % 3]), k
+
+
+@pytest.mark.parametrize("cnt", [700, 1500, 2300])
+def test_in_place_batches_with_the_folded_prologue(eoc, rig_a, cnt):
+    """out aliases an operand (d_out == d_in0, then d_out == d_in1).  Since round 5 the blind rotation's own prologue reads
+    the operand rows (k_prepare folded away) while other workgroups' epilogues already write output rows: a job reads only
+    ITS rows, before its own epilogue writes them, so exact aliasing stays safe -- on the pair kernel (700), the wide kernel
+    (1 500) and a level cut into a wide launch plus a pair-kernel remainder (2 300)."""
+    torch = torch_cuda()
+    r = rig_a
+    b0, c0 = _rand_cts(r, cnt, 31)
+    b1, c1 = _rand_cts(r, cnt, 32)
+    want = r.gate(eoc.OPS["XOR"], c0, c1)                        # out of place
+    pick = np.random.default_rng(cnt).choice(cnt, 40, replace=False)
+    assert np.array_equal(want[pick], r.orc.gate_batch(ol.OPS["XOR"], c0[pick], c1[pick]))
+    for alias in (0, 1):
+        d0, d1 = to_dev(c0), to_dev(c1)
+        out = d0 if alias == 0 else d1
+        r.eng.gate_batch_device(eoc.OPS["XOR"], d0.data_ptr(), d1.data_ptr(), None, out.data_ptr(), cnt)
+        sync()
+        assert np.array_equal(out.cpu().numpy(), want), alias
+    assert np.array_equal(r.sk.decrypt_bits(want), b0 ^ b1)
