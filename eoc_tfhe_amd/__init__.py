@@ -153,6 +153,7 @@ def lib():
         "eoc_engine_workspace_grows": (u64, [vp]),
         "eoc_engine_blind_rotate_launches": (u64, [vp]),
         "eoc_engine_blind_rotate_wide_launches": (u64, [vp]),
+        "eoc_engine_resident_jobs": (C.c_size_t, [vp]),
         "eoc_engine_device": (C.c_int, [vp]),
         "eoc_engine_params": (PP, [vp]),
         "eoc_engine_adopt_cloud_key_device": (C.c_int, [vp, vp, vp]),

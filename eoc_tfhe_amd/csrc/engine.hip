@@ -1138,5 +1138,11 @@ extern "C" int eoc_engine_stats(eoc_engine *e, uint64_t out[3])
 extern "C" uint64_t eoc_engine_workspace_grows(eoc_engine *e) { return e ? e->ws_grows : 0; }
 extern "C" uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e) { return e ? e->br_launches : 0; }
 extern "C" uint64_t eoc_engine_blind_rotate_wide_launches(eoc_engine *e) { return e ? e->br_wide_launches : 0; }
+extern "C" size_t eoc_engine_resident_jobs(eoc_engine *e)
+{
+    if (!e) return 0;
+    const bool wide = e->p.l == 2 && e->br_wide != 0;
+    return (size_t)(wide ? 8 : 4) * (size_t)e->num_cus;
+}
 extern "C" int eoc_engine_device(eoc_engine *e) { return e ? e->device : -1; }
 extern "C" const eoc_params *eoc_engine_params(eoc_engine *e) { return e ? &e->p : nullptr; }

@@ -226,13 +226,14 @@ int slot_gate_block(Slot &s, int op, const uint8_t *ops, const int32_t *in0, con
     }
     int32_t *out_map = static_cast<int32_t *>(mapped_address(out));
     all_pinned &= out_map != nullptr;
-    // Batches wider than one resident set, from pinned buffers: chunks of 1024 gates (one single-round blind-rotate
-    // launch each).  ALL kernels stay on one stream (kernels of different streams do not overlap on this device and
+    // Batches wider than one resident set, from pinned buffers: chunks of one resident set (1024 gates on the pair kernel,
+    // 2048 where the one-wave-per-ciphertext kernel applies: one single-round blind-rotate launch each).  ALL kernels stay on one stream (kernels of different streams do not overlap on this device and
     // would only interleave their launches); the copy engines run beside them on two copy streams: every chunk's
     // operands are DMA'd ahead, and a chunk's result leaves while the next chunk computes.  Exposed: the first chunk's
     // H2D and the last chunk's D2H, 6 MB in all, whatever the batch size.
     size_t nchunks = 1;
-    if (all_pinned && count > 1024) nchunks = (count + 1023) / 1024;
+    const size_t chunk = std::max<size_t>(1024, eoc_engine_resident_jobs(s.e));
+    if (all_pinned && count > chunk) nchunks = (count + chunk - 1) / chunk;
     if (const char *c = getenv("EOC_TFHE_HOST_CHUNKS")) nchunks = std::min<size_t>(std::max(1, atoi(c)), count);
     if (nchunks > 1) {
         const size_t row_bytes = stride_ints * 4;

@@ -185,6 +185,10 @@ uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e);
 /* ... of which launches of the one-wave-per-ciphertext kernel (k_blind_rotate_wide: gadget length 2, levels of at least
  * 6 blind rotations per compute unit -- 1 536 on MI355X; bit-identical to the pair kernel, tests/test_gpu_parity.py) */
 uint64_t eoc_engine_blind_rotate_wide_launches(eoc_engine *e);
+/* blind rotations that fill the device in ONE launch: 8 x compute units where the one-wave-per-ciphertext kernel applies
+ * (gadget length 2), 4 x otherwise.  A host that cuts a long job into pieces should cut at multiples of this (the
+ * host-buffer batch path does). */
+size_t eoc_engine_resident_jobs(eoc_engine *e);
 int eoc_engine_device(eoc_engine *e);
 const eoc_params *eoc_engine_params(eoc_engine *e);
 /*

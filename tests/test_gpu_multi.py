@@ -183,7 +183,8 @@ def test_concurrent_host_threads_are_serialised(eoc, ctx3):
 def test_chunked_host_pipeline(eoc, monkeypatch):
     """the chunked host pipeline (nchunks > 1: operand DMA on the H2D stream, all kernels on one stream,
     results leaving on the D2H stream, 2 x nchunks events) compared with the oracle row for row:
-    2500 pinned rows on ONE engine (3 chunks by size), then EOC_TFHE_HOST_CHUNKS=3 forced on pageable operands and on
+    5000 pinned rows on ONE engine (3 chunks by size: a chunk is the engine's resident set, 2048 rows where the
+    one-wave-per-ciphertext kernel applies), then EOC_TFHE_HOST_CHUNKS=3 forced on pageable operands and on
     a mixed batch in arbitrary opcode order (MUX included, so the third operand travels too)."""
     p = eoc.default_params(0)
     p.n = 40
@@ -193,7 +194,8 @@ def test_chunked_host_pipeline(eoc, monkeypatch):
     eoc.gpu_init(p, devices=[0])
     eoc.upload_cloud_key(sk)
     try:
-        total = 2500
+        total = 5000
+        assert eoc.lib().eoc_engine_resident_jobs(eoc.lib().eoc_global_engine_at(0)) in (1024, 2048)
         rng = np.random.default_rng(15)
         bits = [rng.integers(0, 2, total).astype(np.uint8) for _ in range(3)]
         cts = [sk.encrypt_bits(bits[k], 40 + k, 0) for k in range(3)]
