@@ -191,7 +191,7 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
     if with_traffic and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(f"blind_rotate_{pset}_{G}")
+            traffic = tj.get(f"blind_rotate_{pset}_wide_2048" if shape == "wide" else f"blind_rotate_{pset}_{G}")
             tsrc = f"profiles/traffic.json ({tj.get('collected', 'stored rocprofv3 PMC figure')}; not measured in this run)"
         except Exception:
             traffic = None
@@ -223,7 +223,7 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
     cb = None
     if with_traffic and os.path.exists(tpath):
         try:
-            cb = json.load(open(tpath)).get(f"cobounds_{pset}")
+            cb = json.load(open(tpath)).get(f"cobounds_{pset}_wide" if shape == "wide" else f"cobounds_{pset}")
         except Exception:
             cb = None
     if cb:
@@ -574,7 +574,7 @@ def main():
             sec[wname]["kernels_ms"] = {"blind_rotate_total": round(wkt["blind_rotate"]["ms"], 4),
                                         "blind_rotate_per_launch": round(launch_ms, 4),
                                         "keyswitch": round(wkt["keyswitch"]["ms"], 4)}
-            sec[wname]["roofline"] = roofline_block(p, "A", wboots, wboots / max(1, nl), launch_ms, False,
+            sec[wname]["roofline"] = roofline_block(p, "A", wboots, wboots / max(1, nl), launch_ms, True,
                                                     sclk_mhz=wclk.summary()[0], shape="wide")
 
     # pre-flight (set-up, untimed, not one of the W warm-up steps; reported as `preflight_steps`): the key images just
