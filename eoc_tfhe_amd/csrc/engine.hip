@@ -573,6 +573,7 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
     const bool force_wide = can_wide && e->br_wide > 0;
     struct Seg { uint32_t off, njobs; bool wide; };
     std::vector<Seg> segs;
+    segs.reserve(njobs_total / resident_pair + 2);
     const int auto_parts = e->kpl * 2 * kNH * 16 > 80 * 1024 ? 2 : 1;
     const int parts = std::max(1, std::min(e->br_parts > 0 ? e->br_parts : auto_parts, e->p.n));
     {

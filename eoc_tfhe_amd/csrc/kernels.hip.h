@@ -534,7 +534,11 @@ __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ de
 // release fence, an explicit s_waitcnt vmcnt(0) (a workgroup-scope fence alone emits none outside threadgroup-split mode:
 // it assumes the reader shares the vector L1, which a scalar load does not), the workgroup barrier, s_dcache_inv.  An
 // agent-scope release would also be correct but emits buffer_wbl2 -- an L2 write-back per workgroup -- for a reader that
-// sits behind the same L2 (measured: +18 us per 1024-job launch, more than the folded launch saves).
+// sits behind the same L2 (measured: +18 us per 1024-job launch, more than the folded launch saves).  Reading the row back
+// with VECTOR loads (+ v_readfirstlane) instead would stay inside the formal memory model (workgroup-scope release /
+// acquire through the shared vector L1) and was measured too: +0.3 % (Set A), +0.6 % (Set B) on the kernel -- as much as
+// the fold gains -- so the scalar path stays; EOC_TFHE_NO_FOLD=1 restores the separate k_prepare launch (a kernel
+// boundary orders everything) should a platform ever behave differently.
 __device__ __forceinline__ void eoc_row_stores_to_l2()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -549,7 +553,8 @@ __device__ __forceinline__ void prepare_row(const GateDesc &d, uint32_t inst, in
     int cst8, s0, s1;
     gate_lin(d.op, cst8, s0, s1);
     typedef const __attribute__((address_space(1))) int32_t *gi32p; // operand rows are global memory (device or mapped host)
-    const gi32p a = (gi32p)(uintptr_t)(d.in0 + (size_t)inst * (n + 1)), b = (gi32p)(uintptr_t)(d.in1 + (size_t)inst * (n + 1));
+    const gi32p a = (gi32p)(uintptr_t)(d.in0 + (size_t)inst * (n + 1));
+    const gi32p b = s1 ? (gi32p)(uintptr_t)(d.in1 + (size_t)inst * (n + 1)) : a; // one-operand forms carry no second row
     for (int m = t; m <= n; m += nt) {
         uint32_t v = (uint32_t)s0 * (uint32_t)a[m];
         if (s1) v += (uint32_t)s1 * (uint32_t)b[m];
