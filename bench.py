@@ -114,6 +114,11 @@ class ClockSampler:
     def __init__(self, files):
         import threading
         self.files, self.samples, self.stop = files, [], False
+        # package power next to the clock (same hwmon directory): the kernels run at the board's power cap
+        self.pfiles = [g for f in files for g in (f.replace("freq1_input", "power1_input"), f.replace("freq1_input", "power1_average"))
+                       if os.path.exists(g)][:1] if len(files) == 1 else []
+        self.cfiles = [f.replace("freq1_input", "power1_cap") for f in files] if len(files) == 1 else []
+        self.power = []
         self.th = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
@@ -121,7 +126,14 @@ class ClockSampler:
             v = read_mhz(self.files)
             if v:
                 self.samples.append(max(v))
+            pw = read_mhz(self.pfiles)          # microwatts // 10^6 = watts
+            if pw:
+                self.power.append(pw[0])
             time.sleep(0.004)
+
+    def power_summary(self):
+        cap = read_mhz([f for f in self.cfiles if os.path.exists(f)])
+        return (max(self.power) if self.power else None), (cap[0] if cap else None)
 
     def __enter__(self):
         if self.files:
@@ -606,6 +618,35 @@ def main():
     eng.set_profiling(False)
     wide_headline = eng.stats()["br_wide_launches"] > wide_launches_before_timed
 
+    # the same step captured once into a hipGraph and replayed K times (the engine is capturable once its workspace has its
+    # size): what is left of the launch path is one graph launch per step.  Reported beside `value`, never as it.
+    graph_res = None
+    if single_nand and not args.no_secondary and world == 1:
+        try:
+            eager_out = dout.clone()
+            gst = torch.cuda.Stream()
+            gst.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=gst):
+                eng.gate_batch_device(op, d0.data_ptr(), d1.data_ptr(), None, dout.data_ptr(), G, stream=gst.cuda_stream)
+            torch.cuda.current_stream().wait_stream(gst)
+            dout.zero_()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg0
+            graph_res = {"gates_per_s": round(G * args.steps / tg, 1), "ms_per_step": round(tg / args.steps * 1e3, 4),
+                         "bit_identical_to_eager": bool(torch.equal(dout, eager_out)),
+                         "note": "one captured eoc_gate_batch_device call (descriptor copy + blind rotation + key switch) "
+                                 "replayed per step: the launch path is one hipGraphLaunch"}
+            del graph
+        except Exception as e:  # noqa: BLE001 -- a capture problem must not cost the line
+            graph_res = {"error": repr(e)[:300]}
+
     # the same K steps through the host-buffer call (PCIe inclusive: SURVEY.md 8(d)'s wording of the metric, round 3's
     # `value`), its asynchronous two-deep form, and the host-buffer call on ordinary pageable arrays
     wallclock = pageable = pipelined = None
@@ -773,6 +814,7 @@ def main():
                                        sclk_mhz=clk.summary()[0], shape="wide" if wide_headline else "pair"),
             "clock": {"sclk_mhz_under_load": clk.summary()[0], "sclk_mhz_max_seen": clk.summary()[1],
                       "samples": clk.summary()[2], "matched_by_pci_address": clk_matched,
+                      "package_power_w_max_seen": clk.power_summary()[0], "package_power_cap_w": clk.power_summary()[1],
                       "source": "sysfs hwmon freq1_input of this process's GPU, sampled every 4 ms during the timed "
                                 "steps (median); the package sits at its power cap under this kernel (DESIGN.md 7)"},
         }
@@ -805,6 +847,8 @@ def main():
         sec.update(multi)
         if noise_res:
             sec["noise_measured_vs_predicted"] = noise_res
+        if graph_res:
+            sec["graph_replay_nand1024"] = graph_res
         if in_library is not None:
             sec["in_library_all_devices"] = in_library
         if sec:
