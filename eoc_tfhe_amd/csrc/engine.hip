@@ -71,7 +71,7 @@ struct eoc_engine {
     int prio_duty_override = INT32_MIN;     // EOC_TFHE_PRIO_DUTY in the environment (tuning / diagnostics)
     int prio_multi = -1;                    // duty code of launches of several rounds (EOC_TFHE_PRIO_MULTI)
     int br_slice = 0;                       // jobs per blind-rotate launch: 0 = resident set, < 0 = unlimited (EOC_TFHE_BR_SLICE)
-    bool no_fold = false;                   // EOC_TFHE_NO_FOLD: keep k_ks_init as its own launch
+    bool no_fold = false;                   // EOC_TFHE_NO_FOLD: keep k_prepare and k_ks_init as launches of their own
     int br_parts = 0;                       // consecutive launches per blind rotation (EOC_TFHE_BR_PARTS); 0 = by key-row size
     int br_wide = -1;                       // one-wave-per-ciphertext kernel: -1 = by launch width, 0 = never, 1 = whenever l = 2 (EOC_TFHE_BR_WIDE)
     int bara_stride = 0;
