@@ -1121,8 +1121,16 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
     const double bias1 = 4503599627370496.0 + (double)halfBg, bias2 = 4503599627370496.0 + (double)Bg;
     const int prio_slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)); // HW_ID.WAVE_ID: slot on the SIMD
 
+#ifdef EOC_STAMPS
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+    st_acc[12] = st_prev;
+    st_acc[14] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+    st_acc[13] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+#endif
     int abar_next = load_abar(A.step_begin);
     for (int i = A.step_begin; i < A.step_end; i++) {
+        EOC_STAMP(15);
         if (A.prio_duty >= 0) { // see k_blind_rotate: the two waves of a SIMD alternate the issue priority
             const bool first_part = (i & 15) < A.prio_duty;
             if (first_part == ((prio_slot & 1) != 0))
@@ -1168,11 +1176,14 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
             }
             fwd_pass0_tail(x);
         };
+        EOC_STAMP(0);
         d2 xs0[2][8], xs1[2][8];
         make_x0(d0, 1, xs0[0]);
         fft_fwd_rest_x2(xs0[0], xs0[1], [&]() __attribute__((always_inline)) { make_x0(d0, 2, xs0[1]); }, s_tw, scr, lane);
+        EOC_STAMP(1);
         make_x0(d1, 1, xs1[0]);
         fft_fwd_rest_x2(xs1[0], xs1[1], [&]() __attribute__((always_inline)) { make_x0(d1, 2, xs1[1]); }, s_tw, scr, lane);
+        EOC_STAMP(2);
 
         // the two chains, bin block by bin block; row (q, p, c) of BK_i sits at ((i KPL + q L + p - 1) 2 + c) * 8 KiB
         d2 S0[8], S1[8];
@@ -1208,8 +1219,10 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
             S0[r] = a0;
             S1[r] = a1;
         }
+        EOC_STAMP(3);
         d2 ut[8];
         fft_inv_x2(S0, S1, ut, s_tw, s_twist, scr, lane);
+        EOC_STAMP(8);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const d2 y0 = cmulc(S0[r], ut[r]), y1 = cmulc(S1[r], ut[r]); // 1/512 is in the key image
@@ -1219,7 +1232,13 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
             racc1[8 + r] += wrap_trunc(y1.y);
         }
         wave_lds_fence();
+        EOC_STAMP(9);
     }
+#ifdef EOC_STAMPS
+    st_acc[11] = __builtin_amdgcn_s_memtime();
+    if (A.stamps && lane == 0)
+        for (int k = 0; k < 16; k++) A.stamps[((size_t)blockIdx.x * kBRWideJobsPerWG + h) * 16 + k] = st_acc[k];
+#endif
 
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (A.step_end < A.n) { // not the last part: park the accumulators for the next launch

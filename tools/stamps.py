@@ -20,7 +20,8 @@ eng = eoc.Engine(p)
 eng.load_cloud_key(sk)
 L = eoc.lib()
 L.eoc_dbg_stamps.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
-waves = G * 2
+WIDE = os.environ.get("EOC_TFHE_BR_WIDE") == "1" or G > 1024     # one wave per ciphertext (k_blind_rotate_wide)
+waves = G if WIDE else G * 2
 bits = np.random.default_rng(0).integers(0, 2, G)
 c0 = torch.from_numpy(sk.encrypt_bits(bits, 2, 0)).cuda()
 c1 = torch.from_numpy(sk.encrypt_bits(bits, 3, 0)).cuda()
@@ -32,9 +33,14 @@ assert L.eoc_dbg_stamps(eng.h, waves, None) == 0
 eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), None, out.data_ptr(), G)
 buf = np.zeros((waves, 16), np.uint64)
 assert L.eoc_dbg_stamps(eng.h, waves, buf.ctypes.data) == 0
+wide_names = {0: "rotation + digit words, both polynomials", 1: "forward pair, polynomial 0", 2: "forward pair, polynomial 1",
+              3: "chains (key rows streamed by bin block)", 8: "inverse pair", 9: "untwist + round + acc update",
+              15: "loop top (bara load)"}
 names = {0: "rotate-diff (acc reads)", 1: "BK loads issue + digits + twist", 2: "forward FFT", 3: "MAC (waits BK)",
          4: "xchg write", 5: "barrier A", 6: "xchg read + add", 7: "barrier B", 8: "inverse FFT",
          9: "untwist + round + acc update", 15: "loop top (bara load)"}
+if WIDE:
+    names = wide_names
 meta = buf[:, 11:15].copy()
 buf[:, 11:15] = 0
 tot = buf.sum(axis=1).astype(np.float64)
@@ -46,7 +52,7 @@ for k in sorted(names):
 # per-workgroup loop durations: a launch ends with its slowest workgroup
 dur = (meta[:, 0].astype(np.int64) - meta[:, 1].astype(np.int64)).astype(np.float64)   # exit - entry
 t0 = meta[:, 1].astype(np.int64)
-wg = dur.reshape(-1, 2).max(axis=1)
+wg = dur.reshape(-1, 2).max(axis=1)        # per workgroup (two waves: a pair, or two independent ciphertexts)
 start = (t0.reshape(-1, 2).min(axis=1) - t0.min()).astype(np.float64)
 end = start + wg
 print(f"workgroup loop duration [cycles]: min {wg.min():.0f}  mean {wg.mean():.0f}  max {wg.max():.0f}  (max/mean = {wg.max() / wg.mean():.3f})")
