@@ -1,8 +1,10 @@
 -- tfhe_gates.lua -- text to append to ao-tfhe/tfhe.lua (same pass-through style as :4-53; needs Lua 5.3 string.pack).
--- Not executed in this repository (no Lua interpreter in the image); integration/node/tfhe.js is its tested twin and has
--- the same functions with the same netlists: tests/test_binding_surfaces.py compares the two name by name (`and`, `or`,
--- `not` are Lua keywords: band / bor / bnot here) and lists the three string-level circuits only the JS side has
--- (addBits, lessThanBits, minMaxBits: they decode base64, which the Lua 5.3 standard library cannot).
+-- Never run by a Lua VM (none in the build image).  Executed by tests/lua_double/minilua.py -- an interpreter for the subset of
+-- Lua 5.3 used below -- in tests/test_lua_facade.py: every netlist builder on plaintext bits over all input pairs, the batch
+-- functions' wire packing, and facade -> binding C -> library on the GPU.  integration/node/tfhe.js is its twin with the
+-- same functions and netlists: tests/test_binding_surfaces.py compares the two name by name (`and`, `or`, `not` are Lua
+-- keywords: band / bor / bnot here) and lists the three string-level circuits only the JS side has (addBits, lessThanBits,
+-- minMaxBits: they decode base64, which the Lua 5.3 standard library cannot).
 function Tfhe.generateGateKey(lambda, seed) return Tfhe.backend.generateGateKey(lambda, seed) end
 function Tfhe.resetGateKey()                return Tfhe.backend.resetGateKey() end
 function Tfhe.deviceCount()                 return Tfhe.backend.deviceCount() end     -- GPUs the process can see

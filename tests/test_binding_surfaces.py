@@ -1,6 +1,7 @@
 """The Lua binding is compiled and executed against a test double of the Lua C API (tests/test_lua_binding.py), never
 against liblua (no Lua SDK in the image); the Node addon is built against the real N-API and GPU-tested.  This test keeps
-the two surfaces -- and the Lua facade text, which no interpreter here can run -- mechanically in step:
+the two surfaces -- and the Lua facade text (executed by tests/test_lua_facade.py through the minilua test double, never
+by a Lua VM) -- mechanically in step:
 
   * the luaL_Reg entries integration/lua/eoc-tfhe-gate-bindings.c appends to luaopen_tfhe's table
     (/root/reference/ao-tfhe/eoc-tfhe-bindings.c:128-148 holds the reference's eleven) == the Node addon's exports,

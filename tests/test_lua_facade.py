@@ -1,0 +1,319 @@
+"""The Lua FACADE text (integration/lua/tfhe_gates.lua: what a maintainer appends to ao-tfhe/tfhe.lua, SURVEY.md 8 f3/f4;
+pattern /root/reference/ao-tfhe/tfhe.lua:4-53) EXECUTED -- by tests/lua_double/minilua.py, a small interpreter for the
+subset of Lua 5.3 the file is written in, because the build image has no Lua.  This runs THIS REPOSITORY'S Lua text; it
+is not a Lua VM and proves nothing about one beyond the manual's semantics restated in minilua.py.
+
+  * the interpreter itself against hand-computed results of the language features the facade relies on;
+  * every netlist builder of the facade, evaluated gate by gate on plaintext bits over all / random inputs
+    (adder, adder with constant carry-in, equality, min / max, subtractor, multiplier) and its bootstrap count;
+  * runNetlist / planes / the *BitsBatch functions and encryptStringBits against a plaintext stand-in of the backend
+    (same call signatures and string formats as the C binding);
+  * GPU: the facade on top of the REAL binding C (through the Lua C-API double) on top of the real library:
+    generateGateKey, encryptStringBits + equalStrings, addBitsBatch, minMaxBitsBatch -- decrypted against plaintext, and one
+    circuit's bytes against the oracle.
+"""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "lua_double"))
+import minilua as ml  # noqa: E402
+
+FACADE = os.path.join(ROOT, "integration", "lua", "tfhe_gates.lua")
+OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9, MUX=10, NOT=11, COPY=12, CONST0=13,
+           CONST1=14)
+
+
+# ---- the interpreter ------------------------------------------------------------------------------------------------
+def run(src):
+    it = ml.Interpreter()
+    return [ml.to_python(v) for v in it.run(src)]
+
+
+def test_minilua_language_features_the_facade_uses():
+    assert run("return 7 // 2, -7 // 2, 7 % 3, -7 % 3, 2^10, 7 / 2, (5 >> 1) & 1, 1 << 4, 6 ~ 3, ~0") == \
+        [3, -4, 1, 2, 1024.0, 3.5, 0, 16, 5, -1]
+    assert run("local t = {10, 20, 30, x = 1, [0] = 5}; t[#t + 1] = 40; return #t, t[0], t.x, #'abc' .. 'd'") == [4, 5, 1, b"3d"]
+    assert run("local function f(...) local a, b = ...; return b, a, select('#', ...) end; return f(1, 2, 3)") == [2, 1, 3]
+    assert run("local function f() return 1, 2 end; local t = {f(), f()}; local a, b, c = f(); return #t, (f()), c") == [3, 1, None]
+    # closures over a local table (newNetlist's pattern), method-style definitions, multiple assignment
+    assert run("""
+        local function mk() local o = { n = 0 }; function o.inc(k) local w = o.n; o.n = o.n + (k or 1); return w end; return o end
+        local a, b = mk(), mk(); a.inc(3); a.inc(); b.inc()
+        local x, y = 1, 2; x, y = y, x
+        return a.n, b.n, x, y""") == [4, 1, 2, 1]
+    assert run("local s = 0; for i = 1, 9, 2 do s = s + i end; for i = 3, 1, -1 do s = s * 2 end; return s") == [200]
+    assert run("local i, n = 0, 0; while true do i = i + 1; if i > 5 then break elseif i % 2 == 0 then n = n + i end end; return n") == [6]
+    assert run("return nil and 1, false or 'x', 1 and 2, nil == false, 1 == 1.0, 'a' < 'b', not nil") == \
+        [None, b"x", 2, False, True, True, True]
+    assert run("return string.pack('<i4i4', 1, -1), ('abc'):sub(2), ('hello'):sub(2, 3), ('AB'):byte(2), string.char(72, 105), "
+               "string.rep('\\0', 3), table.concat({'a', 'b', 3}, ',')") == \
+        [struct.pack("<ii", 1, -1), b"bc", b"el", 66, b"Hi", b"\0\0\0", b"a,b,3"]
+    assert run("local t = {}; for k, v in pairs({a = 1, b = 2}) do t[#t + 1] = k end; local s = 0; for _, v in ipairs({4, 5}) do s = s + v end; return #t, s") == [2, 9]
+    with pytest.raises(ml.LuaError, match="arithmetic"):
+        run("return {} + 1")
+    with pytest.raises(ml.LuaError, match="index a nil"):
+        run("local t; return t.x")
+    with pytest.raises(ml.LuaError):
+        run("goto done")                        # outside the subset: refused, not guessed
+
+
+# ---- the facade on a plaintext stand-in of the backend ---------------------------------------------------------------
+ROW = 3                                            # ints per "sample" of the stand-in: the last one carries the bit
+
+
+def gate_eval(op, a, b, c):
+    if op == OPS["NAND"]: return 1 - (a & b)
+    if op == OPS["AND"]: return a & b
+    if op == OPS["OR"]: return a | b
+    if op == OPS["NOR"]: return 1 - (a | b)
+    if op == OPS["XOR"]: return a ^ b
+    if op == OPS["XNOR"]: return 1 - (a ^ b)
+    if op == OPS["ANDNY"]: return (1 - a) & b
+    if op == OPS["ANDYN"]: return a & (1 - b)
+    if op == OPS["ORNY"]: return (1 - a) | b
+    if op == OPS["ORYN"]: return a | (1 - b)
+    if op == OPS["MUX"]: return np.where(a == 1, b, c)
+    if op == OPS["NOT"]: return 1 - a
+    if op == OPS["COPY"]: return a
+    if op == OPS["CONST0"]: return np.zeros_like(a)
+    return np.ones_like(a)
+
+
+def run_packed(packed, bits):
+    """bits [nWires][instances]; evaluates the packed netlist (5 int32 per gate) in order, in place"""
+    g = np.frombuffer(packed, "<i4").reshape(-1, 5)
+    z = np.zeros_like(bits[0])
+    for op, i0, i1, i2, out in g:
+        bits[out] = gate_eval(op, bits[i0] if i0 >= 0 else z, bits[i1] if i1 >= 0 else z, bits[i2] if i2 >= 0 else z)
+    return len(g), int(sum(2 if op == OPS["MUX"] else (0 if op >= OPS["NOT"] else 1) for op, *_ in g))
+
+
+class PlainBackend:
+    """same signatures and string formats as the C binding's l_* entries, on plaintext 'samples'"""
+
+    def __init__(self):
+        self.calls = []
+
+    def table(self):
+        def circuit_run(gates, wires, n_wires, instances):
+            self.calls.append(("circuitRun", len(gates) // 20, n_wires, instances))
+            if len(wires) != n_wires * instances * ROW * 4:
+                return None
+            w = np.frombuffer(wires, "<i4").reshape(n_wires, instances, ROW).copy()
+            bits = w[:, :, -1].copy()
+            run_packed(gates, bits)
+            w[:, :, -1] = bits
+            return w.tobytes()
+
+        def encrypt_bits(bits):
+            self.calls.append(("encryptBits", bits))
+            out = np.zeros((len(bits), ROW), "<i4")
+            out[:, -1] = np.frombuffer(bits, np.uint8)
+            return out.tobytes()
+        return ml.table_from({"sampleInts": lambda: ROW, "circuitRun": circuit_run, "encryptBits": encrypt_bits,
+                              "gateNAND": lambda a, b, pk=None: b"NAND(" + a + b"," + b + b")",
+                              "setDevices": lambda *d: len(d)})
+
+
+@pytest.fixture()
+def facade():
+    it = ml.Interpreter()
+    be = PlainBackend()
+    tf = ml.LuaTable()
+    tf.set(b"backend", be.table())
+    it.set_global("Tfhe", tf)                       # ao-tfhe/tfhe.lua:1-3 creates this table; the text below is appended to it
+    it.run(open(FACADE, "rb").read(), "tfhe_gates.lua")
+    return it, tf, be
+
+
+def call(it, tf, name, *args):
+    return it.call(tf.get(name.encode()), list(args))
+
+
+def planes_of(values, nbits, instances):
+    """LSB-first bit planes [nbits][instances][ROW] as the facade's operand strings"""
+    w = np.zeros((nbits, instances, ROW), "<i4")
+    for i in range(nbits):
+        w[i, :, -1] = (values >> i) & 1
+    return w.tobytes()
+
+
+def value_of(buf, instances):
+    w = np.frombuffer(buf, "<i4").reshape(-1, instances, ROW)[:, :, -1]
+    return sum(w[i].astype(np.int64) << i for i in range(w.shape[0]))
+
+
+def test_facade_defines_its_functions_and_passes_through(facade):
+    it, tf, be = facade
+    for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
+                 "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
+                 "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
+        assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
+    assert call(it, tf, "nand", b"x", b"y") == [b"NAND(x,y)"]
+    assert call(it, tf, "setDevices", 0, 1, 2) == [3]                          # varargs travel
+    assert ml.to_python(tf.get(b"OP"))[b"MUX"] == 10
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 3, 5])
+def test_netlist_builders_on_plaintext(facade, nbits):
+    it, tf, be = facade
+    vals = np.arange(1 << nbits)
+    A, B = [x.ravel() for x in np.meshgrid(vals, vals)]                           # every input pair
+    S = len(A)
+
+    def evaluate(nl, a, b):
+        packed = it.call(nl.get(b"packed"), [])[0]
+        bits = np.zeros((nl.get(b"nWires"), S), np.int64)
+        for i in range(nbits):
+            bits[a + i], bits[b + i] = (A >> i) & 1, (B >> i) & 1
+        return bits, run_packed(packed, bits)
+
+    def word(bits, wires):
+        return sum(bits[w] << i for i, w in enumerate(wires))
+
+    nl, a, b, s = call(it, tf, "adderNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(word(bits, ml.to_python(s)), A + B) and boots == max(2, 5 * nbits - 3)
+    nl, a, b, s = call(it, tf, "adderNetlist", nbits, True)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(word(bits, ml.to_python(s)), A + B) and boots == 5 * nbits    # BASELINE.md's 5 gates per bit
+    nl, x, y, out = call(it, tf, "equalNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, x, y)
+    assert np.array_equal(bits[out], (A == B).astype(np.int64)) and boots == 2 * nbits - 1
+    nl, a, b, lt, mn, mx = call(it, tf, "minMaxNetlist", nbits)
+    bits, _ = evaluate(nl, a, b)
+    assert np.array_equal(bits[lt], (A < B).astype(np.int64))
+    assert np.array_equal(word(bits, ml.to_python(mn)), np.minimum(A, B))
+    assert np.array_equal(word(bits, ml.to_python(mx)), np.maximum(A, B))
+    nl, a, b, diff, br = call(it, tf, "subtractorNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(word(bits, ml.to_python(diff)), (A - B) % (1 << nbits)) and np.array_equal(bits[br], (A < B).astype(np.int64))
+    assert boots == 2 + 4 * (nbits - 1)
+    nl, a, b, prod = call(it, tf, "multiplierNetlist", nbits)
+    bits, _ = evaluate(nl, a, b)
+    prod = ml.to_python(prod)
+    assert len(prod) == 2 * nbits and np.array_equal(word(bits, prod), A * B)
+
+
+def test_eight_bit_netlists_match_the_python_circuit_layer(facade):
+    """the facade's netlists compute what eoc_tfhe_amd/circuits.py's compute, with the same bootstrap counts"""
+    import eoc_tfhe_amd as eoc
+    from eoc_tfhe_amd import circuits
+    it, tf, be = facade
+    rng = np.random.default_rng(4)
+    A, B = rng.integers(0, 256, 200), rng.integers(0, 256, 200)
+    for lua_name, largs, py in (("adderNetlist", (8, True), circuits.ripple_carry_adder(8, carry_in_zero=True)),
+                                ("subtractorNetlist", (8,), circuits.subtractor(8)), ("multiplierNetlist", (8,), circuits.multiplier(8))):
+        res = call(it, tf, lua_name, *largs)
+        nl, a, b, outs = res[0], res[1], res[2], ml.to_python(res[3])
+        bits = np.zeros((nl.get(b"nWires"), len(A)), np.int64)
+        for i in range(8):
+            bits[a + i], bits[b + i] = (A >> i) & 1, (B >> i) & 1
+        _, boots = run_packed(it.call(nl.get(b"packed"), [])[0], bits)
+        got = sum(bits[w] << i for i, w in enumerate(outs))
+        want = {"adderNetlist": A + B, "subtractorNetlist": (A - B) % 256, "multiplierNetlist": A * B}[lua_name]
+        assert np.array_equal(got, want), lua_name
+        assert boots == eoc.circuit_bootstraps(py[0]), (lua_name, boots)
+
+
+def test_batch_functions_pack_and_slice_wires(facade):
+    it, tf, be = facade
+    rng = np.random.default_rng(9)
+    S, nbits = 7, 4
+    A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+    pa, pb = planes_of(A, nbits, S), planes_of(B, nbits, S)
+    out = call(it, tf, "addBitsBatch", pa, pb, nbits, S)[0]
+    assert len(out) == (nbits + 1) * S * ROW * 4 and np.array_equal(value_of(out, S), A + B)
+    assert be.calls[-1] == ("circuitRun", 5 * nbits - 3, be.calls[-1][2], S)
+    out = call(it, tf, "subtractBitsBatch", pa, pb, nbits, S)[0]
+    v = value_of(out, S)
+    assert np.array_equal(v & 15, (A - B) % 16) and np.array_equal(v >> 4, (A < B).astype(np.int64))
+    out = call(it, tf, "multiplyBitsBatch", pa, pb, nbits, S)[0]
+    assert np.array_equal(value_of(out, S), A * B)
+    lo, hi, lt = call(it, tf, "minMaxBitsBatch", pa, pb, nbits, S)
+    assert np.array_equal(value_of(lo, S), np.minimum(A, B)) and np.array_equal(value_of(hi, S), np.maximum(A, B))
+    assert np.array_equal(value_of(lt, S), (A < B).astype(np.int64))
+    # a backend that refuses (nil) comes through as nil, not as an error
+    be2 = PlainBackend().table()
+    be2.set(b"circuitRun", lambda *a: None)
+    tf.set(b"backend", be2)
+    assert call(it, tf, "addBitsBatch", pa, pb, nbits, S) == [None]
+
+
+def test_strings_travel_lsb_first_and_compare(facade):
+    it, tf, be = facade
+    x = call(it, tf, "encryptStringBits", b"Hi")[0]
+    assert be.calls[-1] == ("encryptBits", bytes([0, 0, 0, 1, 0, 0, 1, 0, 1, 0, 0, 1, 0, 1, 1, 0]))   # 'H' = 0x48, 'i' = 0x69
+    y = call(it, tf, "encryptStringBits", b"Hi")[0]
+    z = call(it, tf, "encryptStringBits", b"Hj")[0]
+    eq = call(it, tf, "equalStrings", x, y)[0]
+    ne = call(it, tf, "equalStrings", x, z)[0]
+    assert len(eq) == ROW * 4 and value_of(eq, 1)[0] == 1 and value_of(ne, 1)[0] == 0
+
+
+# ---- GPU: facade -> binding C (Lua C-API double) -> library ----------------------------------------------------------
+@pytest.mark.gpu
+def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
+    from gpu_util import torch_cuda
+    torch_cuda()
+    import eoc_tfhe_amd as eoc
+    import oracle_lib as ol
+    from test_lua_binding import Lua
+    eoc.gpu_shutdown()
+    eoc.Tfhe.resetGateKey()
+    lua = Lua(tmp_path)
+    names = ("generateGateKey", "resetGateKey", "encryptBits", "decryptBits", "gateBatch", "circuitRun", "sampleInts", "keyMode",
+             "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT")
+    backend = ml.table_from({n: (lambda *a, _n=n: lua.call(_n, *a)) for n in names})
+    it = ml.Interpreter()
+    tf = ml.LuaTable()
+    tf.set(b"backend", backend)
+    it.set_global("Tfhe", tf)
+    it.run(open(FACADE, "rb").read(), "tfhe_gates.lua")
+    try:
+        tok = call(it, tf, "generateGateKey", 80, 9)[0]
+        assert tok and call(it, tf, "keyMode") == [1]
+        orc = ol.Oracle(0, 9)
+        # strings: 2 x 3 characters -> 24 bit-ciphertexts each; XOR per bit + OR tree + NOT on the GPU
+        x, y, z = (call(it, tf, "encryptStringBits", s)[0] for s in (b"abc", b"abc", b"abd"))
+        assert len(x) == 24 * 501 * 4
+        assert lua.call("decryptBits", call(it, tf, "equalStrings", x, y)[0]) == b"\x01"
+        assert lua.call("decryptBits", call(it, tf, "equalStrings", x, z)[0]) == b"\x00"
+        # 4-bit adder and min / max over 6 instances
+        rng = np.random.default_rng(21)
+        S, nbits = 6, 4
+        A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+
+        def enc(vals):
+            bits = np.stack([(vals >> i) & 1 for i in range(nbits)]).astype(np.uint8)     # [nbits][S]
+            return lua.call("encryptBits", bits.tobytes())
+
+        def dec(buf):
+            bits = np.frombuffer(lua.call("decryptBits", buf), np.uint8).reshape(-1, S).astype(np.int64)
+            return sum(bits[i] << i for i in range(bits.shape[0]))
+
+        ea, eb = enc(A), enc(B)
+        out = call(it, tf, "addBitsBatch", ea, eb, nbits, S)[0]
+        assert np.array_equal(dec(out), A + B)
+        lo, hi, lt = call(it, tf, "minMaxBitsBatch", ea, eb, nbits, S)
+        assert np.array_equal(dec(lo), np.minimum(A, B)) and np.array_equal(dec(hi), np.maximum(A, B))
+        assert np.array_equal(dec(lt), (A < B).astype(np.int64))
+        # the adder's bytes against the oracle: the facade's netlist, gate by gate
+        nl, a, b, s = call(it, tf, "adderNetlist", nbits)
+        g = np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)
+        wires = np.zeros((nl.get(b"nWires"), S, 501), np.int32)
+        wires[a:a + nbits] = np.frombuffer(ea, np.int32).reshape(nbits, S, 501)
+        wires[b:b + nbits] = np.frombuffer(eb, np.int32).reshape(nbits, S, 501)
+        for op, i0, i1, _, o in g:
+            wires[o] = orc.gate_batch(int(op), wires[i0], wires[i1])
+        want = np.concatenate([wires[w] for w in ml.to_python(s)]).tobytes()
+        assert out == want
+    finally:
+        lua.call("resetGateKey")
+        lua.lib.ld_close(lua.S)
+        eoc.gpu_shutdown()
