@@ -3,8 +3,7 @@
 -- Lua 5.3 used below -- in tests/test_lua_facade.py: every netlist builder on plaintext bits over all input pairs, the batch
 -- functions' wire packing, and facade -> binding C -> library on the GPU.  integration/node/tfhe.js is its twin with the
 -- same functions and netlists: tests/test_binding_surfaces.py compares the two name by name (`and`, `or`, `not` are Lua
--- keywords: band / bor / bnot here) and lists the three string-level circuits only the JS side has (addBits, lessThanBits,
--- minMaxBits: they decode base64, which the Lua 5.3 standard library cannot).
+-- keywords: band / bor / bnot here; base64Decode / base64Encode exist only here: Node has Buffer for that).
 function Tfhe.generateGateKey(lambda, seed) return Tfhe.backend.generateGateKey(lambda, seed) end
 function Tfhe.resetGateKey()                return Tfhe.backend.resetGateKey() end
 function Tfhe.deviceCount()                 return Tfhe.backend.deviceCount() end     -- GPUs the process can see
@@ -136,8 +135,9 @@ function Tfhe.multiplierNetlist(nbits)
   prod[#prod + 1] = top
   return nl, a, b, prod
 end
--- run a netlist over `instances` instances; inputs = { [firstWire] = samples [k][instances][n+1] }
-function Tfhe.runNetlist(nl, inputs, instances)
+-- run a netlist over `instances` instances; inputs = { [firstWire] = samples [k][instances][n+1] };
+-- outputs (optional): the wires the caller reads afterwards -- the netlist is then rewritten first (NOT folding, MUX fusion)
+function Tfhe.runNetlist(nl, inputs, instances, outputs)
   local plane = instances * Tfhe.backend.sampleInts() * 4
   local parts, w = {}, 0
   while w < nl.nWires do                                  -- assemble the wire array plane by plane
@@ -145,11 +145,77 @@ function Tfhe.runNetlist(nl, inputs, instances)
     if buf then parts[#parts + 1] = buf; w = w + #buf // plane
     else parts[#parts + 1] = string.rep("\0", plane); w = w + 1 end
   end
-  return Tfhe.backend.circuitRun(nl.packed(), table.concat(parts), nl.nWires, instances)
+  local gates = nl.packed()
+  if outputs then
+    local o = {}
+    for i = 1, #outputs do o[i] = string.pack("<i4", outputs[i]) end
+    gates = Tfhe.backend.netlistOptimize(gates, table.concat(o)) or gates
+  end
+  return Tfhe.backend.circuitRun(gates, table.concat(parts), nl.nWires, instances)
 end
 local function planes(wires, first, count, instances)
   local plane = instances * Tfhe.backend.sampleInts() * 4
   return wires:sub(first * plane + 1, (first + count) * plane)
+end
+-- base64 ciphertext strings <-> raw samples (wire format of export_lweSample_toStream: a[n] | b | f64 variance,
+-- eoc-tfhe-run.cpp:293-295); Lua 5.3 has no base64 in its standard library
+local B64 = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"
+local B64DEC = {}
+for i = 1, 64 do B64DEC[B64:byte(i)] = i - 1 end
+local function b64decode(s)                               -- stops at the first non-alphabet byte, like the reference decoder
+  local out, acc, bits = {}, 0, 0
+  for i = 1, #s do
+    local v = B64DEC[s:byte(i)]
+    if not v then break end
+    acc = ((acc << 6) | v) & 0xFFFFFF
+    bits = bits + 6
+    if bits >= 8 then
+      bits = bits - 8
+      out[#out + 1] = string.char((acc >> bits) & 0xFF)
+    end
+  end
+  return table.concat(out)
+end
+local function b64char(v) return B64:sub(v + 1, v + 1) end
+local function b64encode(s)
+  local out = {}
+  for i = 1, #s, 3 do
+    local a, b, c = s:byte(i, i + 2)
+    local v = (a << 16) | ((b or 0) << 8) | (c or 0)
+    out[#out + 1] = b64char(v >> 18) .. b64char((v >> 12) & 63) .. (b and b64char((v >> 6) & 63) or "=") .. (c and b64char(v & 63) or "=")
+  end
+  return table.concat(out)
+end
+Tfhe.base64Decode = b64decode
+Tfhe.base64Encode = b64encode
+local function strToSample(s) return b64decode(s):sub(1, Tfhe.backend.sampleInts() * 4) end
+local function sampleToStr(buf) return b64encode(buf .. string.rep("\0", 8)) end
+local function stack(arr)
+  local parts = {}
+  for i = 1, #arr do parts[i] = strToSample(arr[i]) end
+  return table.concat(parts)
+end
+local function pick(wires, ws)                            -- wires of ONE instance -> array of base64 ciphertext strings
+  local out = {}
+  for i = 1, #ws do out[i] = sampleToStr(planes(wires, ws[i], 1, 1)) end
+  return out
+end
+-- string-API circuits: arrays of base64 bit ciphertexts (LSB first) in, arrays out -- ONE backend call per circuit
+function Tfhe.addBits(A, B)                               -- -> #A + 1 ciphertexts
+  local nl, a, b, sum = Tfhe.adderNetlist(#A)
+  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1)
+  return wires and pick(wires, sum)
+end
+function Tfhe.lessThanBits(A, B)                          -- -> one ciphertext: 1 iff A < B (unsigned)
+  local nl, a, b, lt = Tfhe.minMaxNetlist(#A)
+  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1, { lt })
+  return wires and sampleToStr(planes(wires, lt, 1, 1))
+end
+function Tfhe.minMaxBits(A, B)                            -- -> min, max (arrays of #A ciphertexts)
+  local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlist(#A)
+  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1)
+  if not wires then return nil end
+  return pick(wires, mn), pick(wires, mx)
 end
 -- raw-buffer circuits over many instances: operands are samples [nbits][instances][n+1]
 function Tfhe.addBitsBatch(A, B, nbits, instances)

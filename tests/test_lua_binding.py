@@ -90,7 +90,8 @@ class Lua:
         assert L.luaopen_tfhe_gates(self.S) == 1
         self.fn = {}
         for n in ("generateGateKey", "resetGateKey", "encryptBits", "decryptBits", "gateBatch", "circuitRun", "sampleInts",
-                  "keyMode", "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT"):
+                  "keyMode", "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT", "netlistOptimize",
+                  "circuitBootstraps"):
             self.fn[n] = L.ld_table_get(self.S, 1, n.encode())
             assert self.fn[n]
         L.ld_settop0(self.S)

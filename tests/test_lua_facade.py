@@ -268,7 +268,7 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
     eoc.Tfhe.resetGateKey()
     lua = Lua(tmp_path)
     names = ("generateGateKey", "resetGateKey", "encryptBits", "decryptBits", "gateBatch", "circuitRun", "sampleInts", "keyMode",
-             "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT")
+             "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT", "netlistOptimize")
     backend = ml.table_from({n: (lambda *a, _n=n: lua.call(_n, *a)) for n in names})
     it = ml.Interpreter()
     tf = ml.LuaTable()
@@ -313,7 +313,51 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
             wires[o] = orc.gate_batch(int(op), wires[i0], wires[i1])
         want = np.concatenate([wires[w] for w in ml.to_python(s)]).tobytes()
         assert out == want
+        # string-level circuits: base64 ciphertext strings in and out (the facade's own base64), one backend call each;
+        # lessThanBits goes through the backend's netlistOptimize (NOT folding, MUX fusion, dead gates dropped)
+        for av, bv in ((5, 6), (7, 2)):
+            As = ml.table_from([call(it, tf, "encryptBit", (av >> i) & 1)[0] for i in range(3)])
+            Bs = ml.table_from([call(it, tf, "encryptBit", (bv >> i) & 1)[0] for i in range(3)])
+            ssum = ml.to_python(call(it, tf, "addBits", As, Bs)[0])
+            assert sum(call(it, tf, "decryptBit", x)[0] << i for i, x in enumerate(ssum)) == av + bv
+            assert call(it, tf, "decryptBit", call(it, tf, "lessThanBits", As, Bs)[0]) == [int(av < bv)]
+            mn, mx = (ml.to_python(t) for t in call(it, tf, "minMaxBits", As, Bs))
+            assert sum(call(it, tf, "decryptBit", x)[0] << i for i, x in enumerate(mn)) == min(av, bv)
+            assert sum(call(it, tf, "decryptBit", x)[0] << i for i, x in enumerate(mx)) == max(av, bv)
     finally:
         lua.call("resetGateKey")
         lua.lib.ld_close(lua.S)
         eoc.gpu_shutdown()
+
+
+def test_base64_and_string_level_circuits(facade):
+    """the facade's own base64 (Lua 5.3 has none) against Python's, and addBits / lessThanBits / minMaxBits -- arrays of
+    base64 ciphertext strings in and out, ONE backend call per circuit, like tfhe.js"""
+    import base64
+    it, tf, be = facade
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 3, 4, 5, 31, 100):
+        raw = rng.integers(0, 256, n).astype(np.uint8).tobytes()
+        enc = call(it, tf, "base64Encode", raw)[0]
+        assert enc == base64.b64encode(raw)
+        assert call(it, tf, "base64Decode", enc)[0] == raw
+    assert call(it, tf, "base64Decode", b"QUJD!ignored")[0] == b"ABC"          # stops at the first non-alphabet byte
+
+    def ct(bit):                                                              # export_lweSample_toStream bytes of the stand-in
+        return base64.b64encode(struct.pack("<3i", 7, 7, int(bit)) + b"\0" * 8)
+
+    def bit_of(s):
+        return struct.unpack("<3i", base64.b64decode(s)[:12])[2]
+
+    # netlistOptimize of the stand-in backend: identity (the real one is exercised on the GPU leg)
+    be_t = tf.get(b"backend")
+    be_t.set(b"netlistOptimize", lambda gates, outs: gates)
+    for a, b in ((5, 3), (9, 12), (15, 15), (0, 1)):
+        A = ml.table_from([ct((a >> i) & 1) for i in range(4)])
+        B = ml.table_from([ct((b >> i) & 1) for i in range(4)])
+        s = ml.to_python(call(it, tf, "addBits", A, B)[0])
+        assert len(s) == 5 and sum(bit_of(x) << i for i, x in enumerate(s)) == a + b
+        assert bit_of(call(it, tf, "lessThanBits", A, B)[0]) == int(a < b)
+        mn, mx = (ml.to_python(t) for t in call(it, tf, "minMaxBits", A, B))
+        assert sum(bit_of(x) << i for i, x in enumerate(mn)) == min(a, b)
+        assert sum(bit_of(x) << i for i, x in enumerate(mx)) == max(a, b)
