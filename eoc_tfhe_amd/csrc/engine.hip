@@ -118,6 +118,12 @@ static int valid_params(const eoc_params *p)
     if (!p) return 0;
     if (p->n < 1 || p->n > 1023) return 0;
     if (p->l < 1 || p->l > 4 || p->Bgbit < 1 || p->l * p->Bgbit > 32) return 0;
+    // An external-product coefficient is bounded by l * Bg * 2^41 (2 l N digits of magnitude <= Bg / 2 times key
+    // coefficients below 2^31).  The FP64 transform and its conversion are specified for |v| < 2^51 (include/eoc_tfhe_gpu.h:
+    // unconditional for l * Bg < 1024, overwhelmingly probable up to l * Bg = 8192, where the typical magnitude is still
+    // below 2^48); beyond that binary64 no longer holds the sums and neither this engine nor upstream's FFT path computes
+    // the exact product.  Such shapes are refused rather than evaluated approximately.
+    if (((int64_t)p->l << p->Bgbit) > 8192) return 0;
     if (p->ks_t < 1 || p->ks_basebit < 1 || p->ks_basebit > 4 || p->ks_t * p->ks_basebit > 31) return 0;
     return 1;
 }
@@ -207,7 +213,8 @@ static int upload_tables(eoc_engine *e)
 extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **out)
 {
     if (!out || !valid_params(p)) {
-        eoc_set_error("eoc_engine_create: bad arguments");
+        eoc_set_error("eoc_engine_create: bad arguments (need 1 <= n <= 1023, 1 <= l <= 4, l * Bgbit <= 32, l * 2^Bgbit <= 8192 "
+                      "-- the FP64 external product is not exact beyond that --, ks_t * ks_basebit <= 31, ks_basebit <= 4)");
         return EOC_ERR_ARG;
     }
     int cnt = eoc_device_count();

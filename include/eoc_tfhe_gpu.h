@@ -39,9 +39,11 @@ extern "C" {
 
 /* TFheGateBootstrappingParameterSet (type used at eoc-tfhe-run.cpp:230) flattened. */
 typedef struct eoc_params {
-    int32_t n;          /* LWE dimension */
-    int32_t l;          /* gadget length */
-    int32_t Bgbit;      /* log2 gadget base */
+    int32_t n;          /* LWE dimension, 1 ... 1023 */
+    int32_t l;          /* gadget length, 1 ... 4 */
+    int32_t Bgbit;      /* log2 gadget base; l * Bgbit <= 32 and, for an engine, l * 2^Bgbit <= 8192: beyond that an
+                           external-product coefficient (bounded by l * Bg * 2^41) outgrows what the FP64 transform and its
+                           conversion are specified for (see eoc_dbg_fft_inv_device) and eoc_engine_create refuses the shape */
     int32_t ks_t;       /* key-switch length */
     int32_t ks_basebit; /* log2 key-switch base */
     double ks_stdev;    /* LWE / fresh-ciphertext / key-switch-key noise */

@@ -544,3 +544,36 @@ def test_in_place_batches_with_the_folded_prologue(eoc, rig_a, cnt):
         sync()
         assert np.array_equal(out.cpu().numpy(), want), alias
     assert np.array_equal(r.sk.decrypt_bits(want), b0 ^ b1)
+
+
+@pytest.mark.parametrize("n,bgbit,cnt", [(12, 8, 9), (7, 12, 6), (5, 11, 3), (9, 10, 2051)])
+def test_wide_kernel_custom_gadget_bases_bit_exact(eoc, monkeypatch, n, bgbit, cnt):
+    """k_blind_rotate_wide's run-time-base instance (gadget length 2 with Bgbit != 10) and the compile-time one on a
+    custom n, forced onto narrow batches (odd counts leave an idle wave) and taken by width (2 051 rows: a full wide
+    launch + a 3-row remainder on the pair kernel): GPU == oracle bit for bit, NAND / XOR / MUX.  (Bases beyond 2^12 at
+    gadget length 2 leave the conversion contract |v| < 2^51 -- include/eoc_tfhe_gpu.h -- and are not claimed.)"""
+    torch = torch_cuda()
+    if cnt < 1024:
+        monkeypatch.setenv("EOC_TFHE_BR_WIDE", "1")
+    p = eoc.default_params(0)
+    p.n, p.l, p.Bgbit = n, 2, bgbit
+    sk = eoc.SecretKey(p, 78)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    orc = ol.Oracle(0, 78, n_override=n, with_bk=False)
+    orc.p.l, orc.p.Bgbit = 2, bgbit
+    orc.l, orc.kpl = 2, 4
+    orc.gen_cloud()
+    assert np.array_equal(sk.bk, orc.bk)
+    rng = np.random.default_rng(n)
+    c = [sk.encrypt_bits(rng.integers(0, 2, cnt), 95 + k, 0) for k in range(3)]
+    d = [to_dev(x) for x in c]
+    out = torch.empty_like(d[0])
+    w0 = eng.stats()["br_wide_launches"]
+    for name in ("NAND", "XOR", "MUX"):
+        eng.gate_batch_device(eoc.OPS[name], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), cnt)
+        sync()
+        want = orc.gate_batch(ol.OPS[name], c[0], c[1], c[2] if name == "MUX" else None)
+        assert np.array_equal(out.cpu().numpy(), want), (name, n, bgbit)
+    assert eng.stats()["br_wide_launches"] >= w0 + 3
+    eng.close()

@@ -190,3 +190,20 @@ def test_secure_mode_keys_and_encryption(built_lib):
     built_lib.eoc_secret_key_free(h)
     blob[50] ^= 1                                             # a damaged master key no longer matches the key bits
     assert built_lib.eoc_secret_key_import(blob.ctypes.data, need, 0, C.byref(h)) != 0
+
+
+def test_engine_refuses_gadget_shapes_beyond_the_fp64_contract(built_lib):
+    """l * Bg > 8192: an external-product coefficient can exceed what binary64 holds exactly (l * Bg * 2^41); the engine
+    refuses the shape at creation -- before it looks for a device, so the refusal is the same on a box without a GPU"""
+    import eoc_tfhe_amd as eoc
+    for l, bgbit in ((2, 16), (1, 14), (4, 12), (3, 12)):
+        p = eoc.default_params(0)
+        p.l, p.Bgbit = l, bgbit
+        with pytest.raises(eoc.EocError, match="FP64 external product is not exact"):
+            eoc.Engine(p)
+    p = eoc.default_params(0)
+    p.l, p.Bgbit = 2, 12                       # l * Bg = 8192: the last accepted shape (no device here: another error)
+    try:
+        eoc.Engine(p).close()
+    except eoc.EocError as e:
+        assert "no usable HIP device" in str(e)
