@@ -67,3 +67,30 @@ def test_gpu_noise_matches_prediction(eoc, pset):
     # the nearest neighbours are excluded: rounding decomposition (textbook formula) 1.53x (A) / 1.33x (B),
     # average-over-keys key switch 0.75x
     assert r["br_ratio_textbook"] > 1.2 and r["ks_ratio_textbook"] < 0.82, r
+
+
+def test_gpu_mux_noise_is_two_rotations_and_one_key_switch(eoc):
+    """bootsMUX: two blind rotations summed in the extracted domain, ONE key switch -- its output error has
+    variance 2 V_BR + V_KS and mean 2 M_BR + M_KS (the two rotations see independent inputs), Set A, 16 384 samples"""
+    torch = torch_cuda()
+    p = eoc.default_params(0)
+    sk = eoc.SecretKey(p, 1)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    rng = np.random.default_rng(300)
+    b = [rng.integers(0, 2, COUNT) for _ in range(3)]
+    d = [to_dev(sk.encrypt_bits(b[k], 4301 + k)) for k in range(3)]
+    out = dev_empty((COUNT, p.n + 1), torch.int32)
+    eng.gate_batch_device(eoc.OPS["MUX"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), COUNT)
+    sync()
+    o = out.cpu().numpy().astype(np.int64)
+    want = np.where(b[0] == 1, b[1], b[2])
+    assert np.array_equal(sk.decrypt_bits(out.cpu().numpy()), want)
+    ph = ((o[:, -1] - o[:, :-1] @ sk.lwe_key.astype(np.int64)) + 2**31) % 2**32 - 2**31
+    err = (ph - (2 * want - 1) * 2**29) / 2.0**32
+    pred = noise.predict(p, sk.lwe_key, sk.tlwe_key, sk.ksk)
+    var_pred, mean_pred = 2 * pred["br_var"] + pred["ks_var"], 2 * pred["br_mean"] + pred["ks_mean"]
+    assert 0.8 < err.var() / var_pred < 1.25, (err.var(), var_pred)
+    assert abs(err.mean() - mean_pred) < 5 * err.std() / np.sqrt(COUNT), (err.mean(), mean_pred)
+    # and it is NOT one rotation's worth: the single-bootstrap prediction is excluded
+    assert err.var() / pred["total_var"] > 1.5
