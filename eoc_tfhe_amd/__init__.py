@@ -479,6 +479,11 @@ class Engine:
     def keyswitch_device(self, d_u, d_out, count, stream=None):
         _check(self.L.eoc_keyswitch_device(self.h, d_u, d_out, count, stream), "eoc_keyswitch_device")
 
+    def resident_jobs(self):
+        """blind rotations that fill the device in one launch (8 x CUs where the one-wave-per-ciphertext kernel applies,
+        4 x otherwise): cut long jobs at multiples of this"""
+        return int(self.L.eoc_engine_resident_jobs(self.h))
+
     def stats(self):
         out = (C.c_uint64 * 3)()
         _check(self.L.eoc_engine_stats(self.h, C.byref(out)), "eoc_engine_stats")
