@@ -567,7 +567,7 @@ typedef eoc_engine::Workspace WS;
 // workgroups within half a per cent of each other (3.0 ms per 1024 jobs), while a launch of several rounds settles at
 // a 10 % lower rate (the arbiter's age bias), so wide levels are cut into back-to-back single-round launches.
 static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipStream_t st,
-                               const GateDesc *fold_descs = nullptr, uint32_t fold_S = 0)
+                               const GateDesc *fold_descs = nullptr, uint32_t fold_S = 0, const GateDesc *inline_desc = nullptr)
 {
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
     // Two kernel shapes (kernels.hip.h).  The pair kernel (one ciphertext = one wave pair) fills the chip with 4 x CUs
@@ -607,7 +607,7 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
         const bool wide = sg.wide;
         const uint32_t resident = wide ? resident_wide : resident_pair;
         for (int part = 0; part < parts; part++) {
-            BRArgs a;
+            BRArgs a{};
             a.bkfft = e->bkfft;
             a.bara = W.d_bara + (size_t)off * e->bara_stride;
             a.u = W.d_u + (size_t)off * (kN + 1);
@@ -619,6 +619,12 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
             a.stamps = e->d_stamps;
             a.ks_descs = fold_descs;
             a.prep = fold_descs != nullptr;
+            a.inline_desc = inline_desc != nullptr;
+            if (inline_desc) {
+                a.desc0 = *inline_desc;
+                a.ks_descs = reinterpret_cast<const GateDesc *>(W.d_descs); // non-null = fold; never dereferenced
+                a.prep = 1;
+            }
             a.ubar = W.d_ubar;
             a.ks_S = fold_S ? fold_S : 1;
             a.ks_prec_offset = 1u << (32 - (1 + e->p.ks_basebit * e->p.ks_t));
@@ -658,9 +664,12 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
 }
 
 static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint32_t ngates, uint32_t S, hipStream_t st,
-                            bool init_done = false)
+                            bool init_done = false, const GateDesc *inline_desc = nullptr)
 {
     KSArgs a;
+    a.inline_desc = inline_desc != nullptr;
+    if (inline_desc) a.desc0 = *inline_desc;
+    else a.desc0 = GateDesc{0, 0, nullptr, nullptr, nullptr, nullptr};
     a.ksk = e->ksk;
     a.u = W.d_u;
     a.ubar = W.d_ubar;
@@ -792,8 +801,11 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
             return EOC_ERR_STATE;
         }
         const size_t cnt = g1 - g0;
+        // a level of ONE gate without MUX -- the plain eoc_gate_batch_device call -- sends its descriptor as a kernel
+        // argument: no copy into the descriptor ring precedes the two launches (and nothing is consumed from the ring)
+        const bool inline_one = cnt == 1 && !any_mux && !e->no_fold;
         GateDesc *dd = nullptr;
-        int rc = push_descs(W, boot.data() + g0, cnt, st, &dd);
+        int rc = inline_one ? EOC_OK : push_descs(W, boot.data() + g0, cnt, st, &dd);
         if (rc) return rc;
         // without MUX every gate has S jobs (job = gate * S + instance): the blind rotation's prologue derives its own
         // rotation amounts from the operand rows (k_prepare folded away) and its epilogue sets the key switch up
@@ -806,9 +818,10 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
             hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, W.d_bara, e->bara_stride);
             HIP_TRY(hipGetLastError());
         }
-        rc = launch_blind_rotate(e, W, jobs, st, fold ? dd : nullptr, (uint32_t)S);
+        const GateDesc *one = inline_one ? boot.data() + g0 : nullptr;
+        rc = launch_blind_rotate(e, W, jobs, st, fold ? dd : nullptr, (uint32_t)S, one);
         if (rc) return rc;
-        rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st, fold);
+        rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st, fold, one);
         if (rc) return rc;
         e->stats[0] += 1;
         e->stats[1] += jobs;

@@ -637,6 +637,8 @@ struct BRArgs {
     // folded key-switch set-up (levels without MUX): the epilogue writes the key-switch operand and the output row
     // itself, k_ks_init is not launched and the extracted sample never goes to memory
     const GateDesc *ks_descs;   // non-null = fold; gate of job j is j / ks_S (jobs are [gate][instance])
+    GateDesc desc0;             // single-gate levels (the plain batch call): the descriptor travels as a kernel argument,
+    int inline_desc;            // `ks_descs` is then a non-null dummy and no descriptor copy precedes the launch
     int prep;                   // fold only: the prologue derives the job's rotation amounts from the gate's operand rows
                                 // itself (bootsNAND... linear stage + modSwitchFromTorus32), k_prepare is not launched
     uint32_t *ubar;             // [jobs][N], row-major: the epilogue's stores are lane-contiguous (256 B per instruction)
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
     load_tables(s_tw, s_twist, g_tw, g_twist, tid, 128);
     if (A.prep && A.step_begin == 0) { // folded k_prepare: this workgroup's row of rotation amounts
         const uint32_t gjob = A.job0 + job, g = gjob / A.ks_S;
-        prepare_row(A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, tid, 128);
+        prepare_row(A.inline_desc ? A.desc0 : A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, tid, 128);
         eoc_row_stores_to_l2();
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BRArgs A, const d2 *__r
             }
         } else {
             const uint32_t g = gjob / A.ks_S, si = gjob - g * A.ks_S;
-            int32_t *o = A.ks_descs[g].out + (size_t)si * (A.n + 1);
+            int32_t *o = (A.inline_desc ? A.desc0.out : A.ks_descs[g].out) + (size_t)si * (A.n + 1);
             for (int m = lane; m < A.n; m += 64) o[m] = 0;
             if (lane == 0) o[A.n] = ext[0];
         }
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
     load_tables(s_tw, s_twist, g_tw, g_twist, tid, 64 * kBRWideJobsPerWG);
     if (A.prep && A.step_begin == 0 && job < A.njobs) { // folded k_prepare: this wave's row of rotation amounts
         const uint32_t gjob = A.job0 + job, g = gjob / A.ks_S;
-        prepare_row(A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, lane, 64);
+        prepare_row(A.inline_desc ? A.desc0 : A.ks_descs[g], gjob - g * A.ks_S, A.n, A.bara + (size_t)job * A.bara_stride, lane, 64);
         eoc_row_stores_to_l2();
     }
     __syncthreads();
@@ -1268,7 +1270,7 @@ __global__ __launch_bounds__(64 * kBRWideJobsPerWG, 2) void k_blind_rotate_wide(
             A.ubar[(size_t)gjob * kN + j] = (uint32_t)ext[(2 * kN - j) & (2 * kN - 1)] + A.ks_prec_offset;
         }
         const uint32_t g = gjob / A.ks_S, si = gjob - g * A.ks_S;
-        int32_t *o = A.ks_descs[g].out + (size_t)si * (A.n + 1);
+        int32_t *o = (A.inline_desc ? A.desc0.out : A.ks_descs[g].out) + (size_t)si * (A.n + 1);
         for (int m = lane_e; m < A.n; m += 64) o[m] = 0;
         if (lane_e == 0) o[A.n] = bval;
     } else {
@@ -1299,13 +1301,15 @@ struct KSArgs {
     uint32_t *ubar;     // [jobs][N] row-major
     int n, n1p, t, basebit;
     uint32_t S;
+    GateDesc desc0;     // single-gate levels: the descriptor as a kernel argument (see BRArgs)
+    int inline_desc;
     int32_t mu;
 };
 
 // grid: x = S, y = gates
 __global__ __launch_bounds__(256) void k_ks_init(const GateDesc *__restrict__ descs, KSArgs A)
 {
-    const GateDesc d = descs[blockIdx.y];
+    const GateDesc d = A.inline_desc ? A.desc0 : descs[blockIdx.y];
     const uint32_t s = blockIdx.x;
     const uint32_t job = d.job_base + s;
     const int32_t *u1 = A.u + (size_t)job * (kN + 1);
@@ -1381,7 +1385,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
     // LDS offset 0, i.e. the kernel has no static __shared__ object -- trap instead of silently wrapping if that ever changes
     if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();
 
-    const GateDesc d = descs[blockIdx.y];
+    const GateDesc d = A.inline_desc ? A.desc0 : descs[blockIdx.y];
     const uint32_t ntiles = (A.S + 63) / 64, ncb = (uint32_t)A.n1p / 64u;
     const uint32_t tile = blockIdx.x % ntiles, rest = blockIdx.x / ntiles;
     const uint32_t cb = rest % ncb, slice = rest / ncb;
@@ -1523,7 +1527,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void k_keyswitch_waves(const GateDesc 
 // when it starts (k_ks_init or the blind rotate's epilogue wrote it).  grid: x = S, y = gates; block = 256
 __global__ __launch_bounds__(256) void k_keyswitch_generic(const GateDesc *__restrict__ descs, KSArgs A)
 {
-    const GateDesc d = descs[blockIdx.y];
+    const GateDesc d = A.inline_desc ? A.desc0 : descs[blockIdx.y];
     const uint32_t s = blockIdx.x, job = d.job_base + s;
     const int base1 = (1 << A.basebit) - 1;
     int32_t *o = d.out + (size_t)s * (A.n + 1);
