@@ -165,7 +165,8 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  * eoc_engine_reserve sizes them once, after which the launch path does not allocate and a fixed
  * netlist / batch shape can be captured into a hipGraph.  eoc_engine_workspace_grows counts growths since the
  * last reserve (0 in steady state).  It synchronises in ONE place: when the descriptor ring (max_descs slots, at least
- * 1 024) wraps around -- once per ~thousand single-gate-kind batches -- the call waits, on an event recorded behind the
+ * 1 024) wraps around -- a batch of one two-input opcode sends its descriptor as a kernel argument and never uses the
+ * ring; MUX batches, mixed batches and circuits consume one slot per gate and level -- the call waits, on an event recorded behind the
  * engine's own most recent kernels, until the slots it is about to rewrite have been consumed.  Only this engine's
  * earlier work is waited for (no device-wide synchronise: a neighbouring batch's copy streams and captures on other
  * streams are not touched); a call on a capturing stream never wraps (its descriptors go to the arena below).

@@ -506,20 +506,22 @@ def test_wide_kernel_full_width_bit_exact(eoc, rig_a):
 
 
 def test_descriptor_ring_wraps_without_a_device_synchronise(eoc, rig_small):
-    """1 300 back-to-back asynchronous calls on one stream push 1 300 descriptors through the 1 024-slot ring: the wrap
-    waits for the engine's own earlier kernels (an event), results before and after it are the oracle's"""
+    """1 300 back-to-back asynchronous MUX calls on one stream push 1 300 descriptors through the 1 024-slot ring (a MUX level
+    keeps the separate k_prepare / k_ks_init launches and therefore the ring; a single two-input gate travels as a kernel
+    argument and never touches it): the wrap waits for the engine's own earlier kernels (an event), results
+    before and after it are the oracle's"""
     torch = torch_cuda()
     r = rig_small
-    b0, c0 = _rand_cts(r, 4, 71)
-    b1, c1 = _rand_cts(r, 4, 72)
-    d0, d1 = to_dev(c0), to_dev(c1)
+    c = [_rand_cts(r, 4, 71 + k)[1] for k in range(3)]
+    d = [to_dev(x) for x in c]
     outs = dev_empty((1300, 4, r.n + 1), torch.int32)
-    ops = [eoc.OPS["NAND"], eoc.OPS["XOR"], eoc.OPS["OR"]]
+    perms = [(0, 1, 2), (1, 2, 0), (2, 0, 1)]
     for k in range(1300):
-        r.eng.gate_batch_device(ops[k % 3], d0.data_ptr(), d1.data_ptr(), None, outs[k].data_ptr(), 4)
+        i0, i1, i2 = perms[k % 3]
+        r.eng.gate_batch_device(eoc.OPS["MUX"], d[i0].data_ptr(), d[i1].data_ptr(), d[i2].data_ptr(), outs[k].data_ptr(), 4)
     sync()
     got = outs.cpu().numpy()
-    want = [r.orc.gate_batch(ol.OPS[n], c0, c1) for n in ("NAND", "XOR", "OR")]
+    want = [r.orc.gate_batch(ol.OPS["MUX"], c[i0], c[i1], c[i2]) for i0, i1, i2 in perms]
     for k in list(range(0, 1300, 97)) + list(range(1015, 1035)) + [1299]:
         assert np.array_equal(got[k], want[k % 3]), k
 
