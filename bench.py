@@ -641,8 +641,8 @@ def main():
             tg = time.perf_counter() - tg0
             graph_res = {"gates_per_s": round(G * args.steps / tg, 1), "ms_per_step": round(tg / args.steps * 1e3, 4),
                          "bit_identical_to_eager": bool(torch.equal(dout, eager_out)),
-                         "note": "one captured eoc_gate_batch_device call (descriptor copy + blind rotation + key switch) "
-                                 "replayed per step: the launch path is one hipGraphLaunch"}
+                         "note": "one captured eoc_gate_batch_device call (blind rotation + key switch; the descriptor travels as "
+                                 "a kernel argument) replayed per step: the launch path is one hipGraphLaunch"}
             del graph
         except Exception as e:  # noqa: BLE001 -- a capture problem must not cost the line
             graph_res = {"error": repr(e)[:300]}
