@@ -53,16 +53,21 @@ def run_noise(eoc, pset, count=COUNT, seed=1):
     return noise.compare(pred, *noise.measure(u, out, sk.lwe_key, sk.tlwe_key))
 
 
-@pytest.mark.parametrize("pset", [0, 1], ids=["setA", "setB"])
-def test_gpu_noise_matches_prediction(eoc, pset):
-    r = run_noise(eoc, pset)
+@pytest.mark.parametrize("pset,seed", [(0, 1), (1, 1), (0, 5)], ids=["setA", "setB", "setA-key5"])
+def test_gpu_noise_matches_prediction(eoc, pset, seed):
+    """(a second key for Set A: the key switch's bias and variance are properties of the KEY's rows -- predicted per key,
+    not fitted)"""
+    r = run_noise(eoc, pset, seed=seed)
     print({k: (f"{v:.4e}" if isinstance(v, float) else v) for k, v in r.items()})
     assert 0.8 < r["br_ratio"] < 1.25, r
     assert 0.8 < r["ks_ratio"] < 1.25, r
     assert abs(r["br_mean_z"]) < 5 and abs(r["ks_mean_z"]) < 5, r
-    # both predicted means are resolvably non-zero at this sample size: a sign slip fails, not just a scale slip
-    assert abs(r["br_mean"]) > 4 * np.sqrt(r["br_var"] / r["count"]), r
-    assert abs(r["ks_mean"]) > 4 * np.sqrt(r["ks_var"] / r["count"]), r
+    # where a predicted mean is resolvably non-zero at this sample size (the blind rotation's always is; the key switch's is
+    # a property of the key: +1.1e-3 for key 1, +2e-5 for key 5) so is the measured one: a sign slip fails, not just a scale slip
+    for part in ("br", "ks"):
+        se = np.sqrt(r[part + "_var"] / r["count"])
+        if abs(r[part + "_mean_pred"]) > 8 * se:
+            assert abs(r[part + "_mean"]) > 4 * se and r[part + "_mean"] * r[part + "_mean_pred"] > 0, (part, r)
     assert r["max_abs_err"] < 1 / 16
     # the nearest neighbours are excluded: rounding decomposition (textbook formula) 1.53x (A) / 1.33x (B),
     # average-over-keys key switch 0.75x
