@@ -13,7 +13,11 @@ Blind rotation (tfhe_blindRotateAndExtract_FFT), error of the 
 extracted key, over many input ciphertexts and ONE key:
 
   V_BR = n * 2l * N * E[d^2] * sigma_bk^2                (the TLWE-zero rows of BK_i, every step; E[d^2] = (Bg^2 + 2)/12:
-                                                          digits uniform on [-Bg/2, Bg/2), mean -1/2)
+                                                          digits uniform on [-Bg/2, Bg/2), mean -1/2; two per-cent-level
+                                                          refinements in `predict`: gaussian32 truncates toward zero, so
+                                                          the stored noise has variance sigma^2 - sigma sqrt(2/pi) 2^-32 +
+                                                          2^-64/3, and the steps before the first s_i = 1 see a noiseless
+                                                          accumulator)
        + w * (1 + |s'|) * q^2 / 12                        (w = Hamming weight of the LWE key, |s'| of the TLWE key:
                                                           the decomposition's remainder, q = Bg^-l)
        + w * (q/2)^2 * G(s')                              (the remainder is a TRUNCATION: upstream's offset
@@ -28,6 +32,10 @@ G(s') = mean_r ((J*(1-s'))[r])^2, about N^2/12 -- N/2 times the variance term ne
 s_i = 1 nothing rotates any more (rho = 0): a deterministic bias
 
   M_BR = -(q/2) * (1 + |s'| - 2 s'_0).
+
+(At 262 144 samples a third, input-dependent mean term resolves: the steps before the first s_i = 1 multiply constant band
+digits by the FIXED noise of their rows -- about 100 (q/2), zero over uniform rotations.  tools/noise_mean_diag.py simulates
+it from the key and matches the measured means per input class; `predict` keeps the input-independent M_BR.)
 
 Key switch (lweKeySwitch; A.6), added error for ONE key whose rows have noises e[i][j][d]
 (d = 1..base-1; d = 0 is "no row", e = 0), digits uniform:
@@ -78,9 +86,27 @@ def predict(params, lwe_key, tlwe_key, ksk=None):
     pre = np.cumsum(v)
     Jv = 2.0 * pre - pre[-1]
     out = {}
-    out["br_var_rows"] = n * (1.0 - 1.0 / (2 * N)) * 2 * l * N * ((Bg * Bg + 2) / 12.0) * float(params.bk_stdev) ** 2
-    out["br_var_remainder"] = w * (1 + hw) * q * q / 12.0
-    out["br_var_truncation_bias"] = w * (q / 2) ** 2 * float((Jv**2).mean())
+    # (a) gaussian32 converts sigma * z to Torus32 by TRUNCATION toward zero (dtot32 = int32(int64(frac * 2^32)),
+    #     upstream's conversion): the stored noise is sign(x) floor(|x|), variance sigma^2 - sigma sqrt(2/pi) u + u^2/3 with
+    #     u = 2^-32 -- 2.6 % below sigma^2 for Set A's sigma_bk (30.8 units), 0.6 % for Set B's (128 units); measured on the
+    #     keys' rows: 0.9736 / 0.9924
+    u = 2.0**-32
+    sig = float(params.bk_stdev)
+    sig2 = sig * sig - sig * np.sqrt(2.0 / np.pi) * u + u * u / 3.0
+    # (b) until the first step with s_i = 1 has run, the accumulator is still the noiseless (0, X^-b testvector): its mask
+    #     polynomial decomposes to all-zero digits and its body to ~N/2 digits of 2 mu / h_1, so each of those i0 + 1 steps
+    #     adds about (N/2) (2 mu / h_1)^2 / (2l N E[d^2]) of a regular step's row noise (9 % for Set A), and the first active
+    #     step's remainder is exactly zero (no truncation term from it)
+    ones = np.flatnonzero(s)
+    i0 = int(ones[0]) if len(ones) else n
+    Ed2 = (Bg * Bg + 2) / 12.0
+    d_triv = (1 << 30) >> (32 - Bgbit) if Bgbit <= 30 else 0          # first digit of +-2 mu = 2^30
+    triv_frac = min(1.0, 0.5 * d_triv * d_triv / (2 * l * Ed2))
+    n_eff = (n - (i0 + 1) * (1.0 - triv_frac)) * (1.0 - 1.0 / (2 * N))
+    w_eff = max(w - 1, 0)
+    out["br_var_rows"] = n_eff * 2 * l * N * Ed2 * sig2
+    out["br_var_remainder"] = w_eff * (1 + hw) * q * q / 12.0
+    out["br_var_truncation_bias"] = w_eff * (q / 2) ** 2 * float((Jv**2).mean())
     out["br_var"] = out["br_var_rows"] + out["br_var_remainder"] + out["br_var_truncation_bias"]
     out["br_mean"] = -(q / 2) * float(Jv[0])
     out["br_var_textbook"] = (n * 2 * l * N * (Bg * Bg / 12.0) * float(params.bk_stdev) ** 2

@@ -59,11 +59,18 @@ def test_prediction_terms_setA_by_hand():
     s = np.zeros(500, np.int64); s[::2] = 1
     s1 = np.zeros(N, np.int64); s1[::2] = 1
     p = noise.predict(P, s, s1)
-    assert p["br_var_rows"] == pytest.approx(500 * 4 * 1024 * (1024**2 + 2) / 12 * 7.18e-9**2, rel=1e-3)   # 9.2e-6
-    assert p["br_var_remainder"] == pytest.approx(250 * 513 * 2.0**-40 / 12, rel=1e-12)                   # 9.7e-9
+    # rows: sigma^2 corrected for gaussian32's truncation toward zero (30.8 units: -2.6 %), and the one step (i0 = 0) that
+    # sees the noiseless accumulator counted at 0.5 * 256^2 / (4 * E[d^2]) = 9.4 % of a regular step
+    u = 2.0**-32
+    sig2 = 7.18e-9**2 - 7.18e-9 * np.sqrt(2 / np.pi) * u + u * u / 3
+    assert sig2 / 7.18e-9**2 == pytest.approx(0.9745, abs=2e-4)
+    ed2 = (1024**2 + 2) / 12
+    n_eff = (500 - 1 * (1 - 0.5 * 256**2 / (4 * ed2))) * (1 - 1 / 2048)
+    assert p["br_var_rows"] == pytest.approx(n_eff * 4 * 1024 * ed2 * sig2, rel=1e-12)                     # 8.97e-6
+    assert p["br_var_remainder"] == pytest.approx(249 * 513 * 2.0**-40 / 12, rel=1e-12)                   # 9.7e-9
     # alternating key: (J*(1-s'))[r] = 1 - (r//2 + 1) + (511 - r//2) = 511 - 2 (r//2): mean square ~ N^2/12
     jv = 511 - 2 * (np.arange(N) // 2)
-    assert p["br_var_truncation_bias"] == pytest.approx(250 * 2.0**-42 * (jv.astype(float)**2).mean(), rel=1e-12)
+    assert p["br_var_truncation_bias"] == pytest.approx(249 * 2.0**-42 * (jv.astype(float)**2).mean(), rel=1e-12)
     assert 4.5e-6 < p["br_var_truncation_bias"] < 5.5e-6
     assert p["br_mean"] == pytest.approx(-(2.0**-21) * 511, rel=1e-12)        # 1 + |s'| - 2 s'_0, s'_0 = 1
     assert p["ks_var_textbook"] == pytest.approx(1024 * 8 * 0.75 * 2.44e-5**2 + 512 * 2.0**-34 / 3, rel=1e-12)

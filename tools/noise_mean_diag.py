@@ -1,0 +1,111 @@
+"""Where the blind rotation's MEAN error comes from, sample by sample (Set A, one key, 262 144 NAND inputs on the GPU).
+
+Three deterministic mechanisms, all consequences of upstream's conventions, tested against the measured
+error of every sample:
+  1. the last step with s_i = 1 adds -(q/2)(1 + |s'| - 2 s'_0): nothing rotates it any more;
+  2. every earlier active step adds the same polynomial rotated by the remaining rotation rho_i -- zero on average, but
+     KNOWN per sample from the rotation amounts: the measured error regresses on this per-sample prediction with slope ~ 1
+     and correlation ~ 0.58 (a third of the variance is this deterministic truncation structure);
+  3. until the first s_i = 1 has run the accumulator is the noiseless (0, X^-barb testvector): its digits are the constant
+     +-2 mu / h_1 on a band next to the sign boundary, so those i0 + 1 steps add  (2 mu / h_1) * band * e_i  with the FIXED
+     row noise e_i of BK_i -- a key- and input-class-dependent term of the order of 100 units of q/2 that no average-case
+     formula contains; with it the model reproduces the measured mean overall and per input class.
+Usage (GPU box): python tools/noise_mean_diag.py [key seed]"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import eoc_tfhe_amd as eoc
+from eoc_tfhe_amd import noise
+N=1024
+pset, seed, count = 0, (int(sys.argv[1]) if len(sys.argv) > 1 else 5), 262144
+p = eoc.default_params(pset); sk = eoc.SecretKey(p, seed); eng = eoc.Engine(p); eng.load_cloud_key(sk)
+rng = np.random.default_rng(100 + pset)
+b0, b1 = rng.integers(0, 2, count), rng.integers(0, 2, count)
+c0, c1 = sk.encrypt_bits(b0, 4001 + pset), sk.encrypt_bits(b1, 4101 + pset)
+t = (-(c0.astype(np.int64) + c1.astype(np.int64))); t[:, -1] += 1 << 29
+t = (t & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+d_t = torch.from_numpy(t).cuda(); d_u = torch.empty((count, N + 1), dtype=torch.int32, device="cuda")
+eng.blind_rotate_device(d_t.data_ptr(), d_u.data_ptr(), count); torch.cuda.synchronize()
+u = d_u.cpu().numpy().astype(np.int64)
+s1 = sk.tlwe_key.astype(np.int64)
+phu = ((u[:, N] - u[:, :N] @ s1) + 2**31) % 2**32 - 2**31
+sign = np.where(phu > 0, 1, -1)
+e = (phu - sign * 2**29) / 2.0**32
+c = 2.0**-21
+bara = (((t.astype(np.int64) & 0xFFFFFFFF) + (1 << 20)) >> 21) & 2047
+lwe = sk.lwe_key
+ones = np.flatnonzero(lwe); last = ones[-1]
+print("last active", last, "n", p.n, "s'_0", s1[0], "hw", s1.sum(), "pred/c", -(1 + s1.sum() - 2 * s1[0]))
+def rep(mask, name):
+    x = e[mask]; print(f"{name:28s} n={mask.sum():7d} mean/c {x.mean()/c:9.1f} +- {x.std()/np.sqrt(len(x))/c:5.1f}")
+rep(np.ones(count, bool), "all")
+rep(sign > 0, "output +mu"); rep(sign < 0, "output -mu")
+al = bara[:, last]
+rep(al < N, "abar_last < N"); rep(al >= N, "abar_last >= N")
+for lo, hi in ((0,256),(256,512),(512,768),(768,1024),(1024,1280),(1280,1536),(1536,1792),(1792,2048)):
+    rep((al >= lo) & (al < hi), f"abar_last in [{lo},{hi})")
+bb = bara[:, p.n]
+rep(bb < N, "barb < N"); rep(bb >= N, "barb >= N")
+tot = (bb - (bara[:, :p.n] * lwe[None, :]).sum(1)) % (2 * N)
+for lo, hi in ((0,512),(512,1024),(1536,2048)):
+    rep((tot >= lo) & (tot < hi), f"total rotation in [{lo},{hi})")
+
+# ---- per-sample conditional mean from the truncation model: sum over active steps i of (X^rho_i M)[0] ----
+v = -s1.astype(np.float64); v[0] += 1.0
+pre = np.cumsum(v); Jv = 2.0 * pre - pre[-1]
+M = -Jv                                  # in units of c: M[r] = -(J*(1-s'))[r]
+act = ones
+A = bara[:, act].astype(np.int64)         # [count][w] rotation amounts of the active steps
+# rho_i = sum_{j > i} abar_j (mod 2N): reverse cumulative sum, exclusive
+rc = np.cumsum(A[:, ::-1], axis=1)[:, ::-1]
+rho = (rc - A) % (2 * N)
+# (X^rho M)[0]: rho = 0 -> M[0]; 0 < rho < N -> -M[N - rho]; rho = N -> -M[0]; N < rho < 2N -> +M[2N - rho]
+idx = np.where(rho == 0, 0, np.where(rho < N, N - rho, np.where(rho == N, 0, 2 * N - rho)))
+sgn = np.where(rho == 0, 1.0, np.where(rho < N, -1.0, np.where(rho == N, -1.0, 1.0)))
+contrib = sgn * M[idx]
+skip_first = contrib.copy(); skip_first[:, 0] = 0.0     # the first active step has zero remainder (noiseless accumulator)
+cm = skip_first.sum(1)
+print("model: mean of the per-sample conditional means / c =", cm.mean(), "(last step alone:", M[0], ")")
+x = cm - cm.mean(); y = e / c - (e / c).mean()
+slope = (x * y).sum() / (x * x).sum()
+print("regression of the measured error on the model's conditional mean: slope", slope, "corr", np.corrcoef(cm, e)[0, 1],
+      " model std/c", cm.std(), " measured std/c", (e / c).std())
+for lo, hi in ((0,512),(512,1024),(1536,2048)):
+    m = (tot >= lo) & (tot < hi)
+    print(f"class total rotation [{lo},{hi}): model {cm[m].mean():8.1f}  measured {e[m].mean()/c:8.1f}")
+
+# ---- the early steps: until the first s_i = 1 has run the accumulator is the noiseless (0, X^-barb tv); its digits are
+# the CONSTANT +-256 on a band, so those steps add a deterministic (key- and rotation-dependent) term: 256 * band * e_i ----
+sub = slice(0, 65536)
+i0 = int(ones[0])
+bk = sk.bk.reshape(p.n, 2 * p.l, 2, N)
+S = np.zeros((N, N))
+for m_ in range(N):
+    col = np.roll(s1.astype(np.float64), m_).copy(); col[:m_] *= -1; S[m_, :] = col
+early = np.zeros(65536)
+jj = np.arange(N)[None, :]
+bb_ = bara[sub, p.n][:, None]
+for i in range(i0 + 1):
+    row = p.l * 1 + 0                                  # row (q = 1, p = 1)
+    a_, b_ = bk[i, row, 0].astype(np.float64), bk[i, row, 1].astype(np.int64)
+    ph = b_ - np.rint(a_ @ S).astype(np.int64)
+    if lwe[i]:
+        ph[0] -= 1 << (32 - p.Bgbit)                    # message s_i h_1 on the body's constant coefficient
+    ei = (((ph + 2**31) % 2**32) - 2**31) / 2.0**32 / c  # noise of the row, units of c
+    ext = np.concatenate(([ei[0]], -ei[:0:-1], [-ei[0]], ei[:0:-1]))   # (X^k e)[0], k in [0, 2N)
+    ab = bara[sub, i][:, None]
+    # m_j: coefficient j of X^(2N - barb) tv  (k_j = +1 / -1), then D = X^abar m - m, digit = 256 * D / (2 mu)
+    def mcoef(j):                                        # sign of coefficient j (any integer, 2N-periodic negacyclic extension)
+        return np.where(((j - (2 * N - bb_)) % (2 * N)) < N, 1, -1)
+    k = (mcoef(jj - ab) - mcoef(jj)) // 2               # in {-1, 0, 1}
+    rho_i = (A[sub][:, (act > i)].sum(1) % (2 * N))[:, None]
+    early += 256.0 * (k * ext[(jj + rho_i) % (2 * N)]).sum(1)
+print("early steps: i0 =", i0, " mean of the early term / c", early.mean(), " std / c", early.std())
+cm2 = cm[sub] + early
+y2 = e[sub] / c
+print("measured mean / c on this subset", y2.mean(), " model (truncation + early)", cm2.mean())
+x = early - early.mean(); yy = (y2 - cm[sub]); yy = yy - yy.mean()
+print("regression of (measured - truncation model) on the early term: slope", (x * yy).sum() / (x * x).sum(), "corr", np.corrcoef(early, y2 - cm[sub])[0, 1])
+for lo, hi in ((0,512),(512,1024),(1536,2048)):
+    mk = (tot[sub] >= lo) & (tot[sub] < hi)
+    print(f"class [{lo},{hi}): model+early {cm2[mk].mean():8.1f}  measured {y2[mk].mean():8.1f} +- {y2[mk].std()/np.sqrt(mk.sum()):5.1f}")
