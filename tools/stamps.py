@@ -41,6 +41,10 @@ names = {0: "rotate-diff (acc reads)", 1: "BK loads issue + digits + twist", 2: 
          9: "untwist + round + acc update", 15: "loop top (bara load)"}
 if WIDE:
     names = wide_names
+    if pset == 1:
+        names = {0: "rotation + digit words + parking", 1: "forward pair (0,1) (0,2)", 2: "forward pair (0,3) (1,1)",
+                 3: "chain phase A (5 rows)", 4: "single forward (1,2)", 5: "chain phase B (2 rows)", 6: "single forward (1,3)",
+                 7: "chain phase C (5 rows)", 8: "fetch + inverse pair", 9: "untwist + round + acc update", 15: "loop top (bara load)"}
 meta = buf[:, 11:15].copy()
 buf[:, 11:15] = 0
 tot = buf.sum(axis=1).astype(np.float64)

@@ -1,4 +1,5 @@
-"""Pair kernel against the one-wave-per-ciphertext kernel over launch widths (Set A, device-pointer API, NAND).
+"""Pair kernel against the one-wave-per-ciphertext kernel over launch widths (device-pointer API, NAND; PSET=0 Set A, 1 Set B;
+PARTS="1,2,3": also the forced wide kernel with the blind rotation cut into that many consecutive launches).
 Usage (GPU box): python tools/wide_sweep.py [duty ...]   -- each duty is an EOC_TFHE_PRIO_DUTY value for the wide kernel
 (default: the built-in alternation).  Prints ms per call and bootstraps/s; every result is decrypt-checked and the two
 kernels' outputs are compared bit for bit."""
@@ -12,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eoc_tfhe_amd as eoc  # noqa: E402
 
-p = eoc.default_params(0)
+p = eoc.default_params(int(os.environ.get("PSET", "0")))
 sk = eoc.SecretKey(p, 1)
 WIDTHS = [int(x) for x in os.environ.get("WIDTHS", "1024,1280,1536,2048,3072,4096,6144,8192,16384").split(",")]
 G = max(WIDTHS)
@@ -27,8 +28,11 @@ for d in duties:
     if d:
         env["EOC_TFHE_PRIO_DUTY"] = d
     modes.append((f"wide duty={d or 'default'}", env))
+for parts in [x for x in os.environ.get("PARTS", "").split(",") if x]:
+    modes.append((f"wide parts={parts}", {"EOC_TFHE_BR_WIDE": "1", "EOC_TFHE_BR_PARTS": parts}))
+    modes.append((f"pair parts={parts}", {"EOC_TFHE_BR_WIDE": "0", "EOC_TFHE_BR_PARTS": parts}))
 for name, env in modes:
-    for k in ("EOC_TFHE_BR_WIDE", "EOC_TFHE_PRIO_DUTY"):
+    for k in ("EOC_TFHE_BR_WIDE", "EOC_TFHE_PRIO_DUTY", "EOC_TFHE_BR_PARTS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     eng = eoc.Engine(p)
