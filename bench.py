@@ -458,16 +458,21 @@ def main():
         engine.keyswitch_device(d_u.data_ptr(), d_o.data_ptr(), cnt, stream=stream)
         torch.cuda.synchronize()
         pred = noise.predict(params, key.lwe_key, key.tlwe_key, key.ksk)
-        r = noise.compare(pred, *noise.measure(d_u.cpu().numpy(), d_o.cpu().numpy(), key.lwe_key, key.tlwe_key))
+        e_br, e_ks, e_tot = noise.measure(d_u.cpu().numpy(), d_o.cpu().numpy(), key.lwe_key, key.tlwe_key)
+        r = noise.compare(pred, e_br, e_ks, e_tot)
+        # sample by sample: the error against the truncation model's conditional mean (public rotation amounts + the key)
+        r.update(noise.regress(e_br, noise.br_conditional_mean(params, key.lwe_key, key.tlwe_key, t), pred))
         keep = ("count", "br_var", "br_var_pred", "br_ratio", "br_mean", "br_mean_pred", "ks_var", "ks_var_pred", "ks_ratio",
-                "ks_mean", "ks_mean_pred", "total_std", "total_std_pred", "br_ratio_textbook", "ks_ratio_textbook")
+                "ks_mean", "ks_mean_pred", "total_std", "total_std_pred", "br_ratio_textbook", "ks_ratio_textbook",
+                "br_cm_slope", "br_cm_corr", "br_cm_corr_pred")
         out = {k: (float(f"{r[k]:.4g}") if isinstance(r[k], float) else r[k]) for k in keep}
         out["within_window"] = bool(0.8 < r["br_ratio"] < 1.25 and 0.8 < r["ks_ratio"] < 1.25 and abs(r["br_mean_z"]) < 5
                                     and abs(r["ks_mean_z"]) < 5)
         out["note"] = ("variance of the phase error of the blind rotation's output under the extracted key (br_*) and of what "
                        "the key switch adds (ks_*), torus units, against the per-key CGGI prediction of eoc_tfhe_amd/noise.py; "
                        "*_ratio_textbook = against the average-case formula with a ROUNDING decomposition / the average-over-"
-                       "keys key switch, which this algorithm is NOT (upstream truncates: 1.5x / 0.75x)")
+                       "keys key switch, which this algorithm is NOT (upstream truncates: 1.5x / 0.75x); br_cm_* = regression of every sample's "
+                       "error on the truncation model's conditional mean (slope 1, correlation sqrt(V_truncation / V_BR) expected)")
         return out
 
     def make_config3_block():

@@ -128,6 +128,55 @@ def predict(params, lwe_key, tlwe_key, ksk=None):
     return out
 
 
+def rotation_amounts(t_rows):
+    """modSwitchFromTorus32(., 2N) of every word of the LWE samples `t_rows` [count][n+1]: the blind
+    rotation's abar_0..abar_{n-1} and barb (last column)."""
+    t = np.asarray(t_rows, np.int64) & 0xFFFFFFFF
+    return ((t + (1 << 20)) >> 21) & (2 * N - 1)
+
+
+def br_conditional_mean(params, lwe_key, tlwe_key, t_rows):
+    """What the truncating decomposition adds to EACH sample, given only public data and the key: sum over the steps with
+    s_i = 1 (the first one excepted: its accumulator is noiseless, its remainder exactly zero) of coefficient 0 of
+    X^rho_i * M, M = -(q/2) J*(1 - s'), rho_i = sum of the LATER active steps' rotation amounts (mod 2N).  [count] torus units.
+
+    The measured error of a sample regresses on this with slope 1 and correlation sqrt(V_truncation / V_BR) (0.58 for
+    Set A): a sample-by-sample check of the order in which the steps' rotations accumulate and of the remainder's sign
+    and size -- which the variance alone does not see (steps taken in the opposite order give slope 0, a remainder of the
+    other sign slope -1; the rotation's DIRECTION is not resolved: M is antisymmetric about N/2 to leading order)."""
+    n, l, Bgbit = int(params.n), int(params.l), int(params.Bgbit)
+    s = np.asarray(lwe_key, np.int64)
+    s1 = np.asarray(tlwe_key, np.int64)
+    q = 2.0 ** (-l * Bgbit)
+    v = -s1.astype(np.float64)
+    v[0] += 1.0
+    pre = np.cumsum(v)
+    M = -(q / 2) * (2.0 * pre - pre[-1])
+    act = np.flatnonzero(s)
+    A = rotation_amounts(t_rows)[:, :n][:, act]
+    rc = np.cumsum(A[:, ::-1], axis=1)[:, ::-1]
+    rho = (rc - A) % (2 * N)
+    # (X^rho M)[0]: rho = 0 -> M[0]; 0 < rho < N -> -M[N - rho]; rho = N -> -M[0]; N < rho < 2N -> +M[2N - rho]
+    idx = np.where(rho % N == 0, 0, np.where(rho < N, N - rho, 2 * N - rho))
+    sgn = np.where(rho == 0, 1.0, np.where(rho <= N, -1.0, 1.0))
+    contrib = sgn * M[idx]
+    contrib[:, :1] = 0.0
+    return contrib.sum(1)
+
+
+def regress(e_br, cond_mean, pred=None):
+    """slope / correlation of the measured blind-rotation error on its per-sample conditional mean (+ the correlation the
+    prediction implies and the slope's standard error)"""
+    x = cond_mean - cond_mean.mean()
+    y = e_br - e_br.mean()
+    r = float((x * y).sum() / np.sqrt((x * x).sum() * (y * y).sum()))
+    out = {"br_cm_slope": float((x * y).sum() / (x * x).sum()), "br_cm_corr": r,
+           "br_cm_slope_se": float(np.sqrt(max(1.0 - r * r, 0.0) / max(r * r, 1e-30) / len(x)))}
+    if pred is not None:
+        out["br_cm_corr_pred"] = float(np.sqrt(pred["br_var_truncation_bias"] / pred["br_var"]))
+    return out
+
+
 def measure(u, out, lwe_key, tlwe_key):
     """errors of blind-rotation outputs `u` [count][N+1] under the extracted key and of the key-switched
     samples `out` [count][n+1] under the LWE key, against the nearest of +-1/8.  Returns (e_br, e_ks, e_total) in

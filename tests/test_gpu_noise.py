@@ -50,7 +50,10 @@ def run_noise(eoc, pset, count=COUNT, seed=1):
     sync()
     assert np.array_equal(d_g.cpu().numpy(), out)
     pred = noise.predict(p, sk.lwe_key, sk.tlwe_key, sk.ksk)
-    return noise.compare(pred, *noise.measure(u, out, sk.lwe_key, sk.tlwe_key))
+    e_br, e_ks, e_tot = noise.measure(u, out, sk.lwe_key, sk.tlwe_key)
+    r = noise.compare(pred, e_br, e_ks, e_tot)
+    r.update(noise.regress(e_br, noise.br_conditional_mean(p, sk.lwe_key, sk.tlwe_key, t), pred))
+    return r
 
 
 @pytest.mark.parametrize("pset,seed", [(0, 1), (1, 1), (0, 5)], ids=["setA", "setB", "setA-key5"])
@@ -69,6 +72,11 @@ def test_gpu_noise_matches_prediction(eoc, pset, seed):
         if abs(r[part + "_mean_pred"]) > 8 * se:
             assert abs(r[part + "_mean"]) > 4 * se and r[part + "_mean"] * r[part + "_mean_pred"] > 0, (part, r)
     assert r["max_abs_err"] < 1 / 16
+    # sample by sample: the error regresses on the truncation model's conditional mean (known from the public rotation
+    # amounts and the key) with slope 1 and the predicted correlation -- the order in which the steps' rotations accumulate,
+    # sign and size of the remainder; the opposite order gives slope 0 (tests/test_noise_cpu.py; standard error 0.011 / 0.014)
+    assert 0.93 < r["br_cm_slope"] < 1.07, r
+    assert abs(r["br_cm_corr"] - r["br_cm_corr_pred"]) < 0.04, r
     # the nearest neighbours are excluded: rounding decomposition (textbook formula) 1.53x (A) / 1.33x (B),
     # average-over-keys key switch 0.75x
     assert r["br_ratio_textbook"] > 1.2 and r["ks_ratio_textbook"] < 0.82, r

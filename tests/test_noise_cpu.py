@@ -32,20 +32,32 @@ def _measure(o, count, seed):
         u = np.stack(list(ex.map(o.blind_rotate_extract, t)))
         out = np.stack(list(ex.map(o.keyswitch, u)))
     assert np.array_equal(o.decrypt_bits(out), 1 - (b0 & b1))
-    return noise.measure(u, out, o.lwe_key, o.tlwe_key)
+    return noise.measure(u, out, o.lwe_key, o.tlwe_key), np.stack(t)
 
 
 @pytest.mark.parametrize("pset", [0, 1], ids=["setA", "setB"])
 def test_oracle_noise_matches_prediction(pset):
     o = ol.Oracle(pset, 1)
     pred = noise.predict(o.p, o.lwe_key, o.tlwe_key, o.ksk)
-    r = noise.compare(pred, *_measure(o, COUNT, 7 + pset))
+    (e_br, e_ks, e_tot), t = _measure(o, COUNT, 7 + pset)
+    r = noise.compare(pred, e_br, e_ks, e_tot)
+    r.update(noise.regress(e_br, noise.br_conditional_mean(o.p, o.lwe_key, o.tlwe_key, t), pred))
     print({k: (f"{v:.4e}" if isinstance(v, float) else v) for k, v in r.items()})
     assert 0.8 < r["br_ratio"] < 1.25, r          # blind rotation: rows + remainder + truncation-bias terms
     assert 0.8 < r["ks_ratio"] < 1.25, r          # key switch, this key's rows
     assert abs(r["br_mean_z"]) < 5 and abs(r["ks_mean_z"]) < 5, r     # both means are predicted, not just "small"
     assert abs(r["ks_mean"]) > 4 * np.sqrt(r["ks_var"] / r["count"])  # ... and the key switch's is resolvably non-zero
     assert r["max_abs_err"] < 1 / 16
+    # sample by sample (noise.br_conditional_mean): slope 1 on the truncation model's conditional mean, standard error
+    # 0.036 (A) / 0.044 (B) at this sample size
+    assert 0.78 < r["br_cm_slope"] < 1.22, r
+    assert abs(r["br_cm_corr"] - r["br_cm_corr_pred"]) < 0.1, r
+    # negative control: the steps taken in the opposite order (rho_i from the EARLIER steps) -- slope 0.  (Running the
+    # rotation backwards is no control: M is antisymmetric about N/2 to leading order, (X^-rho M)[0] ~ (X^rho M)[0].)
+    t64 = t.astype(np.int64)
+    body = t64[:, :-1][:, ::-1]
+    flip = noise.regress(e_br, noise.br_conditional_mean(o.p, o.lwe_key[::-1], o.tlwe_key, np.concatenate([body, t64[:, -1:]], 1)))
+    assert abs(flip["br_cm_slope"]) < 0.25, flip
     # the measurement separates this algorithm from its nearest neighbours: against the average-case textbook formula
     # (a ROUNDING decomposition) the blind rotation is 1.53x (A) / 1.33x (B) too noisy, against the average-over-keys
     # key-switch formula this key's rows are 0.75x
