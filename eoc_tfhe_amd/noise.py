@@ -164,6 +164,53 @@ def br_conditional_mean(params, lwe_key, tlwe_key, t_rows):
     return contrib.sum(1)
 
 
+def br_early_term(params, lwe_key, tlwe_key, bk, t_rows, mu=1 << 29, chunk=16384):
+    """The steps up to and including the first one with s_i = 1 see the noiseless accumulator (0, X^-barb testvector): the
+    digits of (X^abar - 1) ACC are the CONSTANT +-2 mu / h_1 on a band (first digit of the body polynomial only), so each of
+    those steps adds  (2 mu / h_1) * sum_band +-e_i  with the FIXED noise e_i of row (q = 1, p = 1) of BK_i, rotated by the later
+    active steps.  Deterministic given the key and the public rotation amounts; zero over uniform rotations, ~ 100 (q/2) over
+    NAND's three phase classes.  `bk` = the torus rows [n][2l][2][N] (SecretKey.bk).  [count] torus units.
+    (Exact for i0 = 0; for i0 > 0 the accumulator already carries the inactive steps' row noise, far below one digit.)"""
+    n, l, Bgbit = int(params.n), int(params.l), int(params.Bgbit)
+    s = np.asarray(lwe_key, np.int64)
+    s1 = np.asarray(tlwe_key, np.int64)
+    bk = np.asarray(bk).reshape(n, 2 * l, 2, N)
+    ones = np.flatnonzero(s)
+    bara = rotation_amounts(t_rows)
+    out = np.zeros(bara.shape[0])
+    if not len(ones):
+        return out
+    i0 = int(ones[0])
+    dig = float((2 * mu) >> (32 - Bgbit))
+    S = np.zeros((N, N))                                   # a @ S = a * s' in Z[X]/(X^N + 1)
+    for m_ in range(N):
+        col = np.roll(s1.astype(np.float64), m_)
+        col[:m_] *= -1
+        S[m_, :] = col
+    ext = []
+    for i in range(i0 + 1):
+        a_, b_ = bk[i, l, 0].astype(np.float64), bk[i, l, 1].astype(np.int64)   # row (q = 1, p = 1)
+        ph = b_ - np.rint(a_ @ S).astype(np.int64)
+        if s[i]:
+            ph[0] -= 1 << (32 - Bgbit)                      # the row's message: s_i h_1 on the body's constant coefficient
+        ei = _wrap32(ph) / 2.0**32
+        ext.append(np.concatenate(([ei[0]], -ei[:0:-1], [-ei[0]], ei[:0:-1])))   # (X^k e_i)[0], k in [0, 2N)
+    jj = np.arange(N)[None, :]
+    act_after = [ones[ones > i] for i in range(i0 + 1)]
+    for lo in range(0, bara.shape[0], chunk):
+        B = bara[lo:lo + chunk]
+        bb = B[:, n][:, None]
+
+        def sign_of(j):                                     # coefficient j of X^(2N - barb) testvector, 2N-periodic extension
+            return np.where(((j - (2 * N - bb)) % (2 * N)) < N, 1, -1)
+        for i in range(i0 + 1):
+            ab = B[:, i][:, None]
+            k = (sign_of(jj - ab) - sign_of(jj)) // 2
+            rho = (B[:, act_after[i]].sum(1) % (2 * N))[:, None]
+            out[lo:lo + chunk] += dig * (k * ext[i][(jj + rho) % (2 * N)]).sum(1)
+    return out
+
+
 def regress(e_br, cond_mean, pred=None):
     """slope / correlation of the measured blind-rotation error on its per-sample conditional mean (+ the correlation the
     prediction implies and the slope's standard error)"""
@@ -175,6 +222,14 @@ def regress(e_br, cond_mean, pred=None):
     if pred is not None:
         out["br_cm_corr_pred"] = float(np.sqrt(pred["br_var_truncation_bias"] / pred["br_var"]))
     return out
+
+
+def residual_mean(e_br, cond_mean, early=None):
+    """mean of what the per-sample model leaves of the blind rotation's error (measured - conditional mean - early term), and
+    its z: the sharpest mean test there is -- the model removes a third of the variance and all of the known bias"""
+    res = e_br - cond_mean - (0.0 if early is None else early)
+    return {"br_resid_mean": float(res.mean()), "br_resid_z": float(res.mean() / (res.std() / np.sqrt(len(res)))),
+            "br_model_mean": float((cond_mean + (0.0 if early is None else early)).mean())}
 
 
 def measure(u, out, lwe_key, tlwe_key):

@@ -52,7 +52,9 @@ def run_noise(eoc, pset, count=COUNT, seed=1):
     pred = noise.predict(p, sk.lwe_key, sk.tlwe_key, sk.ksk)
     e_br, e_ks, e_tot = noise.measure(u, out, sk.lwe_key, sk.tlwe_key)
     r = noise.compare(pred, e_br, e_ks, e_tot)
-    r.update(noise.regress(e_br, noise.br_conditional_mean(p, sk.lwe_key, sk.tlwe_key, t), pred))
+    cm = noise.br_conditional_mean(p, sk.lwe_key, sk.tlwe_key, t)
+    r.update(noise.regress(e_br, cm, pred))
+    r.update(noise.residual_mean(e_br, cm, noise.br_early_term(p, sk.lwe_key, sk.tlwe_key, sk.bk, t)))
     return r
 
 
@@ -77,6 +79,8 @@ def test_gpu_noise_matches_prediction(eoc, pset, seed):
     # sign and size of the remainder; the opposite order gives slope 0 (tests/test_noise_cpu.py; standard error 0.011 / 0.014)
     assert 0.93 < r["br_cm_slope"] < 1.07, r
     assert abs(r["br_cm_corr"] - r["br_cm_corr_pred"]) < 0.04, r
+    # ... and what the per-sample model (truncation + the early steps' fixed row noise) leaves has zero mean
+    assert abs(r["br_resid_z"]) < 5, r
     # the nearest neighbours are excluded: rounding decomposition (textbook formula) 1.53x (A) / 1.33x (B),
     # average-over-keys key switch 0.75x
     assert r["br_ratio_textbook"] > 1.2 and r["ks_ratio_textbook"] < 0.82, r

@@ -41,7 +41,9 @@ def test_oracle_noise_matches_prediction(pset):
     pred = noise.predict(o.p, o.lwe_key, o.tlwe_key, o.ksk)
     (e_br, e_ks, e_tot), t = _measure(o, COUNT, 7 + pset)
     r = noise.compare(pred, e_br, e_ks, e_tot)
-    r.update(noise.regress(e_br, noise.br_conditional_mean(o.p, o.lwe_key, o.tlwe_key, t), pred))
+    cm = noise.br_conditional_mean(o.p, o.lwe_key, o.tlwe_key, t)
+    r.update(noise.regress(e_br, cm, pred))
+    r.update(noise.residual_mean(e_br, cm, noise.br_early_term(o.p, o.lwe_key, o.tlwe_key, o.bk, t)))
     print({k: (f"{v:.4e}" if isinstance(v, float) else v) for k, v in r.items()})
     assert 0.8 < r["br_ratio"] < 1.25, r          # blind rotation: rows + remainder + truncation-bias terms
     assert 0.8 < r["ks_ratio"] < 1.25, r          # key switch, this key's rows
@@ -52,6 +54,7 @@ def test_oracle_noise_matches_prediction(pset):
     # 0.036 (A) / 0.044 (B) at this sample size
     assert 0.78 < r["br_cm_slope"] < 1.22, r
     assert abs(r["br_cm_corr"] - r["br_cm_corr_pred"]) < 0.1, r
+    assert abs(r["br_resid_z"]) < 5, r            # what the per-sample model leaves has zero mean
     # negative control: the steps taken in the opposite order (rho_i from the EARLIER steps) -- slope 0.  (Running the
     # rotation backwards is no control: M is antisymmetric about N/2 to leading order, (X^-rho M)[0] ~ (X^rho M)[0].)
     t64 = t.astype(np.int64)

@@ -20,4 +20,6 @@ for pset, name, seed in [(ps, nm, sd) for sd in seeds for ps, nm in ((0, "A"), (
     print(f"set {name}: count {count}  BR var {r['br_var']:.5e} / pred {r['br_var_pred']:.5e} = {r['br_ratio']:.4f} (+-{se:.4f})  "
           f"KS var {r['ks_var']:.5e} / pred {r['ks_var_pred']:.5e} = {r['ks_ratio']:.4f}  "
           f"BR mean {r['br_mean']:.4e} / pred {r['br_mean_pred']:.4e} (z {r['br_mean_z']:+.2f})  "
-          f"KS mean {r['ks_mean']:.4e} / pred {r['ks_mean_pred']:.4e} (z {r['ks_mean_z']:+.2f})", flush=True)
+          f"KS mean {r['ks_mean']:.4e} / pred {r['ks_mean_pred']:.4e} (z {r['ks_mean_z']:+.2f})  "
+          f"per-sample model: slope {r['br_cm_slope']:.4f} corr {r['br_cm_corr']:.4f} (pred {r['br_cm_corr_pred']:.4f})  "
+          f"model mean {r['br_model_mean']:.4e}, residual z {r['br_resid_z']:+.2f}", flush=True)

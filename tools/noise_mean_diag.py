@@ -50,62 +50,28 @@ tot = (bb - (bara[:, :p.n] * lwe[None, :]).sum(1)) % (2 * N)
 for lo, hi in ((0,512),(512,1024),(1536,2048)):
     rep((tot >= lo) & (tot < hi), f"total rotation in [{lo},{hi})")
 
-# ---- per-sample conditional mean from the truncation model: sum over active steps i of (X^rho_i M)[0] ----
-v = -s1.astype(np.float64); v[0] += 1.0
-pre = np.cumsum(v); Jv = 2.0 * pre - pre[-1]
-M = -Jv                                  # in units of c: M[r] = -(J*(1-s'))[r]
-act = ones
-A = bara[:, act].astype(np.int64)         # [count][w] rotation amounts of the active steps
-# rho_i = sum_{j > i} abar_j (mod 2N): reverse cumulative sum, exclusive
-rc = np.cumsum(A[:, ::-1], axis=1)[:, ::-1]
-rho = (rc - A) % (2 * N)
-# (X^rho M)[0]: rho = 0 -> M[0]; 0 < rho < N -> -M[N - rho]; rho = N -> -M[0]; N < rho < 2N -> +M[2N - rho]
-idx = np.where(rho == 0, 0, np.where(rho < N, N - rho, np.where(rho == N, 0, 2 * N - rho)))
-sgn = np.where(rho == 0, 1.0, np.where(rho < N, -1.0, np.where(rho == N, -1.0, 1.0)))
-contrib = sgn * M[idx]
-skip_first = contrib.copy(); skip_first[:, 0] = 0.0     # the first active step has zero remainder (noiseless accumulator)
-cm = skip_first.sum(1)
-print("model: mean of the per-sample conditional means / c =", cm.mean(), "(last step alone:", M[0], ")")
-x = cm - cm.mean(); y = e / c - (e / c).mean()
-slope = (x * y).sum() / (x * x).sum()
-print("regression of the measured error on the model's conditional mean: slope", slope, "corr", np.corrcoef(cm, e)[0, 1],
+# ---- per-sample conditional mean from the truncation model (eoc_tfhe_amd/noise.py): sum over active steps i of (X^rho_i M)[0] ----
+from eoc_tfhe_amd import noise  # noqa: E402
+cm = noise.br_conditional_mean(p, lwe, s1, t) / c
+print("model: mean of the per-sample conditional means / c =", cm.mean(), "(last step alone:", -(1 + s1.sum() - 2 * s1[0]), ")")
+rg = noise.regress(e, cm * c)
+print("regression of the measured error on the model's conditional mean: slope", rg["br_cm_slope"], "corr", rg["br_cm_corr"],
       " model std/c", cm.std(), " measured std/c", (e / c).std())
 for lo, hi in ((0,512),(512,1024),(1536,2048)):
     m = (tot >= lo) & (tot < hi)
     print(f"class total rotation [{lo},{hi}): model {cm[m].mean():8.1f}  measured {e[m].mean()/c:8.1f}")
 
-# ---- the early steps: until the first s_i = 1 has run the accumulator is the noiseless (0, X^-barb tv); its digits are
-# the CONSTANT +-256 on a band, so those steps add a deterministic (key- and rotation-dependent) term: 256 * band * e_i ----
-sub = slice(0, 65536)
-i0 = int(ones[0])
-bk = sk.bk.reshape(p.n, 2 * p.l, 2, N)
-S = np.zeros((N, N))
-for m_ in range(N):
-    col = np.roll(s1.astype(np.float64), m_).copy(); col[:m_] *= -1; S[m_, :] = col
-early = np.zeros(65536)
-jj = np.arange(N)[None, :]
-bb_ = bara[sub, p.n][:, None]
-for i in range(i0 + 1):
-    row = p.l * 1 + 0                                  # row (q = 1, p = 1)
-    a_, b_ = bk[i, row, 0].astype(np.float64), bk[i, row, 1].astype(np.int64)
-    ph = b_ - np.rint(a_ @ S).astype(np.int64)
-    if lwe[i]:
-        ph[0] -= 1 << (32 - p.Bgbit)                    # message s_i h_1 on the body's constant coefficient
-    ei = (((ph + 2**31) % 2**32) - 2**31) / 2.0**32 / c  # noise of the row, units of c
-    ext = np.concatenate(([ei[0]], -ei[:0:-1], [-ei[0]], ei[:0:-1]))   # (X^k e)[0], k in [0, 2N)
-    ab = bara[sub, i][:, None]
-    # m_j: coefficient j of X^(2N - barb) tv  (k_j = +1 / -1), then D = X^abar m - m, digit = 256 * D / (2 mu)
-    def mcoef(j):                                        # sign of coefficient j (any integer, 2N-periodic negacyclic extension)
-        return np.where(((j - (2 * N - bb_)) % (2 * N)) < N, 1, -1)
-    k = (mcoef(jj - ab) - mcoef(jj)) // 2               # in {-1, 0, 1}
-    rho_i = (A[sub][:, (act > i)].sum(1) % (2 * N))[:, None]
-    early += 256.0 * (k * ext[(jj + rho_i) % (2 * N)]).sum(1)
-print("early steps: i0 =", i0, " mean of the early term / c", early.mean(), " std / c", early.std())
-cm2 = cm[sub] + early
-y2 = e[sub] / c
-print("measured mean / c on this subset", y2.mean(), " model (truncation + early)", cm2.mean())
-x = early - early.mean(); yy = (y2 - cm[sub]); yy = yy - yy.mean()
-print("regression of (measured - truncation model) on the early term: slope", (x * yy).sum() / (x * x).sum(), "corr", np.corrcoef(early, y2 - cm[sub])[0, 1])
+# ---- the early steps (noise.br_early_term): until the first s_i = 1 has run the accumulator is the noiseless
+# (0, X^-barb tv); its digits are the CONSTANT +-2 mu / h_1 on a band, so those steps add a deterministic term ----
+early = noise.br_early_term(p, lwe, s1, sk.bk, t) / c
+print("early steps: i0 =", int(ones[0]), " mean of the early term / c", early.mean(), " std / c", early.std())
+cm2 = cm + early
+y2 = e / c
+se = y2.std() / np.sqrt(count)
+print(f"measured mean / c {y2.mean():.1f} +- {se:.1f}   model (truncation + early) {cm2.mean():.1f}   z {(y2.mean() - cm2.mean()) / se:+.2f}"
+      f"   (truncation alone: z {(y2.mean() - cm.mean()) / se:+.2f})")
+x = early - early.mean(); yy = (y2 - cm); yy = yy - yy.mean()
+print("regression of (measured - truncation model) on the early term: slope", (x * yy).sum() / (x * x).sum(), "corr", np.corrcoef(early, y2 - cm)[0, 1])
 for lo, hi in ((0,512),(512,1024),(1536,2048)):
-    mk = (tot[sub] >= lo) & (tot[sub] < hi)
+    mk = (tot >= lo) & (tot < hi)
     print(f"class [{lo},{hi}): model+early {cm2[mk].mean():8.1f}  measured {y2[mk].mean():8.1f} +- {y2[mk].std()/np.sqrt(mk.sum()):5.1f}")
