@@ -877,8 +877,15 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
             run = (k && ops[k] == ops[k - 1]) ? run + 1 : 1;
             if (!gather) max_jobs = std::max(max_jobs, run * (ops[k] == OP_MUX ? 2 : 1));
         }
-        if (gather)
-            for (int o = 0; o <= OP_CONST1; o++) max_jobs = std::max(max_jobs, cnt_op[o] * (o == OP_MUX ? 2 : 1));
+        if (gather) { // the two-input opcodes run as ONE level (OP_MULTI), MUX as another
+            size_t two_input = 0;
+            for (int o = 0; o < OP_MUX; o++) two_input += cnt_op[o];
+            max_jobs = std::max(two_input, 2 * cnt_op[OP_MUX]);
+        }
+    }
+    if (gather && count > (size_t)kPermIndexMask) {
+        eoc_set_error("eoc_gate_batch_device: a mixed batch holds at most %u gates", kPermIndexMask);
+        return EOC_ERR_ARG;
     }
     int rc = ensure_ws(e, W, max_jobs, 2 * (gather ? OP_CONST1 + 1 : runs) + 64, gather ? count : 0, st);
     if (rc) return rc;
@@ -912,7 +919,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         sorted_ops.resize(count);
         for (size_t k = 0; k < count; k++) {
             size_t pos = bucket[ops[k]]++;
-            perm[pos] = (uint32_t)k;
+            perm[pos] = (uint32_t)k | ((uint32_t)ops[k] << 28); // index | opcode: k_gather_rows masks, OP_MULTI reads the top
             sorted_ops[pos] = ops[k];
         }
         int32_t *g0 = W.d_mixed, *g1 = g0 + count * stride, *g2 = g1 + count * stride, *go = g2 + count * stride;
@@ -930,6 +937,21 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         run_ops = sorted_ops.data();
     }
     size_t i = 0;
+    if (gather) {
+        // opcode-sorted: the rows of the ten two-input opcodes come first and differ only in their linear stage -- one
+        // level over all of them (a run of its own per opcode would end each in a partly filled launch)
+        size_t j = 0;
+        while (j < count && run_ops[j] < OP_MUX) j++;
+        if (j > 0 && run_ops[0] != run_ops[j - 1]) {
+            GateDesc d{OP_MULTI, 0, in0, in1, reinterpret_cast<const int32_t *>(d_perm), out};
+            boot.clear();
+            freeg.clear();
+            boot.push_back(d);
+            rc = run_level(e, W, boot, freeg, j, st);
+            if (rc) return rc;
+            i = j;
+        }
+    }
     while (i < count) {
         size_t j = i;
         while (j < count && run_ops[j] == run_ops[i]) j++;

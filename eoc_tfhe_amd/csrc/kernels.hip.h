@@ -482,6 +482,16 @@ struct GateDesc {
     int32_t *out;
 };
 constexpr int OP_MUX = 10, OP_NOT = 11, OP_COPY = 12, OP_CONST0 = 13, OP_CONST1 = 14, OP_RAW = 100;
+// OP_MULTI (internal, mixed batches): one gate descriptor over rows of DIFFERENT two-input opcodes (0..9) -- only the
+// linear stage differs between them, so the whole opcode-sorted block runs as one level (full launches instead of one
+// partly filled launch per opcode).  `in2` then points at one 32-bit word per row whose top four bits are the row's
+// opcode (the gather permutation: original index | op << 28).
+constexpr int OP_MULTI = 101;
+constexpr uint32_t kPermIndexMask = 0x0FFFFFFFu;
+__device__ __forceinline__ int desc_op(const GateDesc &d, uint32_t inst)
+{
+    return d.op == OP_MULTI ? (int)(reinterpret_cast<const uint32_t *>(d.in2)[inst] >> 28) : d.op;
+}
 
 __device__ __forceinline__ void gate_lin(int op, int &cst8, int &s0, int &s1)
 {
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ de
     if (variant >= (d.op == OP_MUX ? 2u : 1u)) return;
     const int m = blockIdx.y * 256 + threadIdx.x;
     if (m > n) return;
-    int op = d.op;
+    int op = desc_op(d, s);
     const int32_t *a = d.in0, *b = d.in1;
     if (d.op == OP_MUX) { // u1 = AND(a,b), u2 = ANDNY(a,c)
         op = variant ? 6 : 1;
@@ -551,7 +561,7 @@ __device__ __forceinline__ void eoc_row_stores_to_l2()
 __device__ __forceinline__ void prepare_row(const GateDesc &d, uint32_t inst, int n, uint16_t *row, int t, int nt)
 {
     int cst8, s0, s1;
-    gate_lin(d.op, cst8, s0, s1);
+    gate_lin(desc_op(d, inst), cst8, s0, s1);
     typedef const __attribute__((address_space(1))) int32_t *gi32p; // operand rows are global memory (device or mapped host)
     const gi32p a = (gi32p)(uintptr_t)(d.in0 + (size_t)inst * (n + 1));
     const gi32p b = s1 ? (gi32p)(uintptr_t)(d.in1 + (size_t)inst * (n + 1)) : a; // one-operand forms carry no second row
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t *__restrict__
 {
     const int m = blockIdx.y * 256 + threadIdx.x;
     if (m >= rowlen) return;
-    const size_t i = blockIdx.x, j = perm[i];
+    const size_t i = blockIdx.x, j = perm[i] & kPermIndexMask; // the top four bits carry the row's opcode (OP_MULTI)
     if (scatter) dst[j * rowlen + m] = src[i * rowlen + m];
     else dst[i * rowlen + m] = src[j * rowlen + m];
 }

@@ -428,6 +428,35 @@ def test_mixed_ops_arbitrary_order_large(eoc, rig_small):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("no_fold", [False, True], ids=["folded", "unfolded"])
+def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
+    """A mixed batch over ALL fifteen opcodes in arbitrary order: the ten two-input opcodes differ only in their linear
+    stage and run as ONE level (one descriptor, the row's opcode read per job: OP_MULTI) instead of one partly filled
+    launch per opcode; MUX is a level of its own; NOT / COPY / CONSTANT take no bootstrap.  Row for row against the
+    oracle, with the separate k_prepare / k_ks_init launches too (EOC_TFHE_NO_FOLD), and by the engine's level counter."""
+    if no_fold:
+        monkeypatch.setenv("EOC_TFHE_NO_FOLD", "1")
+    r = Rig(eoc, 0, 7, n_override=31)
+    cnt = 700
+    rng = np.random.default_rng(144)
+    ops = rng.integers(0, 15, cnt).astype(np.uint8)
+    assert len(set(ops.tolist())) == 15
+    _, a = _rand_cts(r, cnt, 145)
+    _, b = _rand_cts(r, cnt, 146)
+    _, c = _rand_cts(r, cnt, 147)
+    before = r.eng.stats()
+    got = r.gate(0, a, b, c, ops=ops)
+    after = r.eng.stats()
+    assert np.array_equal(got, r.orc.gate_batch(0, a, b, c, ops=ops))
+    assert after["batches"] - before["batches"] == 2                  # the two-input block + the MUX run
+    n_mux = int((ops == eoc.OPS["MUX"]).sum())
+    assert after["bootstraps"] - before["bootstraps"] == int((ops < 10).sum()) + 2 * n_mux
+    # a batch with a single two-input opcode among free gates keeps its plain descriptor
+    ops2 = np.where(ops < 10, 4, np.where(ops == 10, 11, ops)).astype(np.uint8)
+    assert np.array_equal(r.gate(0, a, b, c, ops=ops2), r.orc.gate_batch(0, a, b, c, ops=ops2))
+    r.eng.close()
+
+
 def test_deep_chain_bit_exact_set_a(eoc, rig_a):
     """24 dependent levels x 96 gates on Set A (outputs of one level feed the next, alternating opcodes): GPU and
     oracle stay bit-identical through the whole depth (2304 bootstraps, ~1.1 M CMux steps, so the rare

@@ -1,0 +1,7 @@
+import json,sys
+d=json.load(open(sys.argv[1])); s=d["secondary"]
+print(d["value"], d["clock"]["sclk_mhz_under_load"])
+for k,v in s.items():
+    if isinstance(v,dict):
+        for kk in ("gates_per_s","bootstraps_per_s"):
+            if kk in v: print(" ",k,kk,v[kk])
