@@ -197,8 +197,10 @@ const eoc_params *eoc_engine_params(eoc_engine *e);
 /*
  * one homogeneous or mixed batch of independent gates, all operands resident on the device.
  *   op      : opcode when ops == NULL
- *   ops     : HOST array [count] of opcodes in any order, or NULL (equal opcodes are grouped on the device:
- *             gather into opcode-sorted order, one batch per opcode, scatter back)
+ *   ops     : HOST array [count] of opcodes in any order, or NULL (rows are grouped on the device: gather into
+ *             opcode-sorted order; the ten two-input opcodes -- which differ only in their linear stage -- run as one
+ *             batch, MUX as another, NOT / COPY / CONSTANT without a bootstrap; scatter back).  At most 2^28 - 1 rows
+ *             per call with ops != NULL (EOC_ERR_ARG beyond)
  *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX)
  *   d_out   : DEVICE array  [count][n+1] int32
  * bootsNAND ... bootsMUX over a batch.  Asynchronous on hip_stream (NULL = default stream). */
