@@ -815,8 +815,12 @@ def main():
                        "key_broadcast_s": round(t_bcast, 4)},
             "decrypt_ok": decrypt_ok,
             "kernels_ms": {"prepare": round(pr_ms, 4), "blind_rotate": round(br_ms, 4), "keyswitch": round(ks_ms, 4)},
+            # a level wider than the resident set is timed as ONE span of several kernel launches (slices): the pipe
+            # figures need the steps that span covers
             "roofline": roofline_block(p, args.pset, G, jobs_per_launch, br_ms, args.workload == "nand",
-                                       sclk_mhz=clk.summary()[0], shape="wide" if wide_headline else "pair"),
+                                       sclk_mhz=clk.summary()[0], shape="wide" if wide_headline else "pair",
+                                       steps_per_launch=p.n * max(1, -(-int(round(jobs_per_launch)) // (
+                                           (8 if wide_headline else 4) * torch.cuda.get_device_properties(dev).multi_processor_count)))),
             "clock": {"sclk_mhz_under_load": clk.summary()[0], "sclk_mhz_max_seen": clk.summary()[1],
                       "samples": clk.summary()[2], "matched_by_pci_address": clk_matched,
                       "package_power_w_max_seen": clk.power_summary()[0], "package_power_cap_w": clk.power_summary()[1],

@@ -16,7 +16,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r05_final"
+TAG = "r05_final"          # the set DESIGN.md section 7 quotes (one box, one collect_profiles.sh call)
+TAGS = ["r05_final", "r05_last"]   # ... and the same collection repeated on the round's last library (another box)
 
 
 def line(name):
@@ -36,7 +37,22 @@ def test_traffic_json_is_reproducible_from_the_committed_pmc_summaries():
     assert want["cobounds_A"]["lds_bank_conflict_cycles"] == 0.0 and want["cobounds_A_wide"]["lds_bank_conflict_cycles"] == 0.0
 
 
-@pytest.mark.parametrize("name,pset", [(f"{TAG}_bench_A.json", "A"), (f"{TAG}_bench_B.json", "B")])
+@pytest.mark.parametrize("tag", TAGS)
+def test_the_second_collection_reproduces_the_stored_pmc_figures(tag):
+    """r05_last_traffic.json (the last library, another box) against profiles/traffic.json (r05_final): byte counts per launch
+    within 1 %, the instruction mix identical"""
+    if tag != "r05_last":
+        pytest.skip("the reference set itself")
+    a, b = json.load(open(os.path.join(P, "traffic.json"))), json.load(open(os.path.join(P, f"{tag}_traffic.json")))
+    for k in ("blind_rotate_A_1024", "blind_rotate_B_1024", "blind_rotate_A_wide_2048"):
+        assert b[k] == pytest.approx(a[k], rel=0.01), k
+    for k in ("cobounds_A", "cobounds_B", "cobounds_A_wide"):
+        for f in ("fp64_insts_per_wave_step", "ds_write_b128_per_wave_step", "lds_bank_conflict_cycles"):
+            assert a[k][f] == b[k][f], (k, f)
+        assert b[k]["lds_wait_frac"] == pytest.approx(a[k]["lds_wait_frac"], abs=0.005)
+
+
+@pytest.mark.parametrize("name,pset", [(f"{t}_bench_{ps}.json", ps) for t in TAGS for ps in ("A", "B")])
 def test_bench_lines_carry_the_contract_and_add_up(name, pset):
     d = line(name)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -78,7 +94,8 @@ def stats_avg_ms(csv_name, kernel_prefix):
     raise AssertionError(kernel_prefix)
 
 
-def test_rocprof_kernel_averages_agree_with_the_hip_events_of_the_traced_runs():
+@pytest.mark.parametrize("TAG", TAGS)
+def test_rocprof_kernel_averages_agree_with_the_hip_events_of_the_traced_runs(TAG):
     d = line(f"{TAG}_bench_under_rocprof.json")
     avg, mn, calls = stats_avg_ms(f"{TAG}_kernel_stats.csv", "eoc::k_blind_rotate<2, 10>")
     ev = d["kernels_ms"]["blind_rotate"]
