@@ -177,7 +177,8 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  * batch with more than 15 opcode runs -- are placed in an arena that is never re-used (4 x max_descs slots of 40 bytes;
  * a permutation takes count / 10 slots), because the captured copy nodes read their pinned sources again at every
  * replay; when the arena is exhausted the call fails with EOC_ERR_STATE.
- *   max_jobs       : blind rotations of the widest level (instances x gates of the level, MUX counts twice)
+ *   max_jobs       : blind rotations of the widest level (instances x gates of the level, MUX counts twice; in a mixed
+ *                    batch with more than 15 opcode runs ALL rows with two-input opcodes form one level)
  *   max_descs      : gate descriptors sent between two wrap-arounds of the ring (>= gates of the netlist)
  *   max_mixed_rows : rows of the largest mixed (ops != NULL) batch, 0 if none */
 int eoc_engine_reserve(eoc_engine *e, size_t max_jobs, size_t max_descs, size_t max_mixed_rows);
