@@ -16,8 +16,7 @@ extracted key, over many input ciphertexts and ONE key:
                                                           digits uniform on [-Bg/2, Bg/2), mean -1/2; two per-cent-level
                                                           refinements in `predict`: gaussian32 truncates toward zero, so
                                                           the stored noise has variance sigma^2 - sigma sqrt(2/pi) 2^-32 +
-                                                          2^-64/3, and the steps before the first s_i = 1 see a noiseless
-                                                          accumulator)
+                                                          2^-64/3, and step 0 works on the trivial accumulator)
        + w * (1 + |s'|) * q^2 / 12                        (w = Hamming weight of the LWE key, |s'| of the TLWE key:
                                                           the decomposition's remainder, q = Bg^-l)
        + w * (q/2)^2 * G(s')                              (the remainder is a TRUNCATION: upstream's offset
@@ -33,8 +32,8 @@ s_i = 1 nothing rotates any more (rho = 0): a deterministic bias
 
   M_BR = -(q/2) * (1 + |s'| - 2 s'_0).
 
-(At 262 144 samples a third, input-dependent mean term resolves: the steps before the first s_i = 1 multiply constant band
-digits by the FIXED noise of their rows -- about 100 (q/2), zero over uniform rotations.  tools/noise_mean_diag.py simulates
+(At 262 144 samples a third, input-dependent mean term resolves: step 0 multiplies constant band digits by the FIXED noise
+of its rows -- about 50 (q/2), zero over uniform rotations.  tools/noise_mean_diag.py simulates
 it from the key and matches the measured means per input class; `predict` keeps the input-independent M_BR.)
 
 Key switch (lweKeySwitch; A.6), added error for ONE key whose rows have noises e[i][j][d]
@@ -93,17 +92,15 @@ def predict(params, lwe_key, tlwe_key, ksk=None):
     u = 2.0**-32
     sig = float(params.bk_stdev)
     sig2 = sig * sig - sig * np.sqrt(2.0 / np.pi) * u + u * u / 3.0
-    # (b) until the first step with s_i = 1 has run, the accumulator is still the noiseless (0, X^-b testvector): its mask
-    #     polynomial decomposes to all-zero digits and its body to ~N/2 digits of 2 mu / h_1, so each of those i0 + 1 steps
-    #     adds about (N/2) (2 mu / h_1)^2 / (2l N E[d^2]) of a regular step's row noise (9 % for Set A), and the first active
-    #     step's remainder is exactly zero (no truncation term from it)
-    ones = np.flatnonzero(s)
-    i0 = int(ones[0]) if len(ones) else n
+    # (b) STEP 0 sees the trivial accumulator (0, X^-b testvector): its mask polynomial decomposes to all-zero digits and its
+    #     body to ~N/2 digits of 2 mu / h_1, so that step adds about (N/2) (2 mu / h_1)^2 / (2l N E[d^2]) of a regular step's
+    #     row noise (9 % for Set A), and its remainder is exactly zero (no truncation term from it when s_0 = 1).  From step 1
+    #     on the accumulator's mask is the pseudo-random sum of key-row masks -- a regular step whether s_0 was 0 or 1
     Ed2 = (Bg * Bg + 2) / 12.0
     d_triv = (1 << 30) >> (32 - Bgbit) if Bgbit <= 30 else 0          # first digit of +-2 mu = 2^30
     triv_frac = min(1.0, 0.5 * d_triv * d_triv / (2 * l * Ed2))
-    n_eff = (n - (i0 + 1) * (1.0 - triv_frac)) * (1.0 - 1.0 / (2 * N))
-    w_eff = max(w - 1, 0)
+    n_eff = (n - (1.0 - triv_frac)) * (1.0 - 1.0 / (2 * N))          # step 0 only: after it the accumulator's MASK is
+    w_eff = max(w - int(s[0]), 0)                                     # pseudo-random whatever s_0 is, and every later step regular
     out["br_var_rows"] = n_eff * 2 * l * N * Ed2 * sig2
     out["br_var_remainder"] = w_eff * (1 + hw) * q * q / 12.0
     out["br_var_truncation_bias"] = w_eff * (q / 2) ** 2 * float((Jv**2).mean())
@@ -137,7 +134,7 @@ def rotation_amounts(t_rows):
 
 def br_conditional_mean(params, lwe_key, tlwe_key, t_rows):
     """What the truncating decomposition adds to EACH sample, given only public data and the key: sum over the steps with
-    s_i = 1 (the first one excepted: its accumulator is noiseless, its remainder exactly zero) of coefficient 0 of
+    s_i = 1 (step 0 excepted: its accumulator is the trivial one, its remainder exactly zero) of coefficient 0 of
     X^rho_i * M, M = -(q/2) J*(1 - s'), rho_i = sum of the LATER active steps' rotation amounts (mod 2N).  [count] torus units.
 
     The measured error of a sample regresses on this with slope 1 and correlation sqrt(V_truncation / V_BR) (0.58 for
@@ -160,17 +157,18 @@ def br_conditional_mean(params, lwe_key, tlwe_key, t_rows):
     idx = np.where(rho % N == 0, 0, np.where(rho < N, N - rho, 2 * N - rho))
     sgn = np.where(rho == 0, 1.0, np.where(rho <= N, -1.0, 1.0))
     contrib = sgn * M[idx]
-    contrib[:, :1] = 0.0
+    if len(act) and act[0] == 0:
+        contrib[:, :1] = 0.0          # step 0 works on the trivial accumulator: its remainder is exactly zero
     return contrib.sum(1)
 
 
 def br_early_term(params, lwe_key, tlwe_key, bk, t_rows, mu=1 << 29, chunk=16384):
-    """The steps up to and including the first one with s_i = 1 see the noiseless accumulator (0, X^-barb testvector): the
-    digits of (X^abar - 1) ACC are the CONSTANT +-2 mu / h_1 on a band (first digit of the body polynomial only), so each of
-    those steps adds  (2 mu / h_1) * sum_band +-e_i  with the FIXED noise e_i of row (q = 1, p = 1) of BK_i, rotated by the later
-    active steps.  Deterministic given the key and the public rotation amounts; zero over uniform rotations, ~ 100 (q/2) over
-    NAND's three phase classes.  `bk` = the torus rows [n][2l][2][N] (SecretKey.bk).  [count] torus units.
-    (Exact for i0 = 0; for i0 > 0 the accumulator already carries the inactive steps' row noise, far below one digit.)"""
+    """STEP 0 sees the trivial accumulator (0, X^-barb testvector): the digits of (X^abar_0 - 1) ACC are the CONSTANT
+    +-2 mu / h_1 on a band (first digit of the body polynomial only), so that step adds  (2 mu / h_1) * sum_band +-e_0  with the
+    FIXED noise e_0 of row (q = 1, p = 1) of BK_0, rotated by the active steps behind it.  Deterministic given the key and the
+    public rotation amounts; zero over uniform rotations, of the order of 50 (q/2) over NAND's three phase classes
+    (DESIGN.md 2.3).  (After step 0 the accumulator's mask is a pseudo-random sum of key-row masks whether s_0 is 0 or 1:
+    every later step is a regular one.)  `bk` = the torus rows [n][2l][2][N] (SecretKey.bk).  [count] torus units."""
     n, l, Bgbit = int(params.n), int(params.l), int(params.Bgbit)
     s = np.asarray(lwe_key, np.int64)
     s1 = np.asarray(tlwe_key, np.int64)
@@ -180,7 +178,7 @@ def br_early_term(params, lwe_key, tlwe_key, bk, t_rows, mu=1 << 29, chunk=16384
     out = np.zeros(bara.shape[0])
     if not len(ones):
         return out
-    i0 = int(ones[0])
+    i0 = 0          # step 0 only
     dig = float((2 * mu) >> (32 - Bgbit))
     S = np.zeros((N, N))                                   # a @ S = a * s' in Z[X]/(X^N + 1)
     for m_ in range(N):

@@ -79,7 +79,7 @@ def test_gpu_noise_matches_prediction(eoc, pset, seed):
     # sign and size of the remainder; the opposite order gives slope 0 (tests/test_noise_cpu.py; standard error 0.011 / 0.014)
     assert 0.93 < r["br_cm_slope"] < 1.07, r
     assert abs(r["br_cm_corr"] - r["br_cm_corr_pred"]) < 0.04, r
-    # ... and what the per-sample model (truncation + the early steps' fixed row noise) leaves has zero mean
+    # ... and what the per-sample model (truncation + step 0's fixed row noise) leaves has zero mean
     assert abs(r["br_resid_z"]) < 5, r
     # the nearest neighbours are excluded: rounding decomposition (textbook formula) 1.53x (A) / 1.33x (B),
     # average-over-keys key switch 0.75x

@@ -74,8 +74,8 @@ def test_prediction_terms_setA_by_hand():
     s = np.zeros(500, np.int64); s[::2] = 1
     s1 = np.zeros(N, np.int64); s1[::2] = 1
     p = noise.predict(P, s, s1)
-    # rows: sigma^2 corrected for gaussian32's truncation toward zero (30.8 units: -2.6 %), and the one step (i0 = 0) that
-    # sees the noiseless accumulator counted at 0.5 * 256^2 / (4 * E[d^2]) = 9.4 % of a regular step
+    # rows: sigma^2 corrected for gaussian32's truncation toward zero (30.8 units: -2.6 %), and step 0, which
+    # sees the trivial accumulator, counted at 0.5 * 256^2 / (4 * E[d^2]) = 9.4 % of a regular step
     u = 2.0**-32
     sig2 = 7.18e-9**2 - 7.18e-9 * np.sqrt(2 / np.pi) * u + u * u / 3
     assert sig2 / 7.18e-9**2 == pytest.approx(0.9745, abs=2e-4)

@@ -1,8 +1,8 @@
 """Measured vs predicted output noise at a large sample count (default 262 144 per set: sampling error of a variance
 0.28 %): resolves whether the per-key prediction of eoc_tfhe_amd/noise.py is off at the per-cent level.  (It was: the
 first version ignored that gaussian32 truncates toward zero -- the stored bootstrapping-key noise has 0.974 (A) / 0.992 (B)
-of sigma^2 -- and that the steps before the first s_i = 1 see a noiseless accumulator; both are in `predict` now.)
-Usage (GPU box): python tools/noise_large.py [count]"""
+of sigma^2 -- and that step 0 works on the trivial accumulator; both are in `predict` now.)
+Usage (GPU box): python tools/noise_large.py [count] [key seeds ...]"""
 import os
 import sys
 

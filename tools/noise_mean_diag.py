@@ -6,10 +6,11 @@ error of every sample:
   2. every earlier active step adds the same polynomial rotated by the remaining rotation rho_i -- zero on average, but
      KNOWN per sample from the rotation amounts: the measured error regresses on this per-sample prediction with slope ~ 1
      and correlation ~ 0.58 (a third of the variance is this deterministic truncation structure);
-  3. until the first s_i = 1 has run the accumulator is the noiseless (0, X^-barb testvector): its digits are the constant
-     +-2 mu / h_1 on a band next to the sign boundary, so those i0 + 1 steps add  (2 mu / h_1) * band * e_i  with the FIXED
-     row noise e_i of BK_i -- a key- and input-class-dependent term of the order of 100 units of q/2 that no average-case
-     formula contains; with it the model reproduces the measured mean overall and per input class.
+  3. STEP 0 works on the trivial accumulator (0, X^-barb testvector): its digits are the constant +-2 mu / h_1 on a band next
+     to the sign boundary, so that step adds  (2 mu / h_1) * band * e_0  with the FIXED row noise e_0 of BK_0 -- a key- and
+     input-class-dependent term of the order of 50 units of q/2 that no average-case formula contains (from step 1 on the
+     accumulator's mask is pseudo-random, whatever s_0: regular steps); with it the model reproduces the measured mean overall
+     and per input class.
 Usage (GPU box): python tools/noise_mean_diag.py [key seed]"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -61,10 +62,10 @@ for lo, hi in ((0,512),(512,1024),(1536,2048)):
     m = (tot >= lo) & (tot < hi)
     print(f"class total rotation [{lo},{hi}): model {cm[m].mean():8.1f}  measured {e[m].mean()/c:8.1f}")
 
-# ---- the early steps (noise.br_early_term): until the first s_i = 1 has run the accumulator is the noiseless
-# (0, X^-barb tv); its digits are the CONSTANT +-2 mu / h_1 on a band, so those steps add a deterministic term ----
+# ---- step 0 (noise.br_early_term): the accumulator is the trivial (0, X^-barb tv); its digits are the CONSTANT
+# +-2 mu / h_1 on a band, so that step adds a deterministic term ----
 early = noise.br_early_term(p, lwe, s1, sk.bk, t) / c
-print("early steps: i0 =", int(ones[0]), " mean of the early term / c", early.mean(), " std / c", early.std())
+print("step 0 (s_0 =", int(lwe[0]), "): mean of the early term / c", early.mean(), " std / c", early.std())
 cm2 = cm + early
 y2 = e / c
 se = y2.std() / np.sqrt(count)
