@@ -1,3 +1,4 @@
+"""One-screen summary of a bench.py line: python tools/bench_summary.py <bench.json>  (value, sampled clock, secondary legs)."""
 import json,sys
 d=json.load(open(sys.argv[1])); s=d["secondary"]
 print(d["value"], d["clock"]["sclk_mhz_under_load"])
