@@ -19,7 +19,7 @@ extracted key, over many input ciphertexts and ONE key:
                                                           2^-64/3, and step 0 works on the trivial accumulator)
        + w * (1 + |s'|) * q^2 / 12                        (w = Hamming weight of the LWE key, |s'| of the TLWE key:
                                                           the decomposition's remainder, q = Bg^-l)
-       + w * (q/2)^2 * G(s')                              (the remainder is a TRUNCATION: upstream's offset
+       + (w - 1) * (q/2)^2 * G(s')                        (the remainder is a TRUNCATION: upstream's offset
                                                           sum_p (Bg/2) 2^(32 - p Bgbit) centres the digits, not the
                                                           remainder, which is uniform on [0, q) with mean q/2)
 
@@ -103,7 +103,8 @@ def predict(params, lwe_key, tlwe_key, ksk=None):
     w_eff = max(w - int(s[0]), 0)                                     # pseudo-random whatever s_0 is, and every later step regular
     out["br_var_rows"] = n_eff * 2 * l * N * Ed2 * sig2
     out["br_var_remainder"] = w_eff * (1 + hw) * q * q / 12.0
-    out["br_var_truncation_bias"] = w_eff * (q / 2) ** 2 * float((Jv**2).mean())
+    # the LAST active step is rotated by nothing: its term is the constant M_BR (the mean below), not variance
+    out["br_var_truncation_bias"] = max(w_eff - 1, 0) * (q / 2) ** 2 * float((Jv**2).mean())
     out["br_var"] = out["br_var_rows"] + out["br_var_remainder"] + out["br_var_truncation_bias"]
     out["br_mean"] = -(q / 2) * float(Jv[0])
     out["br_var_textbook"] = (n * 2 * l * N * (Bg * Bg / 12.0) * float(params.bk_stdev) ** 2

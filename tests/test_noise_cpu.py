@@ -85,7 +85,9 @@ def test_prediction_terms_setA_by_hand():
     assert p["br_var_remainder"] == pytest.approx(249 * 513 * 2.0**-40 / 12, rel=1e-12)                   # 9.7e-9
     # alternating key: (J*(1-s'))[r] = 1 - (r//2 + 1) + (511 - r//2) = 511 - 2 (r//2): mean square ~ N^2/12
     jv = 511 - 2 * (np.arange(N) // 2)
-    assert p["br_var_truncation_bias"] == pytest.approx(249 * 2.0**-42 * (jv.astype(float)**2).mean(), rel=1e-12)
+    # 250 active steps: step 0 (trivial accumulator, zero remainder) and the last one (rotated by nothing: the constant
+    # M_BR) carry no truncation VARIANCE
+    assert p["br_var_truncation_bias"] == pytest.approx(248 * 2.0**-42 * (jv.astype(float)**2).mean(), rel=1e-12)
     assert 4.5e-6 < p["br_var_truncation_bias"] < 5.5e-6
     assert p["br_mean"] == pytest.approx(-(2.0**-21) * 511, rel=1e-12)        # 1 + |s'| - 2 s'_0, s'_0 = 1
     assert p["ks_var_textbook"] == pytest.approx(1024 * 8 * 0.75 * 2.44e-5**2 + 512 * 2.0**-34 / 3, rel=1e-12)
