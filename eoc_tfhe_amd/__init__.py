@@ -124,6 +124,8 @@ def lib():
         "eoc_circuit_run_device": (C.c_int, [vp, vp, sz, vp, sz, sz, vp]),
         "eoc_circuit_bootstraps": (sz, [vp, sz]),
         "eoc_netlist_optimize": (C.c_int64, [vp, sz, vp, sz, vp]),
+        "eoc_netlist_levels": (C.c_int64, [vp, sz, vp, vp]),
+        "eoc_netlist_cost": (C.c_int64, [vp, sz, sz, sz]),
         "eoc_dbg_fft_fwd_device": (C.c_int, [vp, vp, vp, sz, vp]),
         "eoc_dbg_fft_inv_device": (C.c_int, [vp, vp, vp, sz, vp]),
         "eoc_blind_rotate_device": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -498,8 +500,8 @@ def circuit_bootstraps(gates):
 
 
 def netlist_optimize(gates, outputs):
-    """eoc_netlist_optimize: NOT folding, MUX fusion and dead-gate removal in the native library (the same
-    rewriting as circuits.optimize).  Raises EocError for netlists that are not single-assignment."""
+    """eoc_netlist_optimize: constant / NOT / COPY folding, MUX and carry fusion, dead-gate removal in the native library
+    (the same rewriting as circuits.optimize).  Raises EocError for netlists that are not single-assignment."""
     arr = (Gate * max(1, len(gates)))(*gates)
     out = (Gate * max(1, len(gates)))()
     outs = (C.c_int32 * max(1, len(outputs)))(*outputs)
@@ -507,6 +509,27 @@ def netlist_optimize(gates, outputs):
     if n < 0:
         raise EocError(f"eoc_netlist_optimize failed ({n}): not a single-assignment netlist?")
     return [Gate(out[k].op, out[k].in0, out[k].in1, out[k].in2, out[k].out) for k in range(n)]
+
+
+def netlist_levels(gates):
+    """eoc_netlist_levels: (level of every gate, number of levels, levels that hold a blind rotation)"""
+    arr = (Gate * max(1, len(gates)))(*gates)
+    lev = (C.c_int32 * max(1, len(gates)))()
+    depth = C.c_int64(0)
+    n = lib().eoc_netlist_levels(C.addressof(arr), len(gates), C.addressof(lev), C.addressof(depth))
+    if n < 0:
+        raise EocError(f"eoc_netlist_levels failed ({n})")
+    return list(lev[:len(gates)]), int(n), int(depth.value)
+
+
+def netlist_cost(gates, instances, resident_jobs=0):
+    """eoc_netlist_cost: estimated run time over `instances` instances in units of 0.1 ms (the native twin of
+    circuits.netlist_cost)"""
+    arr = (Gate * max(1, len(gates)))(*gates)
+    c = lib().eoc_netlist_cost(C.addressof(arr), len(gates), int(instances), int(resident_jobs))
+    if c < 0:
+        raise EocError(f"eoc_netlist_cost failed ({c})")
+    return int(c)
 
 
 # ---- host-buffer batch API (global context: one key, any number of GPUs), numpy in / numpy out ---------

@@ -185,6 +185,151 @@ def multiplier(nbits=4):
     return gates, nxt, a, b, prod
 
 
+# ---- forms chosen by instance count: fewest bootstraps for wide batches, fewest levels for small ones -------------
+
+def mux_carry_adder(nbits=8):
+    """a + b -> nbits + 1 sum bits, LSB first, with the carry as ONE gate per bit: p_i = a_i XOR b_i,
+    c_{i+1} = MUX(p_i, c_i, a_i) (inputs differ: the carry-in passes; inputs agree: either of them is the carry),
+    s_i = p_i XOR c_i; bit 0 is a half adder.  2 + 4 (nbits - 1) bootstraps on nbits dependent levels (30 / 8 for 8 bits
+    against the textbook form's 37 / 16): what fuse_carry makes of ripple_carry_adder, written directly.
+    Same wire layout as ripple_carry_adder.  Returns (gates, n_wires, a_wires, b_wires, sum_wires)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    s = list(range(2 * nbits, 3 * nbits + 1))
+    nxt = 3 * nbits + 1
+    gates = [Gate(OPS["XOR"], a[0], b[0], -1, s[0])]
+    carry = s[1] if nbits == 1 else nxt
+    if nbits > 1:
+        nxt += 1
+    gates.append(Gate(OPS["AND"], a[0], b[0], -1, carry))
+    for i in range(1, nbits):
+        p = nxt
+        nxt += 1
+        gates.append(Gate(OPS["XOR"], a[i], b[i], -1, p))
+        gates.append(Gate(OPS["XOR"], p, carry, -1, s[i]))
+        newc = s[nbits] if i == nbits - 1 else nxt
+        if i != nbits - 1:
+            nxt += 1
+        gates.append(Gate(OPS["MUX"], p, carry, a[i], newc))
+        carry = newc
+    return gates, nxt, a, b, s
+
+
+def prefix_adder(nbits=8):
+    """a + b in logarithmic depth: a Sklansky parallel-prefix network over (generate, propagate) pairs.  A group's G and P
+    exclude each other, so the prefix cell (G, P) = (G_hi OR (P_hi AND G_lo), P_hi AND P_lo) is ONE MUX and one AND on the
+    same level: G = MUX(P_hi, G_lo, G_hi).  A single bit as the upper operand needs no generate wire of its own
+    (MUX(p_i, G_lo, a_i)), a prefix that already starts at bit 0 needs no P.  Levels: 1 (p_i, g_i) + ceil(log2 nbits)
+    + 1 (sums) -- 5 for 8 bits, 6 for 16 -- at 48 bootstraps per 8-bit pair (mux_carry_adder: 30 on 8 levels).
+    Same wire layout as ripple_carry_adder.  Returns (gates, n_wires, a_wires, b_wires, sum_wires)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    s = list(range(2 * nbits, 3 * nbits + 1))
+    state = {"nxt": 3 * nbits + 1}
+    gates = []
+
+    def emit(op, i0, i1, i2=-1, out=None):
+        if out is None:
+            out = state["nxt"]
+            state["nxt"] += 1
+        gates.append(Gate(OPS[op], i0, i1, i2, out))
+        return out
+
+    if nbits == 1:
+        emit("XOR", a[0], b[0], out=s[0])
+        emit("AND", a[0], b[0], out=s[1])
+        return gates, state["nxt"], a, b, s
+    # which positions are combined at level k (bit k of the position set), with the last position of the block below
+    nlev = (nbits - 1).bit_length()
+    P = [emit("XOR", a[i], b[i], out=s[0] if i == 0 else None) for i in range(nbits)]
+    p_bit = list(P)
+    # a generate wire only where the position serves as a LOWER operand while still a single bit (even positions)
+    G = [emit("AND", a[i], b[i]) if i % 2 == 0 and i + 1 < nbits or i == 0 else None for i in range(nbits)]
+    single = [True] * nbits
+    for k in range(nlev):
+        newG, newP, newsingle = list(G), list(P), list(single)
+        for i in range(nbits):
+            if not (i >> k) & 1:
+                continue
+            j = ((i >> k) << k) - 1
+            final = i < (1 << (k + 1))                  # the result covers bits 0 .. i
+            last = final and i == nbits - 1
+            g_hi = a[i] if single[i] else G[i]
+            newG[i] = emit("MUX", P[i], G[j], g_hi, out=s[nbits] if last else None)
+            # P of the combined group is read only by a later cell that uses position i (or a higher position of its
+            # block) as the upper operand: never once the group starts at bit 0
+            newP[i] = None if final else emit("AND", P[i], P[j])
+            newsingle[i] = False
+        G, P, single = newG, newP, newsingle
+    for i in range(1, nbits):
+        emit("XOR", p_bit[i], G[i - 1], out=s[i])
+    return gates, state["nxt"], a, b, s
+
+
+def less_than_tree(nbits=8):
+    """unsigned a < b in logarithmic depth: a balanced tree over (LT, EQ) pairs of bit ranges, upper half first:
+    LT = MUX(EQ_hi, LT_lo, LT_hi), EQ = EQ_hi AND EQ_lo (only where a parent still needs it).  A single bit as the upper
+    operand needs no LT wire (MUX(a_i XNOR b_i, LT_lo, b_i)).  1 + ceil(log2 nbits) levels (4 for 8 bits) at 29
+    bootstraps, against less_than's 8 levels at 22.  Returns (gates, n_wires, a_wires, b_wires, out_wire)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    state = {"nxt": 2 * nbits}
+    gates = []
+
+    def emit(op, i0, i1, i2=-1):
+        out = state["nxt"]
+        state["nxt"] += 1
+        gates.append(Gate(OPS[op], i0, i1, i2, out))
+        return out
+
+    def build(lo, hi, need_lt, need_eq):
+        """(LT wire or None, EQ wire or None) of bits lo .. hi - 1; a single bit with need_lt False hands back b_i as the
+        stand-in its parent's MUX takes"""
+        if hi - lo == 1:
+            eq = emit("XNOR", a[lo], b[lo]) if need_eq else None
+            lt = emit("ANDNY", a[lo], b[lo]) if need_lt else None
+            return lt, eq
+        mid = lo + (hi - lo + 1) // 2                    # lower part [lo, mid), upper part [mid, hi)
+        up_single = hi - mid == 1
+        lt_lo, eq_lo = build(lo, mid, True, need_eq)
+        lt_hi, eq_hi = build(mid, hi, not up_single, True)
+        lt = emit("MUX", eq_hi, lt_lo, b[mid] if up_single else lt_hi) if need_lt else None
+        eq = emit("AND", eq_hi, eq_lo) if need_eq else None
+        return lt, eq
+
+    lt, _ = build(0, nbits, True, False)
+    return gates, state["nxt"], a, b, lt
+
+
+ADDER_FORMS = {"ripple": lambda n: ripple_carry_adder(n), "mux": mux_carry_adder, "prefix": prefix_adder}
+LESS_THAN_FORMS = {"ripple": less_than, "tree": less_than_tree}
+
+
+def pick_form(forms, nbits, instances, resident_jobs=1024):
+    """the form of lowest netlist_cost for this many instances (ties: fewest bootstraps): depth decides below a quarter
+    of the resident set, bootstraps decide above it.  Returns (name, builder result)."""
+    best = None
+    for name, build in forms.items():
+        r = build(nbits)
+        boots = sum(2 if _NAMES[g.op] == "MUX" else 0 if _NAMES[g.op] in ("NOT", "COPY", "CONST0", "CONST1") else 1
+                    for g in r[0])
+        key = (netlist_cost(r[0], instances, resident_jobs), boots)
+        if best is None or key < best[0]:
+            best = (key, name, r)
+    return best[1], best[2]
+
+
+def adder(nbits=8, instances=1, resident_jobs=1024):
+    """the adder form to run for `instances` input pairs: mux_carry_adder for wide batches, prefix_adder for small ones
+    (ripple_carry_adder is never chosen: it is the textbook form BASELINE configs[2] is timed on, kept as written)"""
+    forms = {k: v for k, v in ADDER_FORMS.items() if k != "ripple"}
+    return pick_form(forms, nbits, instances, resident_jobs)[1]
+
+
+def less_than_for(nbits=8, instances=1, resident_jobs=1024):
+    return pick_form(LESS_THAN_FORMS, nbits, instances, resident_jobs)[1]
+
+
 # ---- plaintext semantics and netlist rewriting -----------------------------------------------------
 
 _NAMES = {v: k for k, v in OPS.items()}
@@ -258,18 +403,74 @@ def _drop_dead(gates, keep):
         gates = live
 
 
+def fold_constants(gates, outputs):
+    """Constant propagation: bootsCONSTANT wires (and what follows from them) are folded into their readers -- a
+    two-input gate with one known input is that constant, a COPY or a NOT of the other input (free); MUX with a known
+    selector is a COPY, with one known branch a two-input gate (MUX(s, 0, c) = ANDNY(s, c), MUX(s, 1, c) = OR(s, c),
+    MUX(s, b, 0) = AND(s, b), MUX(s, b, 1) = ORNY(s, b): one bootstrap instead of two), with two known branches a
+    COPY / NOT of the selector or a constant.  Single-assignment netlists only."""
+    _check_ssa(gates)
+    const = {}
+
+    def unary(wire, neg, out):
+        """gate computing `wire` (negated if neg) into out; wire known -> a constant"""
+        if wire in const:
+            v = const[wire] ^ neg
+            const[out] = v
+            return Gate(OPS["CONST1"] if v else OPS["CONST0"], -1, -1, -1, out)
+        return Gate(OPS["NOT"] if neg else OPS["COPY"], wire, -1, -1, out)
+
+    def constant(v, out):
+        const[out] = v
+        return Gate(OPS["CONST1"] if v else OPS["CONST0"], -1, -1, -1, out)
+
+    res = []
+    for g in gates:
+        name = _NAMES[g.op]
+        if name in ("CONST0", "CONST1"):
+            res.append(constant(1 if name == "CONST1" else 0, g.out))
+        elif name in ("NOT", "COPY"):
+            res.append(unary(g.in0, 1 if name == "NOT" else 0, g.out))
+        elif name == "MUX":
+            s, b, c = g.in0, g.in1, g.in2
+            kb, kc = const.get(b), const.get(c)
+            if s in const:
+                res.append(unary(b if const[s] else c, 0, g.out))
+            elif kb is None and kc is None:
+                res.append(Gate(g.op, s, b, c, g.out))
+            elif kb is not None and kc is not None:
+                res.append(constant(kb, g.out) if kb == kc else unary(s, 0 if kb else 1, g.out))
+            elif kb is not None:
+                res.append(Gate(OPS["OR"] if kb else OPS["ANDNY"], s, c, -1, g.out))
+            else:
+                res.append(Gate(OPS["ORNY"] if kc else OPS["AND"], s, b, -1, g.out))
+        else:
+            f = _SEM2[name]
+            ka, kb = const.get(g.in0), const.get(g.in1)
+            if ka is not None and kb is not None:
+                res.append(constant(f(ka, kb), g.out))
+            elif ka is not None or kb is not None:
+                r0, r1 = (f(ka, 0), f(ka, 1)) if ka is not None else (f(0, kb), f(1, kb))
+                other = g.in1 if ka is not None else g.in0
+                res.append(constant(r0, g.out) if r0 == r1 else unary(other, 0 if r1 else 1, g.out))
+            else:
+                res.append(Gate(g.op, g.in0, g.in1, -1, g.out))
+    return _drop_dead(res, outputs)
+
+
 def fold_nots(gates, outputs):
-    """NOT is free, but a NOT in front of a bootstrapped gate is unnecessary altogether: the ten two-input
+    """NOT and COPY are free, but in front of a bootstrapped gate they are unnecessary altogether: the ten two-input
     boots* gates are closed under input negation (AND with a negated first input IS bootsANDNY, ...), a negated
-    MUX selector swaps the branches, NOT(NOT x) is a COPY.  `outputs` are the wires the caller reads; NOT gates
-    nobody reads afterwards are dropped.  Single-assignment netlists only."""
+    MUX selector swaps the branches, NOT(NOT x) is a COPY, and every reader looks through COPY.  `outputs` are the
+    wires the caller reads; NOT / COPY gates nobody reads afterwards are dropped.  Single-assignment netlists only."""
     _check_ssa(gates)
     src = {g.out: g for g in gates}
 
     def strip(wire):
         neg = 0
-        while wire in src and _NAMES[src[wire].op] == "NOT":
-            wire, neg = src[wire].in0, neg ^ 1
+        while wire in src and _NAMES[src[wire].op] in ("NOT", "COPY"):
+            neg ^= 1 if _NAMES[src[wire].op] == "NOT" else 0
+            wire = src[wire].in0
         return wire, neg
 
     out = []
@@ -280,11 +481,18 @@ def fold_nots(gates, outputs):
             out.append(Gate(OPS[_BY_TABLE[_table(name, n0, n1)]], i0, i1, -1, g.out))
         elif name == "MUX":
             (s, ns) = strip(g.in0)
-            b, c = (g.in2, g.in1) if ns else (g.in1, g.in2)
+            (b, nb), (c, nc) = strip(g.in1), strip(g.in2)
+            if nb:
+                b = g.in1                               # a negated branch stays behind its (free) NOT
+            if nc:
+                c = g.in2
+            if ns:
+                b, c = c, b
             out.append(Gate(g.op, s, b, c, g.out))
-        elif name == "NOT":
+        elif name in ("NOT", "COPY"):
             i0, n0 = strip(g.in0)
-            out.append(Gate(OPS["COPY"] if n0 else OPS["NOT"], i0, -1, -1, g.out))
+            n0 ^= 1 if name == "NOT" else 0
+            out.append(Gate(OPS["NOT"] if n0 else OPS["COPY"], i0, -1, -1, g.out))
         else:
             out.append(Gate(g.op, g.in0, g.in1, g.in2, g.out))
     return _drop_dead(out, outputs)
@@ -315,7 +523,7 @@ def fuse_mux(gates, outputs):
         done = False
         if _NAMES[g.op] == "OR" and g.in0 in src and g.in1 in src:
             x, y = src[g.in0], src[g.in1]
-            inner_ok = all(uses.get(t.out, 0) == 1 and t.out not in keep for t in (x, y))
+            inner_ok = all(uses.get(t.out, 0) == 1 and t.out not in keep for t in (x, y)) and x.out != y.out
             if inner_ok:
                 for (s0, d0, p0) in as_sel(x):
                     for (s1, d1, p1) in as_sel(y):
@@ -328,6 +536,94 @@ def fuse_mux(gates, outputs):
     return _drop_dead(out, outputs)
 
 
+def fuse_carry(gates, outputs):
+    """The carry of a textbook full adder, OR(AND(a, b), AND(XOR(a, b), c)), is MUX(XOR(a, b), c, a): where the inputs
+    differ the carry-in passes, where they agree either of them is the carry.  The two AND wires must be single-use and
+    not outputs; the XOR wire stays (the sum bit reads it too).  3 bootstraps on 2 dependent levels become 2 bootstraps on
+    ONE level: the literal 8-bit ripple-carry adder goes from 40 bootstraps / 17 levels to 32 / 9 (30 / 8 once the
+    constant carry-in is folded).  Single-assignment netlists only."""
+    _check_ssa(gates)
+    src = {g.out: g for g in gates}
+    uses = _uses(gates)
+    keep = set(outputs)
+    AND, XOR = OPS["AND"], OPS["XOR"]
+    out = []
+    for g in gates:
+        m = None
+        if _NAMES[g.op] == "OR" and g.in0 in src and g.in1 in src and g.in0 != g.in1:
+            for x, y in ((src[g.in0], src[g.in1]), (src[g.in1], src[g.in0])):      # x = a AND b, y = p AND c
+                if m is not None or x.op != AND or y.op != AND or x.in0 == x.in1:
+                    continue
+                if any(uses.get(t.out, 0) != 1 or t.out in keep for t in (x, y)):
+                    continue
+                for p, c in ((y.in0, y.in1), (y.in1, y.in0)):
+                    q = src.get(p)
+                    if m is None and q is not None and q.op == XOR and \
+                            ((q.in0 == x.in0 and q.in1 == x.in1) or (q.in0 == x.in1 and q.in1 == x.in0)):
+                        m = Gate(OPS["MUX"], p, c, x.in0, g.out)
+        out.append(m if m is not None else Gate(g.op, g.in0, g.in1, g.in2, g.out))
+    return _drop_dead(out, outputs)
+
+
+def _as_tuples(gates):
+    return [(g.op, g.in0, g.in1, g.in2, g.out) for g in gates]
+
+
 def optimize(gates, outputs):
-    """fold_nots, then fuse_mux; returns the rewritten netlist (same wire numbering, fewer gates)."""
-    return fuse_mux(fold_nots(gates, outputs), outputs)
+    """fold_constants, fold_nots, fuse_mux, fuse_carry, repeated until nothing changes (a fused carry with a constant
+    carry-in folds again); returns the rewritten netlist (same wire numbering, never more bootstraps, never more
+    levels).  eoc_netlist_optimize (csrc/host.cpp) is the native twin: same passes, same order, same result."""
+    cur = list(gates)
+    for _ in range(8):
+        nxt = fuse_carry(fuse_mux(fold_nots(fold_constants(cur, outputs), outputs), outputs), outputs)
+        if _as_tuples(nxt) == _as_tuples(cur):
+            break
+        cur = nxt
+    return cur
+
+
+# ---- levels and the level-cost estimate (what picks a circuit form for an instance count) ------------------------
+
+def levels(gates):
+    """level of every gate as eoc_circuit_run_device assigns it (1-based; RAW, WAR and WAW hazards on wires)"""
+    wr, rd, lev = {}, {}, []
+    for g in gates:
+        name = _NAMES[g.op]
+        ins = [] if name in ("CONST0", "CONST1") else [g.in0] if name in ("NOT", "COPY") else \
+            [g.in0, g.in1, g.in2] if name == "MUX" else [g.in0, g.in1]
+        lv = max([wr.get(g.out, 0), rd.get(g.out, 0)] + [wr.get(i, 0) for i in ins]) + 1
+        for i in ins:
+            rd[i] = max(rd.get(i, 0), lv)
+        wr[g.out] = lv
+        lev.append(lv)
+    return lev
+
+
+def bootstrap_depth(gates):
+    """dependent levels that hold at least one blind rotation (free gates ride along)"""
+    lev = levels(gates)
+    return len({lv for g, lv in zip(gates, lev) if _NAMES[g.op] not in ("NOT", "COPY", "CONST0", "CONST1")})
+
+
+def netlist_cost(gates, instances, resident_jobs=1024):
+    """Estimated run time of a netlist over `instances` instances, in units of 0.1 ms on one MI355X (Set A): a level
+    holding J = instances x jobs blind rotations runs as J // R full launches (3.0 ms each, R = resident_jobs, 4 per
+    compute unit) and one partly filled launch of J % R rotations costing 1.4 ms + 1.6 ms x max(J % R, R / 4) / R --
+    the measured 1.8 / 2.3 / 3.0 ms at 256 / 512 / 1024 gates (profiles/r05_narrow_gate.txt): below a quarter of the
+    resident set a level costs the same whatever its width, so DEPTH is the cost of a small batch and the number of
+    BOOTSTRAPS that of a large one.  Native twin: eoc_netlist_cost."""
+    R = max(4, int(resident_jobs))
+    jobs = {}
+    for g, lv in zip(gates, levels(gates)):
+        name = _NAMES[g.op]
+        w = 2 if name == "MUX" else 0 if name in ("NOT", "COPY", "CONST0", "CONST1") else 1
+        if w:
+            jobs[lv] = jobs.get(lv, 0) + w
+    cost = 0
+    for lv in sorted(jobs):
+        J = jobs[lv] * int(instances)
+        full, rem = divmod(J, R)
+        cost += 30 * full
+        if rem:
+            cost += 14 + (16 * max(rem, R // 4) + R - 1) // R
+    return cost

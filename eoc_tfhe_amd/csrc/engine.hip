@@ -1015,9 +1015,7 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
     WS &W = e->ws;
-    // levelise: RAW, WAR and WAW hazards on wires
-    std::vector<int> wr_level(n_wires, 0), rd_level(n_wires, 0), level(n_gates, 0);
-    int nlev = 0;
+    // levelise: RAW, WAR and WAW hazards on wires (eoc_levelise, host.cpp -- the same levels eoc_netlist_cost prices)
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &q = gates[k];
         const int nin = op_valid(q.op) ? op_inputs(q.op) : 0;
@@ -1026,20 +1024,14 @@ extern "C" int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size
             eoc_set_error("eoc_circuit_run_device: bad gate %zu", k);
             return EOC_ERR_ARG;
         }
-        int lv = std::max(wr_level[q.out], rd_level[q.out]) + 0;
-        for (int a = 0; a < nin; a++) {
+        for (int a = 0; a < nin; a++)
             if (ins[a] < 0 || (size_t)ins[a] >= n_wires) {
                 eoc_set_error("eoc_circuit_run_device: bad input wire in gate %zu", k);
                 return EOC_ERR_ARG;
             }
-            lv = std::max(lv, wr_level[ins[a]]);
-        }
-        lv += 1;
-        level[k] = lv;
-        for (int a = 0; a < nin; a++) rd_level[ins[a]] = std::max(rd_level[ins[a]], lv);
-        wr_level[q.out] = lv;
-        nlev = std::max(nlev, lv);
     }
+    std::vector<int> level(n_gates, 0);
+    const int nlev = eoc_levelise(gates, n_gates, n_wires, level.data());
     std::vector<std::vector<GateDesc>> boot(nlev + 1), freeg(nlev + 1);
     const size_t wstride = instances * ((size_t)e->p.n + 1);
     size_t max_jobs = 0, max_gate_jobs = 0;

@@ -771,10 +771,16 @@ extern "C" int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int
 }
 
 // ---- netlist rewriting (host side, no GPU): the native twin of eoc_tfhe_amd/circuits.py -------------------
-// NOT is free, but a NOT in front of a bootstrapped gate is unnecessary altogether: the ten two-input boots*
-// gates are closed under input negation (AND with a negated first input IS bootsANDNY, ...), a negated MUX
-// selector swaps the branches, NOT(NOT x) is a COPY; and OR(AND(s, b), ANDNY(s, c)) with single-use inner
-// wires is bootsMUX(s, b, c): 2 blind rotations + 1 key switch instead of 3 + 3.
+// Four passes, repeated until nothing changes (same passes, same order, same result as circuits.optimize):
+//   fold_constants  bootsCONSTANT wires are folded into their readers (a two-input gate with one known input is a constant,
+//                   a COPY or a NOT; MUX with a known branch is a two-input gate: one bootstrap instead of two)
+//   fold_nots       NOT / COPY are free, but in front of a bootstrapped gate unnecessary altogether: the ten two-input boots*
+//                   gates are closed under input negation (AND with a negated first input IS bootsANDNY, ...), a negated MUX
+//                   selector swaps the branches, NOT(NOT x) is a COPY, every reader looks through COPY
+//   fuse_mux        OR(AND(s, b), ANDNY(s, c)) with single-use inner wires is bootsMUX(s, b, c): 2 blind rotations + 1 key
+//                   switch instead of 3 + 3
+//   fuse_carry      the textbook full adder's carry OR(AND(a, b), AND(XOR(a, b), c)) is MUX(XOR(a, b), c, a): 3 bootstraps on
+//                   two dependent levels become 2 on one (the literal 8-bit adder: 40 bootstraps / 17 levels -> 30 / 8)
 namespace {
 inline int sem2(int op, int a, int b)
 {
@@ -805,27 +811,206 @@ inline int op_with_negated_inputs(int op, int n0, int n1)
         if (table_of(o, 0, 0) == want) return o;
     return -1; // unreachable: the family is closed under input negation
 }
-void drop_dead(std::vector<eoc_gate> &g, const std::vector<char> &keep, size_t n_wires)
+inline bool nl_free(int op) { return op >= EOC_NOT; }
+inline int nl_inputs(int op) { return op >= EOC_CONST0 ? 0 : (op >= EOC_NOT ? 1 : (op == EOC_MUX ? 3 : 2)); }
+typedef std::vector<eoc_gate> Netlist;
+
+void drop_dead(Netlist &g, const std::vector<char> &keep, size_t n_wires)
 {
     for (;;) {
         std::vector<int> uses(n_wires, 0);
         for (const eoc_gate &x : g)
             for (int32_t i : {x.in0, x.in1, x.in2})
                 if (i >= 0) uses[i]++;
-        std::vector<eoc_gate> live;
+        Netlist live;
         for (const eoc_gate &x : g)
             if (keep[x.out] || uses[x.out] > 0) live.push_back(x);
         if (live.size() == g.size()) return;
         g.swap(live);
     }
 }
-} // namespace
-
-extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs,
-                                        size_t n_outputs, eoc_gate *gates_out)
+// wire -> index of the gate that writes it (-1: a circuit input), and read counts
+void index_netlist(const Netlist &g, size_t n_wires, std::vector<int64_t> &src, std::vector<int> &uses)
 {
-    if ((!gates && n_gates) || (!outputs && n_outputs) || (!gates_out && n_gates)) return EOC_ERR_ARG;
-    size_t n_wires = 0;
+    src.assign(n_wires, -1);
+    uses.assign(n_wires, 0);
+    for (size_t k = 0; k < g.size(); k++) {
+        src[g[k].out] = (int64_t)k;
+        for (int32_t i : {g[k].in0, g[k].in1, g[k].in2})
+            if (i >= 0) uses[i]++;
+    }
+}
+inline eoc_gate mk(int op, int32_t i0, int32_t i1, int32_t i2, int32_t out)
+{
+    eoc_gate g;
+    g.op = op;
+    g.in0 = i0;
+    g.in1 = i1;
+    g.in2 = i2;
+    g.out = out;
+    return g;
+}
+
+Netlist pass_fold_constants(const Netlist &in, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<signed char> cst(n_wires, -1); // -1 unknown, else the wire's constant value
+    auto constant = [&](int v, int32_t out) {
+        cst[out] = (signed char)v;
+        return mk(v ? EOC_CONST1 : EOC_CONST0, -1, -1, -1, out);
+    };
+    auto unary = [&](int32_t wire, int neg, int32_t out) {
+        if (cst[wire] >= 0) return constant(cst[wire] ^ neg, out);
+        return mk(neg ? EOC_NOT : EOC_COPY, wire, -1, -1, out);
+    };
+    Netlist res;
+    res.reserve(in.size());
+    for (const eoc_gate &g : in) {
+        if (g.op == EOC_CONST0 || g.op == EOC_CONST1) res.push_back(constant(g.op == EOC_CONST1, g.out));
+        else if (g.op == EOC_NOT || g.op == EOC_COPY) res.push_back(unary(g.in0, g.op == EOC_NOT, g.out));
+        else if (g.op == EOC_MUX) {
+            const int32_t s = g.in0, b = g.in1, c = g.in2;
+            const int kb = cst[b], kc = cst[c];
+            if (cst[s] >= 0) res.push_back(unary(cst[s] ? b : c, 0, g.out));
+            else if (kb < 0 && kc < 0) res.push_back(mk(EOC_MUX, s, b, c, g.out));
+            else if (kb >= 0 && kc >= 0) res.push_back(kb == kc ? constant(kb, g.out) : unary(s, kb ? 0 : 1, g.out));
+            else if (kb >= 0) res.push_back(mk(kb ? EOC_OR : EOC_ANDNY, s, c, -1, g.out));
+            else res.push_back(mk(kc ? EOC_ORNY : EOC_AND, s, b, -1, g.out));
+        } else {
+            const int ka = cst[g.in0], kb = cst[g.in1];
+            if (ka >= 0 && kb >= 0) res.push_back(constant(sem2(g.op, ka, kb), g.out));
+            else if (ka >= 0 || kb >= 0) {
+                const int r0 = ka >= 0 ? sem2(g.op, ka, 0) : sem2(g.op, 0, kb);
+                const int r1 = ka >= 0 ? sem2(g.op, ka, 1) : sem2(g.op, 1, kb);
+                const int32_t other = ka >= 0 ? g.in1 : g.in0;
+                res.push_back(r0 == r1 ? constant(r0, g.out) : unary(other, r1 ? 0 : 1, g.out));
+            } else res.push_back(mk(g.op, g.in0, g.in1, -1, g.out));
+        }
+    }
+    drop_dead(res, keep, n_wires);
+    return res;
+}
+
+Netlist pass_fold_nots(const Netlist &in, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<int64_t> src;
+    std::vector<int> uses;
+    index_netlist(in, n_wires, src, uses);
+    auto strip = [&](int32_t wire, int &neg) {
+        neg = 0;
+        while (src[wire] >= 0 && (in[src[wire]].op == EOC_NOT || in[src[wire]].op == EOC_COPY)) {
+            neg ^= in[src[wire]].op == EOC_NOT;
+            wire = in[src[wire]].in0;
+        }
+        return wire;
+    };
+    Netlist res;
+    res.reserve(in.size());
+    for (const eoc_gate &q : in) {
+        eoc_gate g = q;
+        int n0, n1;
+        if (g.op <= EOC_ORYN) {
+            g.in0 = strip(q.in0, n0);
+            g.in1 = strip(q.in1, n1);
+            g.op = op_with_negated_inputs(q.op, n0, n1);
+            g.in2 = -1;
+        } else if (g.op == EOC_MUX) {
+            int nb, nc;
+            g.in0 = strip(q.in0, n0);
+            const int32_t b = strip(q.in1, nb), c = strip(q.in2, nc);
+            g.in1 = nb ? q.in1 : b; // a negated branch stays behind its (free) NOT
+            g.in2 = nc ? q.in2 : c;
+            if (n0) std::swap(g.in1, g.in2);
+        } else if (g.op == EOC_NOT || g.op == EOC_COPY) {
+            g.in0 = strip(q.in0, n0);
+            n0 ^= q.op == EOC_NOT;
+            g.op = n0 ? EOC_NOT : EOC_COPY;
+            g.in1 = g.in2 = -1;
+        }
+        res.push_back(g);
+    }
+    drop_dead(res, keep, n_wires);
+    return res;
+}
+
+Netlist pass_fuse_mux(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<int64_t> src;
+    std::vector<int> uses;
+    index_netlist(cur, n_wires, src, uses);
+    struct Sel { int32_t sel, data; int pol; };
+    auto as_sel = [](const eoc_gate &g, Sel (&o)[2]) {
+        if (g.op == EOC_AND) { o[0] = {g.in0, g.in1, 1}; o[1] = {g.in1, g.in0, 1}; return 2; }
+        if (g.op == EOC_ANDNY) { o[0] = {g.in0, g.in1, 0}; return 1; }
+        if (g.op == EOC_ANDYN) { o[0] = {g.in1, g.in0, 0}; return 1; }
+        return 0;
+    };
+    Netlist fused;
+    fused.reserve(cur.size());
+    for (const eoc_gate &g : cur) {
+        bool done = false;
+        if (g.op == EOC_OR && src[g.in0] >= 0 && src[g.in1] >= 0) {
+            const eoc_gate &x = cur[src[g.in0]], &y = cur[src[g.in1]];
+            const bool inner_ok = uses[x.out] == 1 && uses[y.out] == 1 && !keep[x.out] && !keep[y.out] && x.out != y.out;
+            Sel sx[2], sy[2];
+            const int nx = as_sel(x, sx), ny = as_sel(y, sy);
+            for (int a = 0; inner_ok && a < nx && !done; a++)
+                for (int b = 0; b < ny && !done; b++)
+                    if (sx[a].sel == sy[b].sel && sx[a].pol != sy[b].pol) {
+                        fused.push_back(mk(EOC_MUX, sx[a].sel, sx[a].pol ? sx[a].data : sy[b].data,
+                                           sx[a].pol ? sy[b].data : sx[a].data, g.out));
+                        done = true;
+                    }
+        }
+        if (!done) fused.push_back(g);
+    }
+    drop_dead(fused, keep, n_wires);
+    return fused;
+}
+
+Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<int64_t> src;
+    std::vector<int> uses;
+    index_netlist(cur, n_wires, src, uses);
+    Netlist res;
+    res.reserve(cur.size());
+    for (const eoc_gate &g : cur) {
+        bool done = false;
+        if (g.op == EOC_OR && src[g.in0] >= 0 && src[g.in1] >= 0 && g.in0 != g.in1) {
+            for (int side = 0; side < 2 && !done; side++) { // x = a AND b, y = p AND c
+                const eoc_gate &x = cur[src[side ? g.in1 : g.in0]], &y = cur[src[side ? g.in0 : g.in1]];
+                if (x.op != EOC_AND || y.op != EOC_AND || x.in0 == x.in1) continue;
+                if (uses[x.out] != 1 || uses[y.out] != 1 || keep[x.out] || keep[y.out]) continue;
+                for (int sw = 0; sw < 2 && !done; sw++) {
+                    const int32_t p = sw ? y.in1 : y.in0, c = sw ? y.in0 : y.in1;
+                    if (src[p] < 0) continue;
+                    const eoc_gate &q = cur[src[p]];
+                    if (q.op == EOC_XOR && ((q.in0 == x.in0 && q.in1 == x.in1) || (q.in0 == x.in1 && q.in1 == x.in0))) {
+                        res.push_back(mk(EOC_MUX, p, c, x.in0, g.out));
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (!done) res.push_back(g);
+    }
+    drop_dead(res, keep, n_wires);
+    return res;
+}
+
+inline bool same_netlist(const Netlist &a, const Netlist &b)
+{
+    if (a.size() != b.size()) return false;
+    for (size_t k = 0; k < a.size(); k++)
+        if (a[k].op != b[k].op || a[k].in0 != b[k].in0 || a[k].in1 != b[k].in1 || a[k].in2 != b[k].in2 || a[k].out != b[k].out)
+            return false;
+    return true;
+}
+
+// argument checks shared by the netlist entry points; n_wires = 1 + the largest wire id
+int check_netlist(const eoc_gate *gates, size_t n_gates, size_t &n_wires)
+{
+    if (!gates && n_gates) return EOC_ERR_ARG;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &g = gates[k];
         const bool is_const = g.op == EOC_CONST0 || g.op == EOC_CONST1;
@@ -834,6 +1019,16 @@ extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, c
         if (g.op == EOC_MUX && g.in2 < 0) return EOC_ERR_ARG;
         for (int32_t i : {g.in0, g.in1, g.in2, g.out}) n_wires = std::max(n_wires, (size_t)(i + 1));
     }
+    return EOC_OK;
+}
+} // namespace
+
+extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs,
+                                        size_t n_outputs, eoc_gate *gates_out)
+{
+    if ((!outputs && n_outputs) || (!gates_out && n_gates)) return EOC_ERR_ARG;
+    size_t n_wires = 0;
+    if (check_netlist(gates, n_gates, n_wires)) return EOC_ERR_ARG;
     for (size_t k = 0; k < n_outputs; k++) {
         if (outputs[k] < 0) return EOC_ERR_ARG;
         n_wires = std::max(n_wires, (size_t)outputs[k] + 1);
@@ -843,8 +1038,8 @@ extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, c
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &g = gates[k];
         if (src[g.out] >= 0) return EOC_ERR_ARG;
-        for (int32_t i : {g.in0, g.in1, g.in2})
-            if (i >= 0 && i == g.out) return EOC_ERR_ARG;
+        for (int k2 = 0; k2 < nl_inputs(g.op); k2++)
+            if ((k2 == 0 ? g.in0 : k2 == 1 ? g.in1 : g.in2) == g.out) return EOC_ERR_ARG;
         src[g.out] = (int64_t)k;
     }
     for (size_t k = 0; k < n_gates; k++)
@@ -853,77 +1048,76 @@ extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, c
     std::vector<char> keep(n_wires, 0);
     for (size_t k = 0; k < n_outputs; k++) keep[outputs[k]] = 1;
 
-    // pass 1: fold NOTs into their readers
-    auto strip = [&](int32_t wire, int &neg) {
-        neg = 0;
-        while (src[wire] >= 0 && gates[src[wire]].op == EOC_NOT) {
-            wire = gates[src[wire]].in0;
-            neg ^= 1;
-        }
-        return wire;
-    };
-    std::vector<eoc_gate> cur;
+    Netlist cur;
     cur.reserve(n_gates);
-    for (size_t k = 0; k < n_gates; k++) {
-        eoc_gate g = gates[k];
-        int n0, n1;
-        if (g.op <= EOC_ORYN) {
-            g.in0 = strip(g.in0, n0);
-            g.in1 = strip(g.in1, n1);
-            g.op = op_with_negated_inputs(g.op, n0, n1);
-            g.in2 = -1;
-        } else if (g.op == EOC_MUX) {
-            g.in0 = strip(g.in0, n0);
-            if (n0) std::swap(g.in1, g.in2);
-        } else if (g.op == EOC_NOT) {
-            g.in0 = strip(g.in0, n0);
-            g.op = n0 ? EOC_COPY : EOC_NOT;
-            g.in1 = g.in2 = -1;
-        }
-        cur.push_back(g);
+    for (size_t k = 0; k < n_gates; k++) { // unused input slots are normalised to -1 (the passes compare gates field by field)
+        const eoc_gate &g = gates[k];
+        const int nin = nl_inputs(g.op);
+        cur.push_back(mk(g.op, nin > 0 ? g.in0 : -1, nin > 1 ? g.in1 : -1, nin > 2 ? g.in2 : -1, g.out));
     }
-    drop_dead(cur, keep, n_wires);
+    for (int round = 0; round < 8; round++) {
+        Netlist nxt = pass_fuse_carry(
+            pass_fuse_mux(pass_fold_nots(pass_fold_constants(cur, keep, n_wires), keep, n_wires), keep, n_wires), keep, n_wires);
+        const bool same = same_netlist(nxt, cur);
+        cur.swap(nxt);
+        if (same) break;
+    }
+    std::copy(cur.begin(), cur.end(), gates_out);
+    return (int64_t)cur.size();
+}
 
-    // pass 2: OR(sel & b, ~sel & c) -> MUX
-    std::vector<int64_t> src2(n_wires, -1);
-    std::vector<int> uses(n_wires, 0);
-    for (size_t k = 0; k < cur.size(); k++) {
-        src2[cur[k].out] = (int64_t)k;
-        for (int32_t i : {cur[k].in0, cur[k].in1, cur[k].in2})
-            if (i >= 0) uses[i]++;
+// levelisation of a netlist exactly as eoc_circuit_run_device evaluates it: RAW, WAR and WAW hazards on wires (a netlist
+// need not be single-assignment to RUN).  level_of[n_gates], 1-based; returns the number of levels.
+int eoc_levelise(const eoc_gate *gates, size_t n_gates, size_t n_wires, int *level_of)
+{
+    std::vector<int> wr_level(n_wires, 0), rd_level(n_wires, 0);
+    int nlev = 0;
+    for (size_t k = 0; k < n_gates; k++) {
+        const eoc_gate &q = gates[k];
+        const int nin = nl_inputs(q.op);
+        const int32_t ins[3] = {q.in0, q.in1, q.in2};
+        int lv = std::max(wr_level[q.out], rd_level[q.out]);
+        for (int a = 0; a < nin; a++) lv = std::max(lv, wr_level[ins[a]]);
+        lv += 1;
+        level_of[k] = lv;
+        for (int a = 0; a < nin; a++) rd_level[ins[a]] = std::max(rd_level[ins[a]], lv);
+        wr_level[q.out] = lv;
+        nlev = std::max(nlev, lv);
     }
-    struct Sel { int32_t sel, data; int pol; };
-    auto as_sel = [](const eoc_gate &g, Sel (&o)[2]) {
-        if (g.op == EOC_AND) { o[0] = {g.in0, g.in1, 1}; o[1] = {g.in1, g.in0, 1}; return 2; }
-        if (g.op == EOC_ANDNY) { o[0] = {g.in0, g.in1, 0}; return 1; }
-        if (g.op == EOC_ANDYN) { o[0] = {g.in1, g.in0, 0}; return 1; }
-        return 0;
-    };
-    std::vector<eoc_gate> fused;
-    fused.reserve(cur.size());
-    for (const eoc_gate &g : cur) {
-        bool done = false;
-        if (g.op == EOC_OR && src2[g.in0] >= 0 && src2[g.in1] >= 0) {
-            const eoc_gate &x = cur[src2[g.in0]], &y = cur[src2[g.in1]];
-            const bool inner_ok = uses[x.out] == 1 && uses[y.out] == 1 && !keep[x.out] && !keep[y.out];
-            Sel sx[2], sy[2];
-            const int nx = as_sel(x, sx), ny = as_sel(y, sy);
-            for (int a = 0; inner_ok && a < nx && !done; a++)
-                for (int b = 0; b < ny && !done; b++)
-                    if (sx[a].sel == sy[b].sel && sx[a].pol != sy[b].pol) {
-                        eoc_gate m;
-                        m.op = EOC_MUX;
-                        m.in0 = sx[a].sel;
-                        m.in1 = sx[a].pol ? sx[a].data : sy[b].data;
-                        m.in2 = sx[a].pol ? sy[b].data : sx[a].data;
-                        m.out = g.out;
-                        fused.push_back(m);
-                        done = true;
-                    }
-        }
-        if (!done) fused.push_back(g);
+    return nlev;
+}
+
+extern "C" int64_t eoc_netlist_levels(const eoc_gate *gates, size_t n_gates, int32_t *level_of, int64_t *bootstrap_levels)
+{
+    size_t n_wires = 0;
+    if (check_netlist(gates, n_gates, n_wires)) return EOC_ERR_ARG;
+    std::vector<int> lev(n_gates, 0);
+    const int nlev = eoc_levelise(gates, n_gates, n_wires, lev.data());
+    if (level_of)
+        for (size_t k = 0; k < n_gates; k++) level_of[k] = lev[k];
+    if (bootstrap_levels) {
+        std::vector<char> has(nlev + 1, 0);
+        for (size_t k = 0; k < n_gates; k++)
+            if (!nl_free(gates[k].op)) has[lev[k]] = 1;
+        *bootstrap_levels = std::count(has.begin(), has.end(), (char)1);
     }
-    drop_dead(fused, keep, n_wires);
-    std::copy(fused.begin(), fused.end(), gates_out);
-    return (int64_t)fused.size();
+    return nlev;
+}
+
+extern "C" int64_t eoc_netlist_cost(const eoc_gate *gates, size_t n_gates, size_t instances, size_t resident_jobs)
+{
+    size_t n_wires = 0;
+    if (check_netlist(gates, n_gates, n_wires)) return EOC_ERR_ARG;
+    const uint64_t R = std::max<uint64_t>(4, resident_jobs ? resident_jobs : 1024);
+    std::vector<int> lev(n_gates, 0);
+    const int nlev = eoc_levelise(gates, n_gates, n_wires, lev.data());
+    std::vector<uint64_t> jobs(nlev + 1, 0);
+    for (size_t k = 0; k < n_gates; k++) jobs[lev[k]] += gates[k].op == EOC_MUX ? 2 : (nl_free(gates[k].op) ? 0 : 1);
+    uint64_t cost = 0;
+    for (int lv = 1; lv <= nlev; lv++) {
+        const uint64_t J = jobs[lv] * (uint64_t)instances, full = J / R, rem = J % R;
+        cost += 30 * full;
+        if (rem) cost += 14 + (16 * std::max(rem, R / 4) + R - 1) / R;
+    }
+    return (int64_t)cost;
 }

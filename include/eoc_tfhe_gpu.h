@@ -221,14 +221,30 @@ int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size_t n_gates,
                            size_t n_wires, size_t instances, void *hip_stream);
 /* number of bootstraps (blind rotations) a netlist costs per instance: MUX = 2, NOT/COPY = 0 */
 size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
-/* Netlist rewriting on the host (no GPU): folds NOT gates into their readers (the ten two-input gates are closed
- * under input negation; a negated MUX selector swaps the branches; NOT(NOT x) = COPY), turns
- * OR(AND(s, b), ANDNY(s, c)) with single-use inner wires into MUX(s, b, c), and drops gates nobody reads.
- * `outputs` are the wires the caller reads afterwards.  Single-assignment netlists only (every wire written at most
- * once, after its readers' inputs): otherwise EOC_ERR_ARG.  gates_out has room for n_gates entries (may alias
- * nothing); returns the number of gates written.  Same wire numbering, never more bootstraps. */
+/* Netlist rewriting on the host (no GPU), four passes repeated until nothing changes:
+ *   constants   bootsCONSTANT wires are folded into their readers (AND(x, 0) = 0, XOR(x, 1) = NOT x, MUX(s, 0, c) = ANDNY(s, c),
+ *               MUX(s, b, 1) = ORNY(s, b), ...: a MUX with a known branch costs one bootstrap instead of two)
+ *   NOT / COPY  folded into their readers (the ten two-input gates are closed under input negation; a negated MUX selector
+ *               swaps the branches; NOT(NOT x) = COPY; every reader looks through COPY)
+ *   MUX fusion  OR(AND(s, b), ANDNY(s, c)) with single-use inner wires -> MUX(s, b, c)
+ *   carry       OR(AND(a, b), AND(XOR(a, b), c)) with single-use AND wires -> MUX(XOR(a, b), c, a): the textbook full adder's
+ *               carry as ONE gate on ONE level (the literal 8-bit ripple-carry adder: 40 bootstraps / 17 levels -> 30 / 8)
+ * and gates nobody reads are dropped.  `outputs` are the wires the caller reads afterwards.  Single-assignment netlists
+ * only (every wire written at most once, after its readers' inputs): otherwise EOC_ERR_ARG.  gates_out has room for n_gates
+ * entries; returns the number of gates written.  Same wire numbering, never more bootstraps, never more levels. */
 int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
                              eoc_gate *gates_out);
+/* levels of a netlist exactly as eoc_circuit_run_device assigns them (RAW, WAR, WAW hazards; 1-based; level_of[n_gates] or
+ * NULL); *bootstrap_levels (or NULL) = levels that hold at least one blind rotation -- the sequential depth a small batch
+ * pays for.  Returns the number of levels. */
+int64_t eoc_netlist_levels(const eoc_gate *gates, size_t n_gates, int32_t *level_of, int64_t *bootstrap_levels);
+/* Estimated run time of a netlist over `instances` instances, in units of 0.1 ms on one MI355X (Set A): a level of
+ * J = instances x jobs blind rotations runs as J / R full launches (3.0 ms) plus one partly filled launch costing
+ * 1.4 ms + 1.6 ms x max(J mod R, R / 4) / R (measured: 1.8 / 2.3 / 3.0 ms at 256 / 512 / 1024 gates; R = resident_jobs, 0 =
+ * 1024 = four ciphertexts per compute unit).  Below R / 4 a level costs the same whatever its width: DEPTH is the cost of a
+ * small batch, BOOTSTRAPS that of a large one -- what the facades' addBits / lessThanBits use to pick a circuit form
+ * (ripple / MUX-carry / parallel-prefix) for an instance count.  No GPU needed. */
+int64_t eoc_netlist_cost(const eoc_gate *gates, size_t n_gates, size_t instances, size_t resident_jobs);
 
 /* building blocks exposed for parity tests and profiling (device pointers, async) */
 int eoc_dbg_fft_fwd_device(eoc_engine *e, const int32_t *d_polys, double *d_specs, size_t count,

@@ -145,15 +145,17 @@ def test_fuse_mux_keeps_shared_inner_wires():
 
 def test_random_netlists_rewrite_is_equivalent():
     rng = np.random.default_rng(11)
-    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "COPY"]
-    for trial in range(60):
+    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "MUX", "COPY", "CONST0", "CONST1"]
+    for trial in range(300):
         n_in, n_g = 4, int(rng.integers(5, 40))
         gates, avail = [], list(range(n_in))
         for k in range(n_g):
             name = names[int(rng.integers(0, len(names)))]
             pick = lambda: int(avail[int(rng.integers(0, len(avail)))])
             out = n_in + k
-            if name in ("NOT", "COPY"):
+            if name in ("CONST0", "CONST1"):
+                gates.append(Gate(OPS[name], -1, -1, -1, out))
+            elif name in ("NOT", "COPY"):
                 gates.append(Gate(OPS[name], pick(), -1, -1, out))
             elif name == "MUX":
                 gates.append(Gate(OPS[name], pick(), pick(), pick(), out))
@@ -163,6 +165,7 @@ def test_random_netlists_rewrite_is_equivalent():
         outs = [int(v) for v in rng.choice(avail[n_in:], size=min(3, n_g), replace=False)]
         opt = c.optimize(gates, outs)
         assert circuit_bootstraps(opt) <= circuit_bootstraps(gates)
+        assert c.bootstrap_depth(opt) <= c.bootstrap_depth(gates)
         w = np.zeros((n_in + n_g, 16), np.uint8)
         for k in range(16):
             for i in range(n_in):
@@ -182,9 +185,9 @@ def test_native_optimizer_matches_python(built_lib):
     """eoc_netlist_optimize (C ABI, host.cpp) rewrites exactly like circuits.optimize"""
     import eoc_tfhe_amd as eoc
     rng = np.random.default_rng(23)
-    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "COPY", "CONST0", "CONST1"]
+    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "MUX", "COPY", "CONST0", "CONST1"]
     as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
-    for trial in range(80):
+    for trial in range(400):
         n_in, n_g = 4, int(rng.integers(1, 50))
         gates, avail = [], list(range(n_in))
         for k in range(n_g):
@@ -208,6 +211,10 @@ def test_native_optimizer_matches_python(built_lib):
         ref, opt = c.evaluate_plain(gates, w), c.evaluate_plain(c.optimize(gates, outs), w)
         assert all(np.array_equal(ref[o], opt[o]) for o in outs), trial
         assert as_t(eoc.netlist_optimize(gates, outs)) == as_t(c.optimize(gates, outs)), trial
+        lv, nlev, depth = eoc.netlist_levels(gates)
+        assert lv == c.levels(gates) and nlev == max(lv) and depth == c.bootstrap_depth(gates), trial
+        for S in (1, 7, 300, 5000):
+            assert eoc.netlist_cost(gates, S, 1024) == c.netlist_cost(gates, S, 1024), (trial, S)
     # the word-select example: 1 NOT + 3 gates per bit -> 1 MUX per bit
     gates = [Gate(OPS["NOT"], 0, -1, -1, 9)]
     outs = []
@@ -244,3 +251,146 @@ def test_subtractor_and_multiplier_all_inputs(nbits):
     opt = c.optimize(gates, p)
     assert circuit_bootstraps(opt) <= circuit_bootstraps(gates)
     assert np.array_equal(_value(c.evaluate_plain(opt, w), p), A * B)
+
+
+# ---- round 6: the carry rewrite, constant folding, and the forms picked by instance count ---------------------------
+
+def _adder_check(gates, nw, a, b, s, nbits):
+    A, B, S = _words(nbits)
+    w = np.zeros((nw, S), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    assert np.array_equal(_value(c.evaluate_plain(gates, w), s), A + B)
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5, 6])
+def test_adder_forms_all_inputs(nbits):
+    """every adder form, every input pair; the bootstrap counts and depths the docstrings state"""
+    for name, build in c.ADDER_FORMS.items():
+        gates, nw, a, b, s = build(nbits)
+        c._check_ssa(gates)
+        _adder_check(gates, nw, a, b, s, nbits)
+    assert circuit_bootstraps(c.mux_carry_adder(nbits)[0]) == 2 + 4 * (nbits - 1)
+    assert c.bootstrap_depth(c.mux_carry_adder(nbits)[0]) == nbits
+    if nbits > 1:       # 1 (p, g) + prefix levels + 1 (sums); the top sum bit may be ready a level early
+        assert 1 + (nbits - 1).bit_length() <= c.bootstrap_depth(c.prefix_adder(nbits)[0]) <= 2 + (nbits - 1).bit_length()
+
+
+def test_adder_forms_eight_bits_counts():
+    ripple, mux, prefix = (f(8)[0] for f in (c.ADDER_FORMS["ripple"], c.mux_carry_adder, c.prefix_adder))
+    assert (circuit_bootstraps(ripple), c.bootstrap_depth(ripple)) == (37, 15)
+    assert (circuit_bootstraps(mux), c.bootstrap_depth(mux)) == (30, 8)
+    assert (circuit_bootstraps(prefix), c.bootstrap_depth(prefix)) == (48, 5)
+    rng = np.random.default_rng(8)
+    A, B = rng.integers(0, 256, 4000), rng.integers(0, 256, 4000)
+    for build in (c.mux_carry_adder, c.prefix_adder):
+        gates, nw, a, b, s = build(8)
+        w = np.zeros((nw, 4000), np.uint8)
+        _load(w, a, A)
+        _load(w, b, B)
+        assert np.array_equal(_value(c.evaluate_plain(gates, w), s), A + B)
+    gates, nw, a, b, s = c.prefix_adder(16)
+    A, B = rng.integers(0, 1 << 16, 4000), rng.integers(0, 1 << 16, 4000)
+    w = np.zeros((nw, 4000), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    assert np.array_equal(_value(c.evaluate_plain(gates, w), s), A + B)
+    assert c.bootstrap_depth(gates) == 6
+
+
+@pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5, 7])
+def test_less_than_tree_all_inputs(nbits):
+    A, B, S = _words(nbits)
+    gates, nw, a, b, lt = c.less_than_tree(nbits)
+    c._check_ssa(gates)
+    w = np.zeros((nw, S), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    assert np.array_equal(c.evaluate_plain(gates, w)[lt], (A < B).astype(np.uint8))
+    assert c.bootstrap_depth(gates) == (1 + (nbits - 1).bit_length() if nbits > 1 else 1)
+    g8 = c.less_than_tree(8)[0]
+    assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (29, 4)
+
+
+def test_carry_rewrite_on_the_literal_adder():
+    """VERDICT r5 task 1a: OR(AND(a, b), AND(XOR(a, b), c)) -> MUX(XOR(a, b), c, a).  BASELINE configs[2]'s literal
+    netlist (40 bootstraps, 17 dependent levels) becomes 32 bootstraps on 9 levels by the carry rewrite alone and 30 on 8 once
+    the constant carry-in is folded; sums unchanged for every input pair at 4 bits and for random 8-bit pairs"""
+    gates, nw, a, b, s = c.ripple_carry_adder(8, carry_in_zero=True)
+    only_carry = c.fuse_carry(gates, s)
+    assert circuit_bootstraps(gates) == 40 and c.bootstrap_depth(gates) == 17
+    assert circuit_bootstraps(only_carry) == 32 and c.bootstrap_depth(only_carry) == 9
+    assert sum(1 for g in only_carry if g.op == OPS["MUX"]) == 8
+    opt = c.optimize(gates, s)
+    assert circuit_bootstraps(opt) == 30 and c.bootstrap_depth(opt) == 8
+    rng = np.random.default_rng(6)
+    A, B = rng.integers(0, 256, 3000), rng.integers(0, 256, 3000)
+    for nl in (only_carry, opt):
+        w = np.zeros((nw, 3000), np.uint8)
+        _load(w, a, A)
+        _load(w, b, B)
+        assert np.array_equal(_value(c.evaluate_plain(nl, w), s), A + B)
+    for carry_in_zero in (False, True):
+        gates, nw, a, b, s = c.ripple_carry_adder(4, carry_in_zero=carry_in_zero)
+        _adder_check(c.optimize(gates, s), nw, a, b, s, 4)
+        _adder_check(c.fuse_carry(gates, s), nw, a, b, s, 4)
+    # every operand order of the pattern; a shared AND wire blocks it
+    for g_ab in ((0, 1), (1, 0)):
+        for x_ab in ((0, 1), (1, 0)):
+            for pc_swap in (0, 1):
+                for or_swap in (0, 1):
+                    nl = [Gate(OPS["XOR"], x_ab[0], x_ab[1], -1, 3), Gate(OPS["AND"], g_ab[0], g_ab[1], -1, 4),
+                          Gate(OPS["AND"], *((2, 3) if pc_swap else (3, 2)), -1, 5),
+                          Gate(OPS["OR"], *((5, 4) if or_swap else (4, 5)), -1, 6)]
+                    opt = c.fuse_carry(nl, [6])
+                    assert [c._NAMES[g.op] for g in opt] == ["XOR", "MUX"], (g_ab, x_ab, pc_swap, or_swap)
+                    w = np.zeros((7, 8), np.uint8)
+                    for k in range(8):
+                        w[0, k], w[1, k], w[2, k] = k & 1, (k >> 1) & 1, (k >> 2) & 1
+                    assert np.array_equal(c.evaluate_plain(nl, w)[6], c.evaluate_plain(opt, w)[6])
+    shared = [Gate(OPS["XOR"], 0, 1, -1, 3), Gate(OPS["AND"], 0, 1, -1, 4), Gate(OPS["AND"], 3, 2, -1, 5),
+              Gate(OPS["OR"], 4, 5, -1, 6), Gate(OPS["XOR"], 4, 2, -1, 7)]
+    assert [c._NAMES[g.op] for g in c.fuse_carry(shared, [6, 7])] == ["XOR", "AND", "AND", "OR", "XOR"]
+
+
+def test_constant_folding_every_gate_and_position():
+    two = list(c._SEM2)
+    for name in two:
+        for pos in (0, 1, 2):                           # which input is constant (2 = both)
+            for v in (0, 1):
+                for v2 in (0, 1):
+                    nl = [Gate(OPS["CONST1" if v else "CONST0"], -1, -1, -1, 2), Gate(OPS["CONST1" if v2 else "CONST0"], -1, -1, -1, 3)]
+                    ins = (2, 1) if pos == 0 else (0, 2) if pos == 1 else (2, 3)
+                    nl.append(Gate(OPS[name], ins[0], ins[1], -1, 4))
+                    opt = c.fold_constants(nl, [4])
+                    assert circuit_bootstraps(opt) == 0, (name, pos, v)
+                    w = np.zeros((5, 4), np.uint8)
+                    w[0], w[1] = [0, 0, 1, 1], [0, 1, 0, 1]
+                    assert np.array_equal(c.evaluate_plain(nl, w)[4], c.evaluate_plain(opt, w)[4]), (name, pos, v, v2)
+    for mask in range(1, 27):                           # MUX: each of selector / branches unknown, 0 or 1 (base 3 digits)
+        k = [(mask // 3 ** i) % 3 for i in range(3)]
+        nl = [Gate(OPS["CONST0"], -1, -1, -1, 3), Gate(OPS["CONST1"], -1, -1, -1, 4)]
+        ins = [i if k[i] == 0 else 2 + k[i] for i in range(3)]
+        nl.append(Gate(OPS["MUX"], ins[0], ins[1], ins[2], 5))
+        opt = c.fold_constants(nl, [5])
+        assert circuit_bootstraps(opt) <= 1, k
+        w = np.zeros((6, 8), np.uint8)
+        for j in range(8):
+            w[0, j], w[1, j], w[2, j] = j & 1, (j >> 1) & 1, (j >> 2) & 1
+        assert np.array_equal(c.evaluate_plain(nl, w)[5], c.evaluate_plain(opt, w)[5]), k
+
+
+def test_form_is_picked_by_instance_count():
+    """fewest LEVELS below a quarter of the resident set, fewest BOOTSTRAPS for wide batches (VERDICT r5 task 1b)"""
+    for S in (1, 8, 64):
+        assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k != "ripple"}, 8, S)[0] == "prefix"
+        assert c.pick_form(c.LESS_THAN_FORMS, 8, S)[0] == "tree"
+    for S in (1024, 4096, 100000):
+        assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k != "ripple"}, 8, S)[0] == "mux"
+        assert c.pick_form(c.LESS_THAN_FORMS, 8, S)[0] == "ripple"
+    small, wide = c.adder(8, 8)[0], c.adder(8, 4096)[0]
+    assert c.bootstrap_depth(small) == 5 and circuit_bootstraps(wide) == 30
+    # the estimate: below a quarter of the resident set a level costs the same whatever its width
+    g = c.prefix_adder(8)[0]
+    assert c.netlist_cost(g, 1) == c.netlist_cost(g, 8) == 18 * 5
+    assert c.netlist_cost(c.mux_carry_adder(8)[0], 4096) == 30 * 30 * 4
