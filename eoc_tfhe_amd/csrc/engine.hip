@@ -72,6 +72,8 @@ struct eoc_engine {
     int prio_multi = -1;                    // duty code of launches of several rounds (EOC_TFHE_PRIO_MULTI)
     int br_slice = 0;                       // jobs per blind-rotate launch: 0 = resident set, < 0 = unlimited (EOC_TFHE_BR_SLICE)
     bool no_fold = false;                   // EOC_TFHE_NO_FOLD: keep k_prepare and k_ks_init as launches of their own
+    bool scalar_abar = false;               // EOC_TFHE_SCALAR_ABAR: rotation amounts read back by scalar loads (kernels.hip.h)
+    bool no_pool = false;                   // EOC_TFHE_NO_POOL: every opcode run of a mixed batch is a level of its own
     int br_parts = 0;                       // consecutive launches per blind rotation (EOC_TFHE_BR_PARTS); 0 = by key-row size
     int br_wide = -1;                       // one-wave-per-ciphertext kernel: -1 = by launch width, 0 = never, 1 = whenever l = 2 (EOC_TFHE_BR_WIDE)
     int bara_stride = 0;
@@ -230,7 +232,7 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
     e->p = *p;
     e->kpl = 2 * p->l;
     e->n1p = eoc_ksk_row_stride(p);
-    e->bara_stride = (p->n + 1 + 7) / 8 * 8;
+    e->bara_stride = (p->n + 1 + 31) / 32 * 32; // rows 64 bytes apart: two jobs never share a (scalar) cache line
     int rc = upload_tables(e);
     if (rc) {
         delete e;
@@ -243,6 +245,8 @@ extern "C" int eoc_engine_create(int device, const eoc_params *p, eoc_engine **o
         if (const char *s = getenv("EOC_TFHE_PRIO_MULTI")) e->prio_multi = atoi(s);
         if (const char *s = getenv("EOC_TFHE_BR_SLICE")) e->br_slice = atoi(s);
         if (getenv("EOC_TFHE_NO_FOLD")) e->no_fold = true;
+        if (getenv("EOC_TFHE_NO_POOL")) e->no_pool = true;
+        if (const char *s = getenv("EOC_TFHE_SCALAR_ABAR")) e->scalar_abar = atoi(s) != 0;
         if (const char *s = getenv("EOC_TFHE_BR_PARTS")) e->br_parts = atoi(s);
         if (const char *s = getenv("EOC_TFHE_BR_WIDE")) e->br_wide = atoi(s);
     }
@@ -636,26 +640,29 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
             a.prio_duty = (e->prio_duty_override != INT32_MIN) ? e->prio_duty_override
                           : (njobs <= resident ? kPrioDuty : e->prio_multi);
             dim3 grid(njobs), block(128);
+            // SABAR: the rotation amounts read back by scalar loads (EOC_TFHE_SCALAR_ABAR=1) instead of vector loads
+#define EOC_BR_LAUNCH(KERNEL_, LDS_, ...)                                                                          \
+    do {                                                                                                          \
+        if (e->scalar_abar) hipLaunchKernelGGL((KERNEL_<__VA_ARGS__, true>), grid, block, LDS_, st, a, e->d_tw, e->d_twist);  \
+        else hipLaunchKernelGGL((KERNEL_<__VA_ARGS__, false>), grid, block, LDS_, st, a, e->d_tw, e->d_twist);     \
+    } while (0)
             if (wide) {
                 grid = dim3((njobs + kBRWideJobsPerWG - 1) / kBRWideJobsPerWG);
                 block = dim3(64 * kBRWideJobsPerWG);
-                if (e->p.Bgbit == 10) // Set A
-                    hipLaunchKernelGGL((k_blind_rotate_wide<10>), grid, block, kBRWideLds, st, a, e->d_tw, e->d_twist);
-                else
-                    hipLaunchKernelGGL((k_blind_rotate_wide<0>), grid, block, kBRWideLds, st, a, e->d_tw, e->d_twist);
+                if (e->p.Bgbit == 10) EOC_BR_LAUNCH(k_blind_rotate_wide, kBRWideLds, 10); // Set A
+                else EOC_BR_LAUNCH(k_blind_rotate_wide, kBRWideLds, 0);
                 e->br_wide_launches++;
-            } else if (e->p.l == 2 && e->p.Bgbit == 10) // Set A
-                hipLaunchKernelGGL((k_blind_rotate<2, 10>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
-            else if (e->p.l == 3 && e->p.Bgbit == 7) // Set B
-                hipLaunchKernelGGL((k_blind_rotate<3, 7>), grid, block, kBRLds, st, a, e->d_tw, e->d_twist);
+            } else if (e->p.l == 2 && e->p.Bgbit == 10) EOC_BR_LAUNCH(k_blind_rotate, kBRLds, 2, 10); // Set A
+            else if (e->p.l == 3 && e->p.Bgbit == 7) EOC_BR_LAUNCH(k_blind_rotate, kBRLds, 3, 7);     // Set B
             else
                 switch (e->p.l) {
-                case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-                case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-                case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
-                case 4: hipLaunchKernelGGL(k_blind_rotate<4>, grid, block, kBRLds, st, a, e->d_tw, e->d_twist); break;
+                case 1: EOC_BR_LAUNCH(k_blind_rotate, kBRLds, 1, 0); break;
+                case 2: EOC_BR_LAUNCH(k_blind_rotate, kBRLds, 2, 0); break;
+                case 3: EOC_BR_LAUNCH(k_blind_rotate, kBRLds, 3, 0); break;
+                case 4: EOC_BR_LAUNCH(k_blind_rotate, kBRLds, 4, 0); break;
                 default: return EOC_ERR_ARG;
                 }
+#undef EOC_BR_LAUNCH
             HIP_TRY(hipGetLastError());
             e->br_launches++;
         }
@@ -832,6 +839,56 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
     return EOC_OK;
 }
 
+// One POOL: bootstrapped gate groups that are independent of each other but run over DIFFERENT numbers of rows (the
+// opcode runs of a mixed batch: the two-input block over j rows, the MUX run over m rows -- 2 m blind rotations).  Every
+// job is "a row of rotation amounts", so all groups share ONE blind rotation over the concatenated jobs -- one partly
+// filled last launch per call instead of one per group -- between a k_prepare and a key-switch set-up per group (which is
+// where the groups differ: row count, linear stage, one extracted sample or the sum of two).  Bit-identical to running
+// the groups as levels of their own: a job's result does not depend on its position in the launch.
+struct PoolItem {
+    GateDesc d;
+    size_t S;
+};
+static int run_pool(eoc_engine *e, WS &W, std::vector<PoolItem> &pool, hipStream_t st)
+{
+    const int n = e->p.n;
+    size_t jobs = 0;
+    std::vector<GateDesc> descs;
+    descs.reserve(pool.size());
+    for (PoolItem &it : pool) {
+        it.d.job_base = (uint32_t)jobs;
+        jobs += it.S * (it.d.op == OP_MUX ? 2 : 1);
+        descs.push_back(it.d);
+    }
+    if (jobs > W.ws_jobs || jobs > 0xFFFFFFFFull) {
+        eoc_set_error("internal: workspace too small for a pooled level (%zu jobs > %zu)", jobs, W.ws_jobs);
+        return EOC_ERR_STATE;
+    }
+    GateDesc *dd = nullptr;
+    int rc = push_descs(W, descs.data(), descs.size(), st, &dd);
+    if (rc) return rc;
+    {
+        SpanGuard span(e, st, KIND_PREPARE);
+        for (size_t k = 0; k < pool.size(); k++) {
+            const size_t S = pool[k].S;
+            dim3 grid((unsigned)(S * (pool[k].d.op == OP_MUX ? 2 : 1)), (unsigned)((n + 1 + 255) / 256), 1);
+            hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd + k, n, (uint32_t)S, W.d_bara, e->bara_stride);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    rc = launch_blind_rotate(e, W, (uint32_t)jobs, st);
+    if (rc) return rc;
+    for (size_t k = 0; k < pool.size(); k++) {
+        rc = launch_keyswitch(e, W, dd + k, 1, (uint32_t)pool[k].S, st);
+        if (rc) return rc;
+        e->stats[2] += pool[k].S;
+    }
+    e->stats[0] += 1;
+    e->stats[1] += jobs;
+    ring_mark(W, st);
+    return EOC_OK;
+}
+
 // ---- batch of independent gates --------------------------------------------------------------
 static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const int32_t *d_in0, const int32_t *d_in1,
                          const int32_t *d_in2, int32_t *d_out, size_t count, hipStream_t st)
@@ -869,15 +926,18 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
     const int32_t *in0 = d_in0, *in1 = d_in1, *in2 = d_in2;
     int32_t *out = d_out;
     const bool gather = runs > 15; // more runs than opcodes: sorting pays
+    // every bootstrapped row of the call is one job of ONE blind rotation (run_pool), a MUX row two
     size_t max_jobs = 0;
-    {
+    for (size_t k = 0; k < count; k++) max_jobs += ops[k] == OP_MUX ? 2 : (op_free(ops[k]) ? 0 : 1);
+    if (e->no_pool) { // diagnostics (EOC_TFHE_NO_POOL=1): every opcode run is a level of its own, as before round 6
         size_t cnt_op[OP_CONST1 + 1] = {0}, run = 0;
+        max_jobs = 0;
         for (size_t k = 0; k < count; k++) {
             cnt_op[ops[k]]++;
             run = (k && ops[k] == ops[k - 1]) ? run + 1 : 1;
             if (!gather) max_jobs = std::max(max_jobs, run * (ops[k] == OP_MUX ? 2 : 1));
         }
-        if (gather) { // the two-input opcodes run as ONE level (OP_MULTI), MUX as another
+        if (gather) {
             size_t two_input = 0;
             for (int o = 0; o < OP_MUX; o++) two_input += cnt_op[o];
             max_jobs = std::max(two_input, 2 * cnt_op[OP_MUX]);
@@ -936,19 +996,28 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         out = go;
         run_ops = sorted_ops.data();
     }
+    // The opcode runs are independent of each other.  Free runs (NOT / COPY / CONSTANT) go straight to k_free_gates; the
+    // bootstrapped runs are collected and share ONE blind rotation (run_pool) -- unless there is only one, which keeps the
+    // folded single-level path (its descriptor as a kernel argument, no k_prepare / k_ks_init launches).
+    std::vector<PoolItem> pool;
+    auto flush_one = [&](const GateDesc &d, size_t S) -> int {
+        boot.clear();
+        freeg.clear();
+        (op_free(d.op) ? freeg : boot).push_back(d);
+        return run_level(e, W, boot, freeg, S, st);
+    };
     size_t i = 0;
     if (gather) {
         // opcode-sorted: the rows of the ten two-input opcodes come first and differ only in their linear stage -- one
-        // level over all of them (a run of its own per opcode would end each in a partly filled launch)
+        // group over all of them (a run of its own per opcode would end each in a partly filled launch)
         size_t j = 0;
         while (j < count && run_ops[j] < OP_MUX) j++;
         if (j > 0 && run_ops[0] != run_ops[j - 1]) {
             GateDesc d{OP_MULTI, 0, in0, in1, reinterpret_cast<const int32_t *>(d_perm), out};
-            boot.clear();
-            freeg.clear();
-            boot.push_back(d);
-            rc = run_level(e, W, boot, freeg, j, st);
-            if (rc) return rc;
+            if (e->no_pool) {
+                rc = flush_one(d, j);
+                if (rc) return rc;
+            } else pool.push_back({d, j});
             i = j;
         }
     }
@@ -958,13 +1027,15 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         int o = run_ops[i];
         GateDesc d{o, 0, in0 ? in0 + i * stride : nullptr, in1 ? in1 + i * stride : nullptr,
                    in2 ? in2 + i * stride : nullptr, out + i * stride};
-        boot.clear();
-        freeg.clear();
-        (op_free(o) ? freeg : boot).push_back(d);
-        rc = run_level(e, W, boot, freeg, j - i, st);
-        if (rc) return rc;
+        if (op_free(o) || e->no_pool) {
+            rc = flush_one(d, j - i);
+            if (rc) return rc;
+        } else pool.push_back({d, j - i});
         i = j;
     }
+    if (pool.size() == 1) rc = flush_one(pool[0].d, pool[0].S);
+    else if (!pool.empty()) rc = run_pool(e, W, pool, st);
+    if (rc) return rc;
     if (gather) {
         dim3 grid((unsigned)count, (unsigned)((stride + 255) / 256));
         hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, st, out, d_out, d_perm, (int)stride, 1);

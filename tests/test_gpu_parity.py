@@ -431,9 +431,11 @@ def test_mixed_ops_arbitrary_order_large(eoc, rig_small):
 @pytest.mark.parametrize("no_fold", [False, True], ids=["folded", "unfolded"])
 def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
     """A mixed batch over ALL fifteen opcodes in arbitrary order: the ten two-input opcodes differ only in their linear
-    stage and run as ONE level (one descriptor, the row's opcode read per job: OP_MULTI) instead of one partly filled
-    launch per opcode; MUX is a level of its own; NOT / COPY / CONSTANT take no bootstrap.  Row for row against the
-    oracle, with the separate k_prepare / k_ks_init launches too (EOC_TFHE_NO_FOLD), and by the engine's level counter."""
+    stage and form ONE group (one descriptor, the row's opcode read per job: OP_MULTI) instead of one partly filled
+    launch per opcode; the MUX run is a second group; both share ONE blind rotation over the concatenated jobs (round 6:
+    one pool per call -- one partly filled last launch instead of two); NOT / COPY / CONSTANT take no bootstrap.  Row for
+    row against the oracle, with the separate k_prepare / k_ks_init launches too (EOC_TFHE_NO_FOLD), by the engine's
+    level counter and by its blind-rotate spans (HIP-event pairs, one per launch_blind_rotate call)."""
     if no_fold:
         monkeypatch.setenv("EOC_TFHE_NO_FOLD", "1")
     r = Rig(eoc, 0, 7, n_override=31)
@@ -444,16 +446,38 @@ def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
     _, a = _rand_cts(r, cnt, 145)
     _, b = _rand_cts(r, cnt, 146)
     _, c = _rand_cts(r, cnt, 147)
+    want = r.orc.gate_batch(0, a, b, c, ops=ops)
+    r.gate(0, a, b, c, ops=ops)                                        # workspace growth outside the counted call
+    r.eng.set_profiling(True)
+    r.eng.kernel_times(reset=True)
     before = r.eng.stats()
     got = r.gate(0, a, b, c, ops=ops)
     after = r.eng.stats()
-    assert np.array_equal(got, r.orc.gate_batch(0, a, b, c, ops=ops))
-    assert after["batches"] - before["batches"] == 2                  # the two-input block + the MUX run
+    kt = r.eng.kernel_times(reset=True)
+    r.eng.set_profiling(False)
+    assert np.array_equal(got, want)
+    assert after["batches"] - before["batches"] == 1                  # the two-input block and the MUX run: one pool
+    assert kt["blind_rotate"]["launches"] == 1, kt                    # ONE blind-rotate span for the whole mixed call
+    assert kt["keyswitch"]["launches"] == 2, kt                       # a key switch per group (j rows, m rows)
     n_mux = int((ops == eoc.OPS["MUX"]).sum())
     assert after["bootstraps"] - before["bootstraps"] == int((ops < 10).sum()) + 2 * n_mux
-    # a batch with a single two-input opcode among free gates keeps its plain descriptor
+    # few runs (no gather): every bootstrapped run is a group of the same pool -- NAND run, MUX run, XOR run, free run
+    ops3 = np.concatenate([np.full(200, 0), np.full(150, 10), np.full(250, 4), np.full(100, 11)]).astype(np.uint8)
+    r.eng.set_profiling(True)
+    r.eng.kernel_times(reset=True)
+    got3 = r.gate(0, a, b, c, ops=ops3)
+    kt3 = r.eng.kernel_times(reset=True)
+    r.eng.set_profiling(False)
+    assert np.array_equal(got3, r.orc.gate_batch(0, a, b, c, ops=ops3))
+    assert kt3["blind_rotate"]["launches"] == 1 and kt3["keyswitch"]["launches"] == 3, kt3
+    # a batch with a single two-input opcode among free gates keeps its plain descriptor (and the folded single-level path)
     ops2 = np.where(ops < 10, 4, np.where(ops == 10, 11, ops)).astype(np.uint8)
     assert np.array_equal(r.gate(0, a, b, c, ops=ops2), r.orc.gate_batch(0, a, b, c, ops=ops2))
+    # in place (out = in0) through the pool: rows are independent, every group reads its rows before any group writes
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c)
+    r.eng.gate_batch_device(0, da.data_ptr(), db.data_ptr(), dc.data_ptr(), da.data_ptr(), cnt, ops=ops3)
+    sync()
+    assert np.array_equal(da.cpu().numpy(), r.orc.gate_batch(0, a, b, c, ops=ops3))
     r.eng.close()
 
 
@@ -481,11 +505,16 @@ def test_deep_chain_bit_exact_set_a(eoc, rig_a):
 @pytest.mark.parametrize("env", [{"EOC_TFHE_BR_PARTS": "3"}, {"EOC_TFHE_BR_PARTS": "1", "EOC_TFHE_BR_SLICE": "5"},
                                  {"EOC_TFHE_NO_FOLD": "1"}, {"EOC_TFHE_PRIO_DUTY": "-1", "EOC_TFHE_BR_SLICE": "-1"},
                                  {"EOC_TFHE_BR_WIDE": "1"}, {"EOC_TFHE_BR_WIDE": "1", "EOC_TFHE_BR_PARTS": "3", "EOC_TFHE_NO_FOLD": "1"},
-                                 {"EOC_TFHE_BR_WIDE": "1", "EOC_TFHE_BR_SLICE": "5"}, {"EOC_TFHE_BR_WIDE": "0"}])
+                                 {"EOC_TFHE_BR_WIDE": "1", "EOC_TFHE_BR_SLICE": "5"}, {"EOC_TFHE_BR_WIDE": "0"},
+                                 {"EOC_TFHE_SCALAR_ABAR": "1"}, {"EOC_TFHE_SCALAR_ABAR": "1", "EOC_TFHE_BR_WIDE": "1"},
+                                 {"EOC_TFHE_SCALAR_ABAR": "1", "EOC_TFHE_NO_FOLD": "1", "EOC_TFHE_BR_PARTS": "2"},
+                                 {"EOC_TFHE_NO_POOL": "1"}, {"EOC_TFHE_NO_POOL": "1", "EOC_TFHE_NO_FOLD": "1"}])
 def test_launch_shapes_do_not_change_results(eoc, monkeypatch, env):
     """the launch-shape knobs of the engine -- a blind rotation cut into consecutive launches (accumulators parked in
     between), job slices, the separate k_ks_init launch, wave priorities off, the one-wave-per-ciphertext kernel forced
-    on narrow launches (gadget length 2; odd job counts leave an idle wave) or off -- give the oracle's bits, all of them"""
+    on narrow launches (gadget length 2; odd job counts leave an idle wave) or off, the rotation amounts read back by
+    scalar loads instead of through LDS (round 6: the shipped form stays inside the memory model), the opcode runs of a
+    mixed batch as levels of their own instead of one pooled blind rotation -- give the oracle's bits, all of them"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for pset in (0, 1):
