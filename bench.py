@@ -371,15 +371,28 @@ def main():
         """(step, bootstraps per step, description, check) of a secondary workload on this rank's shard"""
         from eoc_tfhe_amd import circuits
         wrng = np.random.default_rng(7000 + rank)
-        if name in ("adder8", "streq32"):
-            if name == "adder8":
+        if name in ("adder8", "adder8_optimized", "adder8_prefix", "streq32"):
+            if name.startswith("adder8"):
                 S = instances or 4096 // max(1, world) or 1
                 gates, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8, carry_in_zero=True)
                 A, B = wrng.integers(0, 256, S), wrng.integers(0, 256, S)
-                bits_in = {aw[0]: ((A[:, None] >> np.arange(8)) & 1), bw[0]: ((B[:, None] >> np.arange(8)) & 1)}
                 desc = (f"8-bit ripple-carry add, {S} input pairs per GPU (BASELINE configs[2]); "
                         f"{eoc.circuit_bootstraps(gates)} bootstraps per pair = BASELINE.md's uniform 5 gates per bit "
                         f"(full adder at bit 0 with a constant-0 carry-in), {eoc.circuit_bootstraps(gates) * S} in all")
+                if name == "adder8_optimized":
+                    # the SAME literal netlist through eoc_netlist_optimize (carry rewrite OR(AND(a,b),AND(XOR(a,b),c)) ->
+                    # MUX(XOR(a,b),c,a) + constant folding): same sums, fewer blind rotations, half the levels
+                    gates = eoc.netlist_optimize(gates, sw)
+                    desc = (f"BASELINE configs[2]'s literal adder netlist rewritten by eoc_netlist_optimize, {S} pairs per GPU: "
+                            f"{eoc.circuit_bootstraps(gates)} bootstraps per pair on {eoc.netlist_levels(gates)[2]} levels "
+                            f"(as written: 40 on 17); the work counted is the work DONE ({eoc.circuit_bootstraps(gates) * S} "
+                            f"bootstraps) -- compare pairs_per_s with adder8's")
+                elif name == "adder8_prefix":
+                    gates, n_wires, aw, bw, sw = circuits.prefix_adder(8)
+                    desc = (f"8-bit parallel-prefix (Sklansky, MUX cells) adder, {S} pairs: {eoc.circuit_bootstraps(gates)} "
+                            f"bootstraps per pair on {eoc.netlist_levels(gates)[2]} levels -- the form picked below a quarter of "
+                            f"the resident set")
+                bits_in = {aw[0]: ((A[:, None] >> np.arange(8)) & 1), bw[0]: ((B[:, None] >> np.arange(8)) & 1)}
             else:
                 S = instances or 1024 // max(1, world) or 1
                 gates, n_wires, xw, yw, outw = circuits.string_equal(32)
@@ -398,7 +411,7 @@ def main():
             def wstep():
                 eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S, stream=stream)
 
-            if name == "adder8":
+            if name.startswith("adder8"):
                 def check():
                     sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
                     tot = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
@@ -542,9 +555,11 @@ def main():
     # tensor all-reduces, the configs[3] / [4] block legs) on one rank and skips the single-GPU secondary legs
     single_nand = world == 1 and headline_nand and dist is None
     sec_runs = []
+    latency_runs = []
     if single_nand and not args.no_secondary:
-        for wname, inst in (("adder8", 0), ("streq32", 256), ("mixed", 32768)):
+        for wname, inst in (("adder8", 0), ("adder8_optimized", 0), ("streq32", 256), ("mixed", 32768)):
             sec_runs.append((wname,) + make_workload(wname, inst))
+        latency_runs = [(form,) + make_workload(form, 8) for form in ("adder8", "adder8_optimized", "adder8_prefix")]
         if args.pset == "A":
             sec_runs.append(("nand16384_wide",) + make_wide_leg())
     multi_legs = []
@@ -585,6 +600,11 @@ def main():
         sec[wname] = {"bootstraps_per_s": round(wboots / dt, 1), "bootstraps": wboots, "workload": wdesc,
                       "blind_rotate_launches": st_w2["br_launches"] - st_w["br_launches"],
                       "of_which_wide": st_w2["br_wide_launches"] - st_w["br_wide_launches"]}
+        if wname.startswith("adder8"):
+            sec[wname]["pairs_per_s"] = round(4096 // max(1, world) / dt, 1)
+            sec[wname]["ms"] = round(dt * 1e3, 3)
+        if wname == "mixed":
+            sec[wname]["blind_rotate_spans"] = wkt["blind_rotate"]["launches"]   # ONE pooled blind rotation per call (round 6)
         if wname == "nand16384_wide" and st_w2["br_wide_launches"] > st_w["br_wide_launches"]:
             nl = st_w2["br_launches"] - st_w["br_launches"]
             launch_ms = wkt["blind_rotate"]["ms"] / max(1, nl)
@@ -594,6 +614,20 @@ def main():
             sec[wname]["roofline"] = roofline_block(p, "A", wboots, wboots / max(1, nl), launch_ms, True,
                                                     sclk_mhz=wclk.summary()[0], shape="wide")
 
+    # latency of ONE small batch (8 instances: every level is far below the resident set, so a level costs the same
+    # ~1.8 ms whatever its width and DEPTH is the whole cost): the literal ripple form, the same netlist rewritten, and the
+    # log-depth form the facades pick for this instance count -- median of 7 calls each, sums decrypt-checked below
+    lat = {}
+    for lname, lstep, lboots, ldesc, lcheck in latency_runs:
+        lstep()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            lstep()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        lat[lname] = float(np.median(ts)) * 1e3
     # pre-flight (set-up, untimed, not one of the W warm-up steps; reported as `preflight_steps`): the key images just
     # built/received are exercised so that a bad broadcast or key load fails here, before anything is measured -- and
     # for long enough (16 batches, 50 ms) that a rank which had nothing to run before (N > 1: no secondary passes)
@@ -832,6 +866,17 @@ def main():
         if sec:
             for wname, _, _, _, wcheck in sec_runs:
                 sec[wname]["decrypt_ok"] = wcheck()
+        if sec and "adder8_optimized" in sec and "adder8" in sec:
+            sec["adder8_optimized"]["pairs_per_s_over_adder8"] = round(sec["adder8_optimized"]["pairs_per_s"] / sec["adder8"]["pairs_per_s"], 4)
+        if lat:
+            sec["latency_8_instances_ms"] = {
+                "ripple_as_written": round(lat["adder8"], 3), "ripple_rewritten": round(lat["adder8_optimized"], 3),
+                "prefix_log_depth": round(lat["adder8_prefix"], 3),
+                "prefix_over_ripple": round(lat["adder8_prefix"] / lat["adder8"], 4),
+                "decrypt_ok": all(chk() for _, _, _, _, chk in latency_runs),
+                "note": "one 8-bit addition over 8 input pairs, wires resident, median of 7 calls: 17 / 8 / 5 dependent levels "
+                        "(40 / 30 / 48 bootstraps per pair); Tfhe.addBits / addBitsBatch pick the form by instance count "
+                        "(eoc_netlist_cost)"}
         if setb_res:
             tb, ktb, nlaunch_b = setb_res
             pb = setb["p"]

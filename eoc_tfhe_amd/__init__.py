@@ -864,3 +864,50 @@ class Tfhe:
     @staticmethod
     def mux(a, b, c, pk=""):
         return _take_str(lib().gateMUX(a.encode(), b.encode(), c.encode(), pk.encode()))
+
+    # ---- word-level circuits, one backend call each; the FORM is picked by the instance count (circuits.pick_form: ----
+    # ---- fewest levels for a handful of instances, fewest bootstraps for thousands), like Tfhe.addBits in tfhe.js / .lua ----
+    @staticmethod
+    def _samples(cts):
+        import base64
+        n1 = global_params().n + 1
+        return np.stack([np.frombuffer(base64.b64decode(c), "<i4", count=n1) for c in cts])[:, None, :]
+
+    @staticmethod
+    def _strings(planes):
+        import base64
+        return [base64.b64encode(np.ascontiguousarray(p[0], "<i4").tobytes() + bytes(8)).decode() for p in planes]
+
+    @staticmethod
+    def _run(built, a_planes, b_planes, instances, outputs):
+        gates, n_wires, a, b = built[0], built[1], built[2], built[3]
+        wires = np.zeros((n_wires, instances, a_planes.shape[-1]), np.int32)
+        wires[a[0]: a[0] + len(a)] = a_planes
+        wires[b[0]: b[0] + len(b)] = b_planes
+        return global_circuit_run(gates, wires, instances)[list(outputs)]
+
+    @staticmethod
+    def addBitsBatch(A, B):
+        """A, B: samples [nbits][instances][n+1] (LSB first) -> [nbits + 1][instances][n+1]"""
+        from . import circuits
+        A, B = np.ascontiguousarray(A, np.int32), np.ascontiguousarray(B, np.int32)
+        built = circuits.adder(A.shape[0], A.shape[1])
+        return Tfhe._run(built, A, B, A.shape[1], built[4])
+
+    @staticmethod
+    def lessThanBitsBatch(A, B):
+        """A, B: samples [nbits][instances][n+1] -> [instances][n+1]: 1 iff A < B (unsigned)"""
+        from . import circuits
+        A, B = np.ascontiguousarray(A, np.int32), np.ascontiguousarray(B, np.int32)
+        built = circuits.less_than_for(A.shape[0], A.shape[1])
+        return Tfhe._run(built, A, B, A.shape[1], [built[4]])[0]
+
+    @staticmethod
+    def addBits(A, B):
+        """arrays of base64 bit ciphertexts (LSB first) -> len(A) + 1 ciphertext strings (the log-depth adder)"""
+        return Tfhe._strings(Tfhe.addBitsBatch(Tfhe._samples(A), Tfhe._samples(B)))
+
+    @staticmethod
+    def lessThanBits(A, B):
+        return Tfhe._strings(Tfhe.lessThanBitsBatch(Tfhe._samples(A), Tfhe._samples(B))[None])[0]
+

@@ -190,6 +190,22 @@ static int l_circuitBootstraps(lua_State *L) {        /* (gates) -> blind rotati
   lua_pushinteger(L, (lua_Integer)eoc_circuit_bootstraps((const eoc_gate *)g, gbytes / sizeof(eoc_gate)));
   return 1;
 }
+static int l_netlistCost(lua_State *L) {              /* (gates, instances) -> estimated run time in 0.1 ms units (eoc_netlist_cost), or -1 */
+  size_t gbytes;
+  const char *g = luaL_checklstring(L, 1, &gbytes);
+  lua_Integer inst = luaL_checkinteger(L, 2);
+  if (gbytes % sizeof(eoc_gate) || inst < 0) { lua_pushinteger(L, -1); return 1; }
+  lua_pushinteger(L, (lua_Integer)eoc_netlist_cost((const eoc_gate *)g, gbytes / sizeof(eoc_gate), (size_t)inst, 0));
+  return 1;
+}
+static int l_netlistDepth(lua_State *L) {             /* (gates) -> dependent levels that hold a blind rotation, or -1 */
+  size_t gbytes;
+  const char *g = luaL_checklstring(L, 1, &gbytes);
+  int64_t depth = -1;
+  if (gbytes % sizeof(eoc_gate) || eoc_netlist_levels((const eoc_gate *)g, gbytes / sizeof(eoc_gate), NULL, &depth) < 0) depth = -1;
+  lua_pushinteger(L, (lua_Integer)depth);
+  return 1;
+}
 static int l_deviceCount(lua_State *L) { lua_pushinteger(L, eoc_device_count()); return 1; }
 static int l_engineCount(lua_State *L) { lua_pushinteger(L, eoc_gpu_engine_count()); return 1; }
 /* NOT mirrored from the Node addon (tests/test_binding_surfaces.py lists them): hostAlloc / gateBatchSubmit /
@@ -209,7 +225,8 @@ static const luaL_Reg eoc_gate_functions[] = {
   {"keyMode", l_keyMode},
   {"sampleInts", l_sampleInts}, {"encryptBits", l_encryptBits}, {"decryptBits", l_decryptBits},
   {"gateBatch", l_gateBatch}, {"circuitRun", l_circuitRun}, {"netlistOptimize", l_netlistOptimize},
-  {"circuitBootstraps", l_circuitBootstraps}, {"deviceCount", l_deviceCount}, {"engineCount", l_engineCount},
+  {"circuitBootstraps", l_circuitBootstraps}, {"netlistCost", l_netlistCost}, {"netlistDepth", l_netlistDepth},
+  {"deviceCount", l_deviceCount}, {"engineCount", l_engineCount},
   {NULL, NULL}
 };
 /* the same functions as a module of their own, like luaopen_tfhe (:128-148) */

@@ -101,6 +101,110 @@ function Tfhe.subtractorNetlist(nbits)
   end
   return nl, a, b, diff, br
 end
+-- ---- forms picked by instance count (fewest bootstraps for wide batches, fewest levels for small ones) ----
+-- carry as ONE gate per bit: c_{i+1} = MUX(a_i ^ b_i, c_i, a_i); 2 + 4 (nbits - 1) bootstraps on nbits levels (30 / 8 for 8 bits)
+function Tfhe.muxAdderNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, sum = nl.wire(nbits), nl.wire(nbits), {}
+  sum[1] = nl.gate(OP.XOR, a, b)
+  local c = nl.gate(OP.AND, a, b)
+  for i = 1, nbits - 1 do
+    local p = nl.gate(OP.XOR, a + i, b + i)
+    sum[#sum + 1] = nl.gate(OP.XOR, p, c)
+    c = nl.gate(OP.MUX, p, c, a + i)
+  end
+  sum[#sum + 1] = c
+  return nl, a, b, sum
+end
+-- logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
+-- 48 bootstraps on 5 levels for 8 bits
+function Tfhe.prefixAdderNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, sum = nl.wire(nbits), nl.wire(nbits), {}
+  if nbits == 1 then
+    sum[1] = nl.gate(OP.XOR, a, b); sum[2] = nl.gate(OP.AND, a, b)
+    return nl, a, b, sum
+  end
+  local P, G, pbit, single = {}, {}, {}, {}
+  for i = 0, nbits - 1 do P[i] = nl.gate(OP.XOR, a + i, b + i); pbit[i] = P[i]; single[i] = true end
+  for i = 0, nbits - 1 do
+    if i == 0 or (i % 2 == 0 and i + 1 < nbits) then G[i] = nl.gate(OP.AND, a + i, b + i) end
+  end
+  local k = 0
+  while (1 << k) < nbits do
+    local newG, newP, newS = {}, {}, {}
+    for i = 0, nbits - 1 do newG[i] = G[i]; newP[i] = P[i]; newS[i] = single[i] end
+    for i = 0, nbits - 1 do
+      if (i >> k) & 1 == 1 then
+        local j = ((i >> k) << k) - 1
+        local ghi = G[i]
+        if single[i] then ghi = a + i end
+        newG[i] = nl.gate(OP.MUX, P[i], G[j], ghi)
+        if i < (1 << (k + 1)) then newP[i] = nil else newP[i] = nl.gate(OP.AND, P[i], P[j]) end
+        newS[i] = false
+      end
+    end
+    G, P, single = newG, newP, newS
+    k = k + 1
+  end
+  sum[1] = pbit[0]
+  for i = 1, nbits - 1 do sum[#sum + 1] = nl.gate(OP.XOR, pbit[i], G[i - 1]) end
+  sum[#sum + 1] = G[nbits - 1]
+  return nl, a, b, sum
+end
+-- unsigned a < b alone, ripple form: lt_0 = ANDNY(a_0, b_0); lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i); 1 + 3 (nbits - 1) bootstraps
+function Tfhe.lessThanNetlist(nbits)
+  local nl = newNetlist()
+  local a, b = nl.wire(nbits), nl.wire(nbits)
+  local lt = nl.gate(OP.ANDNY, a, b)
+  for i = 1, nbits - 1 do lt = nl.gate(OP.MUX, nl.gate(OP.XNOR, a + i, b + i), lt, b + i) end
+  return nl, a, b, lt
+end
+-- unsigned a < b in logarithmic depth: tree over (LT, EQ) of bit ranges, LT = MUX(EQ_hi, LT_lo, LT_hi); 29 bootstraps on 4
+-- levels for 8 bits (lessThanNetlist: 22 on 8)
+function Tfhe.lessThanTreeNetlist(nbits)
+  local nl = newNetlist()
+  local a, b = nl.wire(nbits), nl.wire(nbits)
+  local function build(lo, hi, needLt, needEq)
+    if hi - lo == 1 then
+      local eq, lt = nil, nil
+      if needEq then eq = nl.gate(OP.XNOR, a + lo, b + lo) end
+      if needLt then lt = nl.gate(OP.ANDNY, a + lo, b + lo) end
+      return lt, eq
+    end
+    local mid = lo + (hi - lo + 1) // 2
+    local upSingle = (hi - mid == 1)
+    local ltLo, eqLo = build(lo, mid, true, needEq)
+    local ltHi, eqHi = build(mid, hi, not upSingle, true)
+    local lt, eq = nil, nil
+    if needLt then
+      local hiv = ltHi
+      if upSingle then hiv = b + mid end
+      lt = nl.gate(OP.MUX, eqHi, ltLo, hiv)
+    end
+    if needEq then eq = nl.gate(OP.AND, eqHi, eqLo) end
+    return lt, eq
+  end
+  local lt = build(0, nbits, true, false)
+  return nl, a, b, lt
+end
+-- the form of lowest estimated cost for this many instances (backend.netlistCost: below a quarter of the resident set a
+-- level costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
+local function cheapest(builders, nbits, instances)
+  local best, bestCost
+  for i = 1, #builders do
+    local r = { builders[i](nbits) }
+    local cost = Tfhe.backend.netlistCost(r[1].packed(), instances)
+    if not best or (cost >= 0 and cost < bestCost) then best, bestCost = r, cost end
+  end
+  return table.unpack(best)
+end
+function Tfhe.adderNetlistFor(nbits, instances)
+  return cheapest({ Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist }, nbits, instances)
+end
+function Tfhe.lessThanNetlistFor(nbits, instances)
+  return cheapest({ Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
+end
 -- a * b -> 2 nbits bits, LSB first: nbits^2 AND partial products, nbits - 1 shifted ripple-carry rows
 function Tfhe.multiplierNetlist(nbits)
   local nl = newNetlist()
@@ -201,13 +305,13 @@ local function pick(wires, ws)                            -- wires of ONE instan
   return out
 end
 -- string-API circuits: arrays of base64 bit ciphertexts (LSB first) in, arrays out -- ONE backend call per circuit
-function Tfhe.addBits(A, B)                               -- -> #A + 1 ciphertexts
-  local nl, a, b, sum = Tfhe.adderNetlist(#A)
+function Tfhe.addBits(A, B)                               -- -> #A + 1 ciphertexts (one instance: the log-depth form)
+  local nl, a, b, sum = Tfhe.adderNetlistFor(#A, 1)
   local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1)
   return wires and pick(wires, sum)
 end
-function Tfhe.lessThanBits(A, B)                          -- -> one ciphertext: 1 iff A < B (unsigned)
-  local nl, a, b, lt = Tfhe.minMaxNetlist(#A)
+function Tfhe.lessThanBits(A, B)                          -- -> one ciphertext: 1 iff A < B (unsigned; the log-depth form)
+  local nl, a, b, lt = Tfhe.lessThanNetlistFor(#A, 1)
   local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1, { lt })
   return wires and sampleToStr(planes(wires, lt, 1, 1))
 end
@@ -218,8 +322,8 @@ function Tfhe.minMaxBits(A, B)                            -- -> min, max (arrays
   return pick(wires, mn), pick(wires, mx)
 end
 -- raw-buffer circuits over many instances: operands are samples [nbits][instances][n+1]
-function Tfhe.addBitsBatch(A, B, nbits, instances)
-  local nl, a, b, sum = Tfhe.adderNetlist(nbits)
+function Tfhe.addBitsBatch(A, B, nbits, instances)      -- the form is picked by the instance count (adderNetlistFor)
+  local nl, a, b, sum = Tfhe.adderNetlistFor(nbits, instances)
   local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
   if not wires then return nil end
   local out = {}

@@ -419,6 +419,26 @@ static napi_value n_circuitBootstraps(napi_env env, napi_callback_info info)
     if (!get_i32_array(env, argv[0], &g, &glen) || glen % 5) return ret_int(env, -1);
     return ret_int(env, (int)eoc_circuit_bootstraps((const eoc_gate *)g, glen / 5));
 }
+static napi_value n_netlistCost(napi_env env, napi_callback_info info)
+{ /* (Int32Array gates, instances) -> estimated run time in 0.1 ms units (eoc_netlist_cost), or -1 */
+    ARGS(2);
+    int32_t *g, inst;
+    size_t glen;
+    if (!get_i32_array(env, argv[0], &g, &glen) || glen % 5 || napi_get_value_int32(env, argv[1], &inst) != napi_ok || inst < 0)
+        return ret_int(env, -1);
+    int64_t c = eoc_netlist_cost((const eoc_gate *)g, glen / 5, (size_t)inst, 0);
+    return ret_int(env, c > 0x7fffffff ? 0x7fffffff : (int)c);
+}
+static napi_value n_netlistDepth(napi_env env, napi_callback_info info)
+{ /* (Int32Array gates) -> dependent levels that hold a blind rotation, or -1 */
+    ARGS(1);
+    int32_t *g;
+    size_t glen;
+    int64_t depth = -1;
+    if (!get_i32_array(env, argv[0], &g, &glen) || glen % 5 || eoc_netlist_levels((const eoc_gate *)g, glen / 5, NULL, &depth) < 0)
+        return ret_int(env, -1);
+    return ret_int(env, (int)depth);
+}
 static napi_value n_engineCount(napi_env env, napi_callback_info info) { (void)info; return ret_int(env, eoc_gpu_engine_count()); }
 static napi_value n_setDevices(napi_env env, napi_callback_info info)
 { /* (Int32Array devices) -> 0 or a negative code: the devices the next generateGateKey / importCloudKey brings up, one
@@ -449,6 +469,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"sampleInts", n_sampleInts}, {"encryptBits", n_encryptBits}, {"decryptBits", n_decryptBits},
         {"gateBatch", n_gateBatch}, {"deviceCount", n_deviceCount}, {"circuitRun", n_circuitRun},
         {"netlistOptimize", n_netlistOptimize}, {"circuitBootstraps", n_circuitBootstraps}, {"engineCount", n_engineCount},
+        {"netlistCost", n_netlistCost}, {"netlistDepth", n_netlistDepth},
         {"setDevices", n_setDevices}, {"hostAlloc", n_hostAlloc}, {"gateBatchSubmit", n_gateBatchSubmit},
         {"gateBatchWait", n_gateBatchWait},
     };

@@ -132,6 +132,84 @@ Tfhe.multiplierNetlist = nbits => {
   prod.push(top === null ? nl.gate(OP.CONST0, -1) : top);
   return { nl, a, b, prod };
 };
+// ---- forms picked by instance count (fewest bootstraps for wide batches, fewest levels for small ones) ----
+// carry as ONE gate per bit: c_{i+1} = MUX(a_i ^ b_i, c_i, a_i); 2 + 4 (nbits - 1) bootstraps on nbits levels (30 / 8 for 8 bits)
+Tfhe.muxAdderNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), sum = [];
+  sum.push(nl.gate(OP.XOR, a, b));
+  let c = nl.gate(OP.AND, a, b);
+  for (let i = 1; i < nbits; i++) {
+    const p = nl.gate(OP.XOR, a + i, b + i);
+    sum.push(nl.gate(OP.XOR, p, c));
+    c = nl.gate(OP.MUX, p, c, a + i);
+  }
+  sum.push(c);
+  return { nl, a, b, sum };
+};
+// logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
+// 48 bootstraps on 5 levels for 8 bits
+Tfhe.prefixAdderNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  if (nbits === 1) return { nl, a, b, sum: [nl.gate(OP.XOR, a, b), nl.gate(OP.AND, a, b)] };
+  let P = [...Array(nbits).keys()].map(i => nl.gate(OP.XOR, a + i, b + i));
+  const pbit = P.slice();
+  let G = [...Array(nbits).keys()].map(i => (i === 0 || (i % 2 === 0 && i + 1 < nbits)) ? nl.gate(OP.AND, a + i, b + i) : null);
+  let single = Array(nbits).fill(true);
+  for (let k = 0; (1 << k) < nbits; k++) {
+    const newG = G.slice(), newP = P.slice(), newS = single.slice();
+    for (let i = 0; i < nbits; i++) {
+      if (!((i >> k) & 1)) continue;
+      const j = ((i >> k) << k) - 1;
+      newG[i] = nl.gate(OP.MUX, P[i], G[j], single[i] ? a + i : G[i]);
+      newP[i] = i < (1 << (k + 1)) ? null : nl.gate(OP.AND, P[i], P[j]);
+      newS[i] = false;
+    }
+    G = newG; P = newP; single = newS;
+  }
+  const sum = [pbit[0]];
+  for (let i = 1; i < nbits; i++) sum.push(nl.gate(OP.XOR, pbit[i], G[i - 1]));
+  sum.push(G[nbits - 1]);
+  return { nl, a, b, sum };
+};
+// unsigned a < b alone, ripple form: lt_0 = ANDNY(a_0, b_0); lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i); 1 + 3 (nbits - 1) bootstraps
+Tfhe.lessThanNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  let lt = nl.gate(OP.ANDNY, a, b);
+  for (let i = 1; i < nbits; i++) lt = nl.gate(OP.MUX, nl.gate(OP.XNOR, a + i, b + i), lt, b + i);
+  return { nl, a, b, lt };
+};
+// unsigned a < b in logarithmic depth: tree over (LT, EQ) of bit ranges, LT = MUX(EQ_hi, LT_lo, LT_hi); 29 bootstraps on 4
+// levels for 8 bits (lessThanNetlist: 22 on 8)
+Tfhe.lessThanTreeNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  const build = (lo, hi, needLt, needEq) => {
+    if (hi - lo === 1) {
+      const eq = needEq ? nl.gate(OP.XNOR, a + lo, b + lo) : null;
+      const lt = needLt ? nl.gate(OP.ANDNY, a + lo, b + lo) : null;
+      return [lt, eq];
+    }
+    const mid = lo + ((hi - lo + 1) >> 1), upSingle = hi - mid === 1;
+    const [ltLo, eqLo] = build(lo, mid, true, needEq);
+    const [ltHi, eqHi] = build(mid, hi, !upSingle, true);
+    const lt = needLt ? nl.gate(OP.MUX, eqHi, ltLo, upSingle ? b + mid : ltHi) : null;
+    const eq = needEq ? nl.gate(OP.AND, eqHi, eqLo) : null;
+    return [lt, eq];
+  };
+  const lt = build(0, nbits, true, false)[0];
+  return { nl, a, b, lt };
+};
+// the form of lowest estimated cost for this many instances (B.netlistCost: below a quarter of the resident set a level
+// costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
+const cheapest = (builders, nbits, instances) => {
+  let best = null, bestCost = 0;
+  for (const build of builders) {
+    const r = build(nbits), cost = B.netlistCost(r.nl.packed(), instances);
+    if (best === null || (cost >= 0 && cost < bestCost)) { best = r; bestCost = cost; }
+  }
+  return best;
+};
+Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
+Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
 // run a netlist over `instances` instances: inputs = {firstWire: Buffer [k][instances][n+1]}; returns the wire Buffer
 Tfhe.runNetlist = (nl, inputs, instances, outputs) => {
   const w = B.sampleInts() * 4, plane = instances * w;
@@ -152,13 +230,13 @@ const stack = arr => Buffer.concat(arr.map(strToSample));
 const unstack = (buf, k) => { const w = B.sampleInts() * 4; return [...Array(k).keys()].map(i => sampleToStr(buf.slice(i * w, (i + 1) * w))); };
 
 // string-API circuits: arrays of base64 bit ciphertexts in, arrays out -- ONE backend call per circuit
-Tfhe.addBits = (A, Bs) => {
-  const { nl, a, b, sum } = Tfhe.adderNetlist(A.length);
+Tfhe.addBits = (A, Bs) => {   // one instance: the log-depth form
+  const { nl, a, b, sum } = Tfhe.adderNetlistFor(A.length, 1);
   const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1);
   return wires && sum.map(wi => unstack(planes(wires, wi, 1, 1), 1)[0]);
 };
-Tfhe.lessThanBits = (A, Bs) => {
-  const { nl, a, b, lt } = Tfhe.minMaxNetlist(A.length);
+Tfhe.lessThanBits = (A, Bs) => {   // one instance: the log-depth form
+  const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(A.length, 1);
   const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1, [lt]);
   return wires && unstack(planes(wires, lt, 1, 1), 1)[0];
 };
@@ -169,8 +247,8 @@ Tfhe.minMaxBits = (A, Bs) => {
   return wires && { min: pick(min), max: pick(max) };
 };
 // raw-buffer circuits over many instances: operands are Buffers [nbits][instances][n+1]
-Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {
-  const { nl, a, b, sum } = Tfhe.adderNetlist(nbits);
+Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // the form is picked by the instance count
+  const { nl, a, b, sum } = Tfhe.adderNetlistFor(nbits, instances);
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
   return wires && Buffer.concat(sum.map(wi => planes(wires, wi, 1, instances)));   // [nbits + 1][instances][n+1]
 };

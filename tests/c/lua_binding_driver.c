@@ -49,7 +49,7 @@ int main(int argc, char **argv)
     /* ---- the module table: luaopen_tfhe_gates, like luaopen_tfhe (ao-tfhe/eoc-tfhe-bindings.c:128-148) ---- */
     CHECK(luaopen_tfhe_gates(L) == 1 && ld_type(L, 1) == LUA_TTABLE);
     n_fn = ld_table_size(L, 1);
-    CHECK(n_fn == 30);
+    CHECK(n_fn == 32);
     for (int k = 0; k < n_fn; k++) {
         fn_name[k] = ld_table_name(L, 1, k);
         fn[k] = ld_table_get(L, 1, fn_name[k]);
@@ -194,6 +194,22 @@ int main(int argc, char **argv)
     CHECK(call("circuitBootstraps", 1) == 1 && ld_to_int(L, 1) == 3);
     ld_push_lstr(L, nl, sizeof nl - 1);
     CHECK(call("circuitBootstraps", 1) == 1 && ld_to_int(L, 1) == -1);
+    /* netlistCost / netlistDepth (round 6): the levels are the engine's -- NOT is free but its reader waits for its level, so
+     * AND(s, x) | AND(NOT s, y) | OR sit on three dependent levels: 3 x 18 units (0.1 ms) for 3 instances; a level of 1024
+     * jobs is one full launch = 30 */
+    ld_push_lstr(L, nl, sizeof nl);
+    CHECK(call("netlistDepth", 1) == 1 && ld_to_int(L, 1) == 3);
+    ld_push_lstr(L, nl, sizeof nl - 2);
+    CHECK(call("netlistDepth", 1) == 1 && ld_to_int(L, 1) == -1);
+    ld_push_lstr(L, nl, sizeof nl);
+    ld_push_int(L, 3);
+    CHECK(call("netlistCost", 2) == 1 && ld_to_int(L, 1) == 54);
+    ld_push_lstr(L, nl, sizeof nl);
+    ld_push_int(L, 1024);
+    CHECK(call("netlistCost", 2) == 1 && ld_to_int(L, 1) == 90);
+    ld_push_lstr(L, nl, sizeof nl);
+    ld_push_int(L, -1);
+    CHECK(call("netlistCost", 2) == 1 && ld_to_int(L, 1) == -1);
     ld_push_lstr(L, nl, sizeof nl);
     ld_push_lstr(L, outs, sizeof outs);
     CHECK(call("netlistOptimize", 2) == 1);

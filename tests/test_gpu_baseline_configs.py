@@ -75,6 +75,80 @@ def test_config3_adder_4096_pairs(eoc, rig):
         assert np.array_equal(got[g.out], want[g.out]), f"wire {g.out} (op {g.op})"
 
 
+def _run_adder(eoc, rig, gates, n_wires, aw, bw, sw, S, seed):
+    """encrypt S random 8-bit pairs, run the netlist on the GPU; returns (A, B, wires tensor, inputs of the first 16)"""
+    p, sk, eng = rig
+    torch = torch_cuda()
+    rng = np.random.default_rng(seed)
+    A, B = rng.integers(0, 256, S), rng.integers(0, 256, S)
+    wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
+    wires[aw[0]: aw[0] + 8] = to_dev(_enc_planes(sk, ((A[:, None] >> np.arange(8)) & 1).astype(np.uint8), 1000))
+    wires[bw[0]: bw[0] + 8] = to_dev(_enc_planes(sk, ((B[:, None] >> np.arange(8)) & 1).astype(np.uint8), 2000))
+    inputs = wires[:, :ORACLE_INSTANCES].cpu().numpy()
+    before = eng.stats()["bootstraps"]
+    eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
+    sync()
+    assert eng.stats()["bootstraps"] - before == eoc.circuit_bootstraps(gates) * S
+    sums = wires[sw[0]: sw[0] + 9].cpu().numpy()
+    total = sum(sk.decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9))
+    assert np.array_equal(total, A + B)
+    return wires, inputs
+
+
+@pytest.mark.parametrize("S", [4096, 8])
+def test_config3_adder_rewritten_and_log_depth_forms(eoc, rig, S):
+    """VERDICT r5 task 1: BASELINE configs[2]'s literal 40-gate netlist through eoc_netlist_optimize (carry rewrite +
+    constant folding: 30 bootstraps on 8 levels), the MUX-carry adder written directly and the parallel-prefix adder
+    (48 bootstraps on 5 levels), over 4096 pairs and over 8: all sums decrypt, and EVERY wire the rewritten netlist writes
+    equals the oracle's evaluation of that rewritten netlist on the first 16 (or all 8) instances, bit for bit"""
+    from eoc_tfhe_amd import circuits
+    lit, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8, carry_in_zero=True)
+    opt = eoc.netlist_optimize(lit, sw)
+    assert [(g.op, g.in0, g.in1, g.in2, g.out) for g in opt] == [(g.op, g.in0, g.in1, g.in2, g.out) for g in circuits.optimize(lit, sw)]
+    assert eoc.circuit_bootstraps(opt) == 30 and eoc.netlist_levels(opt)[2] == 8
+    forms = [("optimized literal", (opt, n_wires, aw, bw, sw)), ("mux carry", circuits.mux_carry_adder(8)),
+             ("prefix", circuits.prefix_adder(8))]
+    assert eoc.netlist_levels(forms[2][1][0])[2] == 5
+    orc = ol.Oracle(0, 1)
+    for name, (gates, nw, a, b, s) in forms:
+        wires, inputs = _run_adder(eoc, rig, gates, nw, a, b, s, S, 3)
+        k = min(S, ORACLE_INSTANCES)
+        want = _oracle_netlist(orc, gates, inputs[:, :k])
+        got = wires[:, :k].cpu().numpy()
+        for g in gates:
+            assert np.array_equal(got[g.out], want[g.out]), f"{name}: wire {g.out} (op {g.op})"
+    # the chooser: 8 instances take the prefix form, 4096 the MUX-carry form (the engine's own resident set)
+    assert circuits.pick_form({k: v for k, v in circuits.ADDER_FORMS.items() if k != "ripple"}, 8, S,
+                              rig[2].resident_jobs() // 2)[0] == ("prefix" if S == 8 else "mux")
+
+
+@pytest.mark.parametrize("S", [1024, 8])
+def test_less_than_tree_and_ripple_bit_exact(eoc, rig, S):
+    """the log-depth comparator (29 bootstraps on 4 levels) and the ripple one (22 on 8): decrypt to a < b, every written
+    wire of the first 16 instances equals the oracle's"""
+    from eoc_tfhe_amd import circuits
+    p, sk, eng = rig
+    torch = torch_cuda()
+    orc = ol.Oracle(0, 1)
+    rng = np.random.default_rng(17)
+    A, B = rng.integers(0, 256, S), rng.integers(0, 256, S)
+    B[::5] = A[::5]                                             # equal operands: a < b is false through every EQ
+    for build in (circuits.less_than_tree, circuits.less_than):
+        gates, n_wires, aw, bw, lt = build(8)
+        wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
+        wires[aw[0]: aw[0] + 8] = to_dev(_enc_planes(sk, ((A[:, None] >> np.arange(8)) & 1).astype(np.uint8), 6000))
+        wires[bw[0]: bw[0] + 8] = to_dev(_enc_planes(sk, ((B[:, None] >> np.arange(8)) & 1).astype(np.uint8), 7000))
+        k = min(S, ORACLE_INSTANCES)
+        inputs = wires[:, :k].cpu().numpy()
+        eng.circuit_run_device(gates, wires.data_ptr(), n_wires, S)
+        sync()
+        assert np.array_equal(sk.decrypt_bits(wires[lt].cpu().numpy()), (A < B).astype(np.uint8)), build.__name__
+        want = _oracle_netlist(orc, gates, inputs)
+        got = wires[:, :k].cpu().numpy()
+        for g in gates:
+            assert np.array_equal(got[g.out], want[g.out]), f"{build.__name__}: wire {g.out} (op {g.op})"
+
+
 def test_config5_string_equality_1024x32(eoc, rig):
     """ASCII-string equality (per-bit XOR + OR tree + NOT) on 1024 pairs of 32-byte strings, half equal."""
     from eoc_tfhe_amd import circuits

@@ -157,6 +157,25 @@ def test_string_api_and_host_batch_api(eoc):
         raw1 = np.frombuffer(raw[: 4 * 501], np.int32)
         out = eoc.gate_batch(eoc.OPS["OR"], np.stack([raw0, raw1]), np.stack([raw0, raw0]))
         assert out.shape == (2, 501)
+        # word-level circuits of the facade (round 6): one instance takes the log-depth forms -- one backend call each
+        for av, bv in ((200, 100), (13, 250), (77, 77)):
+            A = [T.encryptBit((av >> i) & 1) for i in range(8)]
+            B = [T.encryptBit((bv >> i) & 1) for i in range(8)]
+            st0 = eoc.stats()
+            ssum = T.addBits(A, B)
+            st1 = eoc.stats()
+            assert len(ssum) == 9 and sum(T.decryptBit(x) << i for i, x in enumerate(ssum)) == av + bv
+            assert st1["bootstraps"] - st0["bootstraps"] == 48 and st1["batches"] - st0["batches"] == 5   # prefix adder
+            assert T.decryptBit(T.lessThanBits(A, B)) == int(av < bv)
+            assert eoc.stats()["bootstraps"] - st1["bootstraps"] == 29                                  # tree comparator
+        planes = lambda vals: np.stack([eoc.global_encrypt_bits(((vals >> i) & 1).astype(np.uint8)) for i in range(8)])
+        rng = np.random.default_rng(12)
+        Av, Bv = rng.integers(0, 256, 1200), rng.integers(0, 256, 1200)
+        st0 = eoc.stats()
+        sums = T.addBitsBatch(planes(Av), planes(Bv))
+        assert eoc.stats()["bootstraps"] - st0["bootstraps"] == 30 * 1200                               # MUX-carry adder
+        assert np.array_equal(sum(eoc.global_decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9)), Av + Bv)
+        assert np.array_equal(eoc.global_decrypt_bits(T.lessThanBitsBatch(planes(Av), planes(Bv))), (Av < Bv).astype(np.uint8))
     finally:
         T.resetGateKey()
 

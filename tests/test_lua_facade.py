@@ -115,7 +115,14 @@ class PlainBackend:
             out = np.zeros((len(bits), ROW), "<i4")
             out[:, -1] = np.frombuffer(bits, np.uint8)
             return out.tobytes()
+        def netlist_cost(gates, instances):
+            """the binding's l_netlistCost on the Python twin of eoc_netlist_cost (tests/test_circuits_cpu.py compares the two)"""
+            from eoc_tfhe_amd import Gate, circuits
+            g = [Gate(*map(int, row)) for row in np.frombuffer(gates, "<i4").reshape(-1, 5)]
+            self.calls.append(("netlistCost", len(g), instances))
+            return circuits.netlist_cost(g, instances, 1024)
         return ml.table_from({"sampleInts": lambda: ROW, "circuitRun": circuit_run, "encryptBits": encrypt_bits,
+                              "netlistCost": netlist_cost,
                               "gateNAND": lambda a, b, pk=None: b"NAND(" + a + b"," + b + b")",
                               "setDevices": lambda *d: len(d)})
 
@@ -151,6 +158,7 @@ def value_of(buf, instances):
 def test_facade_defines_its_functions_and_passes_through(facade):
     it, tf, be = facade
     for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
+                 "muxAdderNetlist", "prefixAdderNetlist", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
                  "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
                  "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
         assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
@@ -198,6 +206,19 @@ def test_netlist_builders_on_plaintext(facade, nbits):
     bits, _ = evaluate(nl, a, b)
     prod = ml.to_python(prod)
     assert len(prod) == 2 * nbits and np.array_equal(word(bits, prod), A * B)
+    # round 6: the forms picked by instance count -- gate for gate the Python circuit layer's netlists
+    from eoc_tfhe_amd import circuits
+    for lua_name, py in (("muxAdderNetlist", circuits.mux_carry_adder), ("prefixAdderNetlist", circuits.prefix_adder)):
+        nl, a, b, s = call(it, tf, lua_name, nbits)
+        bits, (ngates, boots) = evaluate(nl, a, b)
+        assert np.array_equal(word(bits, ml.to_python(s)), A + B), lua_name
+        pg = py(nbits)[0]
+        assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 1 for g in pg)), lua_name
+    nl, a, b, lt = call(it, tf, "lessThanTreeNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(bits[lt], (A < B).astype(np.int64))
+    pg = circuits.less_than_tree(nbits)[0]
+    assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 1 for g in pg))
 
 
 def test_eight_bit_netlists_match_the_python_circuit_layer(facade):
@@ -221,6 +242,25 @@ def test_eight_bit_netlists_match_the_python_circuit_layer(facade):
         assert boots == eoc.circuit_bootstraps(py[0]), (lua_name, boots)
 
 
+def test_forms_are_picked_by_instance_count(facade):
+    """Tfhe.adderNetlistFor / lessThanNetlistFor ask the backend's level-cost estimate (eoc_netlist_cost): one instance or
+    a handful take the log-depth forms (5 and 4 levels at 8 bits), thousands the forms with the fewest bootstraps"""
+    from eoc_tfhe_amd import Gate, circuits
+    it, tf, be = facade
+
+    def shape(nl):
+        g = [Gate(*map(int, row)) for row in np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)]
+        return sum(2 if x.op == 10 else 0 if x.op >= 11 else 1 for x in g), circuits.bootstrap_depth(g)
+
+    for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (30, 8), (22, 8))):
+        assert shape(call(it, tf, "adderNetlistFor", 8, inst)[0]) == add_want, inst
+        assert shape(call(it, tf, "lessThanNetlistFor", 8, inst)[0]) == lt_want, inst
+    A = np.array([200, 13, 255]); B = np.array([100, 250, 255])
+    out = call(it, tf, "addBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)[0]
+    assert np.array_equal(value_of(out, 3), A + B)
+    assert be.calls[-1][:2] == ("circuitRun", len(circuits.prefix_adder(8)[0]))
+
+
 def test_batch_functions_pack_and_slice_wires(facade):
     it, tf, be = facade
     rng = np.random.default_rng(9)
@@ -229,7 +269,9 @@ def test_batch_functions_pack_and_slice_wires(facade):
     pa, pb = planes_of(A, nbits, S), planes_of(B, nbits, S)
     out = call(it, tf, "addBitsBatch", pa, pb, nbits, S)[0]
     assert len(out) == (nbits + 1) * S * ROW * 4 and np.array_equal(value_of(out, S), A + B)
-    assert be.calls[-1] == ("circuitRun", 5 * nbits - 3, be.calls[-1][2], S)
+    # the form is picked by the instance count: at 4 bits the MUX-carry adder (3 nbits - 1 gates) is as shallow as the
+    # prefix form and cheaper
+    assert be.calls[-1] == ("circuitRun", 3 * nbits - 1, be.calls[-1][2], S)
     out = call(it, tf, "subtractBitsBatch", pa, pb, nbits, S)[0]
     v = value_of(out, S)
     assert np.array_equal(v & 15, (A - B) % 16) and np.array_equal(v >> 4, (A < B).astype(np.int64))
@@ -268,7 +310,8 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
     eoc.Tfhe.resetGateKey()
     lua = Lua(tmp_path)
     names = ("generateGateKey", "resetGateKey", "encryptBits", "decryptBits", "gateBatch", "circuitRun", "sampleInts", "keyMode",
-             "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT", "netlistOptimize")
+             "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT", "netlistOptimize", "netlistCost",
+             "netlistDepth", "circuitBootstraps")
     backend = ml.table_from({n: (lambda *a, _n=n: lua.call(_n, *a)) for n in names})
     it = ml.Interpreter()
     tf = ml.LuaTable()
@@ -304,13 +347,15 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
         assert np.array_equal(dec(lo), np.minimum(A, B)) and np.array_equal(dec(hi), np.maximum(A, B))
         assert np.array_equal(dec(lt), (A < B).astype(np.int64))
         # the adder's bytes against the oracle: the facade's netlist, gate by gate
-        nl, a, b, s = call(it, tf, "adderNetlist", nbits)
+        # (the form addBitsBatch picked for 6 instances: the MUX-carry adder at 4 bits)
+        nl, a, b, s = call(it, tf, "adderNetlistFor", nbits, S)
         g = np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)
+        assert (g[:, 0] == OPS["MUX"]).sum() == nbits - 1
         wires = np.zeros((nl.get(b"nWires"), S, 501), np.int32)
         wires[a:a + nbits] = np.frombuffer(ea, np.int32).reshape(nbits, S, 501)
         wires[b:b + nbits] = np.frombuffer(eb, np.int32).reshape(nbits, S, 501)
-        for op, i0, i1, _, o in g:
-            wires[o] = orc.gate_batch(int(op), wires[i0], wires[i1])
+        for op, i0, i1, i2, o in g:
+            wires[o] = orc.gate_batch(int(op), wires[i0], wires[i1], wires[i2] if i2 >= 0 else None)
         want = np.concatenate([wires[w] for w in ml.to_python(s)]).tobytes()
         assert out == want
         # string-level circuits: base64 ciphertext strings in and out (the facade's own base64), one backend call each;

@@ -27,6 +27,17 @@ def test_reference_tests_in_node_cpu(built_lib):
 
 
 @needs_node
+def test_netlist_forms_in_node_cpu(built_lib):
+    """round 6: tfhe.js's circuit layer on plaintext -- every adder / comparator form against integer arithmetic, the
+    bootstrap counts and depths eoc_tfhe_amd/circuits.py states, the optimizer's carry rewrite through the addon, and the
+    form picked by instance count (netlistCost / netlistDepth)"""
+    _build()
+    r = subprocess.run(["node", os.path.join(NODE_DIR, "test_netlists_cpu.js")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "node netlist cpu tests OK" in r.stdout
+
+
+@needs_node
 def test_cloud_key_client_server_in_node_cpu(built_lib, tmp_path):
     """f2 through the N-API addon: a client process exports the cloud key, a second process installs ONLY that key
     (keyMode 2: no encrypt / decrypt / secret export), adds two ciphertexts, and the client decrypts the sum"""

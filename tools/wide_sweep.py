@@ -60,3 +60,41 @@ for name, env in modes:
         line.append(f"{cnt}: {dt * 1e3:.3f} ms {cnt / dt / 1e3:.1f}k{'' if ok else ' WRONG'}{'' if same else ' DIFFERS'}")
     print(f"{name:24s} " + " | ".join(line), flush=True)
     eng.close()
+
+# ---- mixed column (round 6): `cnt` rows of NAND / XOR / MUX in arbitrary order -- the two-input block and the MUX run
+# as ONE pooled blind rotation (shipped) against one level per group (EOC_TFHE_NO_POOL=1); bootstraps = rows + MUX rows
+if os.environ.get("MIXED", "1") == "1" and p.l == 2:
+    c2 = torch.from_numpy(sk.encrypt_bits(bits, 4, 0)).cuda()
+    mops_all = np.random.default_rng(4).choice(np.array([0, 4, 10], np.uint8), G)
+    mref = {}
+    for name, env in (("mixed, levels per group", {"EOC_TFHE_NO_POOL": "1"}), ("mixed, one pool (shipped)", {})):
+        for k in ("EOC_TFHE_BR_WIDE", "EOC_TFHE_PRIO_DUTY", "EOC_TFHE_BR_PARTS", "EOC_TFHE_NO_POOL"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        eng = eoc.Engine(p)
+        eng.load_cloud_key(sk)
+        line = []
+        for cnt in WIDTHS:
+            mops = mops_all[:cnt]
+            boots = cnt + int((mops == 10).sum())
+            out = torch.empty_like(c0[:cnt])
+            for _ in range(4):
+                eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), c2.data_ptr(), out.data_ptr(), cnt, ops=mops)
+            torch.cuda.synchronize()
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.gate_batch_device(0, c0.data_ptr(), c1.data_ptr(), c2.data_ptr(), out.data_ptr(), cnt, ops=mops)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            o = out.cpu().numpy()
+            b = bits[:cnt]
+            want = np.where(mops == 0, 1 - (b & b), np.where(mops == 4, b ^ b, b))       # all three operands carry `bits`
+            ok = np.array_equal(sk.decrypt_bits(o), want)
+            if cnt not in mref:
+                mref[cnt] = o
+            same = np.array_equal(o, mref[cnt])
+            line.append(f"{cnt}: {dt * 1e3:.3f} ms {boots / dt / 1e3:.1f}k{'' if ok else ' WRONG'}{'' if same else ' DIFFERS'}")
+        print(f"{name:24s} " + " | ".join(line), flush=True)
+        eng.close()
+    os.environ.pop("EOC_TFHE_NO_POOL", None)
