@@ -409,6 +409,80 @@ def test_async_submit_wait_pipeline(eoc, devices):
         eoc.gpu_shutdown()
 
 
+def test_eight_engines_on_one_device(eoc):
+    """VERDICT r5 task 3b: the in-library path at its REAL world size -- eight engines, seven persistent workers, peer-copy
+    key replication to seven replicas, 8-way gather_blocks -- rehearsed on one GPU at small n: ragged blocks (8-way split of
+    61 rows: 8 8 8 8 8 7 7 7), fewer gates than engines (5 rows: three engines idle and NOT woken), a mixed batch (every
+    engine pools its block's groups), a circuit whose instances stay on their engine, and the asynchronous two-deep
+    pipeline across all eight -- every result against the oracle, bit for bit"""
+    from eoc_tfhe_amd import circuits
+    p = eoc.default_params(0)
+    p.n = 40
+    sk = eoc.SecretKey(p, 9)
+    orc = ol.Oracle(0, 9, n_override=40)
+    eoc.gpu_shutdown()
+    eoc.gpu_init(p, devices=[0] * 8)
+    eoc.upload_cloud_key(sk)
+    try:
+        assert eoc.gpu_engine_count() == 8
+        st = eoc.stats_multi()
+        assert st["key_broadcast_method"] == "peer-copy" and len(st["engines"]) == 8
+        rng = np.random.default_rng(88)
+        total = 61
+        b = [rng.integers(0, 2, total).astype(np.uint8) for _ in range(3)]
+        c = [sk.encrypt_bits(b[k], 2 + k, 0) for k in range(3)]
+        before = [e["bootstraps"] for e in eoc.stats_multi()["engines"]]
+        out = eoc.gate_batch(eoc.OPS["NAND"], c[0], c[1])
+        after = [e["bootstraps"] for e in eoc.stats_multi()["engines"]]
+        assert [x - y for x, y in zip(after, before)] == [8, 8, 8, 8, 8, 7, 7, 7]
+        assert np.array_equal(out, orc.gate_batch(ol.OPS["NAND"], c[0], c[1]))
+        ops = rng.choice(np.array([0, 4, 10, 11, 2, 13, 10], np.uint8), total)
+        assert np.array_equal(eoc.gate_batch(0, c[0], c[1], c[2], ops=ops), orc.gate_batch(0, c[0], c[1], c[2], ops=ops))
+        assert np.array_equal(eoc.gate_batch(eoc.OPS["MUX"], c[0], c[1], c[2]), orc.gate_batch(ol.OPS["MUX"], c[0], c[1], c[2]))
+        # fewer rows than engines: blocks 1 1 1 1 1 0 0 0 -- the idle engines' workers stay asleep
+        wake0 = eoc.stats_multi()["worker_wakeups"]
+        out = eoc.gate_batch(eoc.OPS["XOR"], c[0][:5], c[1][:5])
+        wake1 = eoc.stats_multi()["worker_wakeups"]
+        assert np.array_equal(out, orc.gate_batch(ol.OPS["XOR"], c[0][:5], c[1][:5]))
+        assert [x - y for x, y in zip(wake1, wake0)] == [0, 1, 1, 1, 1, 0, 0, 0], (wake0, wake1)
+        # a circuit over 13 instances (blocks 2 2 2 2 2 1 1 1): the picked adder form, every sum decrypts, bytes vs oracle
+        gates, n_wires, aw, bw, sw = circuits.adder(4, 13)
+        S = 13
+        A, B = rng.integers(0, 16, S), rng.integers(0, 16, S)
+        wires = np.zeros((n_wires, S, p.n + 1), np.int32)
+        for i in range(4):
+            wires[aw[0] + i] = sk.encrypt_bits(((A >> i) & 1).astype(np.uint8), 100 + i, 0)
+            wires[bw[0] + i] = sk.encrypt_bits(((B >> i) & 1).astype(np.uint8), 200 + i, 0)
+        ref = wires.copy()
+        eoc.circuit_run(gates, wires, S)
+        assert np.array_equal(sum(sk.decrypt_bits(wires[w]).astype(np.int64) << i for i, w in enumerate(sw)), A + B)
+        for g in gates:
+            ref[g.out] = orc.gate_batch(g.op, ref[g.in0] if g.in0 >= 0 else None, ref[g.in1] if g.in1 >= 0 else None,
+                                        ref[g.in2] if g.in2 >= 0 else None)
+        assert np.array_equal(wires[sw], ref[sw])
+        # asynchronous, two deep, five batches of ragged widths over all eight engines
+        widths = [100, 3, 257, 64, 9]
+        jobs, tickets = [], []
+        for k, w in enumerate(widths):
+            pin = [eoc.PinnedArray((w, p.n + 1)) for _ in range(4)]
+            for j in range(3):
+                pin[j].array[:] = sk.encrypt_bits(rng.integers(0, 2, w).astype(np.uint8), 300 + 10 * k + j, 0)
+            opsk = rng.choice(np.array([0, 4, 10, 12], np.uint8), w) if k % 2 else None
+            jobs.append((pin, 10 if opsk is None else 0, opsk))
+        for k, (pin, op, opsk) in enumerate(jobs):
+            if k >= 2:
+                eoc.gate_batch_wait(tickets[k - 2])
+            tickets.append(eoc.gate_batch_submit(op, pin[0].array, pin[1].array, pin[2].array, ops=opsk, out=pin[3].array))
+        for t in tickets:
+            eoc.gate_batch_wait(t)
+        for k, (pin, op, opsk) in enumerate(jobs):
+            assert np.array_equal(pin[3].array, orc.gate_batch(op, pin[0].array, pin[1].array, pin[2].array, ops=opsk)), k
+            for a in pin:
+                a.free()
+    finally:
+        eoc.gpu_shutdown()
+
+
 def test_freeing_a_pinned_buffer_drains_pending_submissions(eoc):
     """eoc_host_free (a Node Buffer finalizer, a PinnedArray going out of scope) must not release memory under
     a DMA in flight -- it first completes what is pending; a key re-upload drains too.  Two submissions in flight, the

@@ -91,7 +91,7 @@ class Lua:
         self.fn = {}
         for n in ("generateGateKey", "resetGateKey", "encryptBits", "decryptBits", "gateBatch", "circuitRun", "sampleInts",
                   "keyMode", "engineCount", "gateNAND", "encryptBit", "decryptBit", "gateMUX", "gateNOT", "netlistOptimize",
-                  "circuitBootstraps"):
+                  "circuitBootstraps", "netlistCost", "netlistDepth"):
             self.fn[n] = L.ld_table_get(self.S, 1, n.encode())
             assert self.fn[n]
         L.ld_settop0(self.S)
