@@ -173,10 +173,16 @@ def pipe_busy(pset, shape, launch_ms, steps_per_launch, sclk_mhz):
     fp64, w, r, b = mix
     cyc_step = launch_ms * 1e-3 / steps_per_launch * sclk_mhz * 1e6
     lds_cyc = w * LDS_CYCLES["ds_write_b128"] + r * LDS_CYCLES["ds_read_b128"] + b * LDS_CYCLES["ds_bpermute_b32"]
-    return {"fp64_pipe_busy": round(fp64 * FP64_ISSUE_CYCLES * WAVES_PER_SIMD / cyc_step, 3),
-            "lds_pipe_busy": round(lds_cyc * WAVES_PER_CU / cyc_step, 3),
+    fp64_busy = fp64 * FP64_ISSUE_CYCLES * WAVES_PER_SIMD / cyc_step
+    lds_busy = lds_cyc * WAVES_PER_CU / cyc_step
+    return {"fp64_pipe_busy": round(fp64_busy, 3),
+            "lds_pipe_busy": round(lds_busy, 3),
             "lds_store_share_of_lds_pipe": round(w * LDS_CYCLES["ds_write_b128"] / lds_cyc, 3),
-            "bound_primary": "lds_store_path",
+            # derived from the two fractions above, not a constant: the busier pipe of THIS run
+            "bound_primary": "lds_pipe (store path)" if lds_busy >= fp64_busy else "fp64_pipe",
+            "stored_not_measured_in_this_run": "the per-wave-step instruction mix (ISA count) and the LDS cycle costs per "
+                                               "instruction (13.6 / 4.2 / 6.2: tools/ubench_lds*.hip, profiles/r04_ubench_lds3.txt); "
+                                               "live: the launch time (HIP events) and the sampled shader clock",
             "cycles_per_step": round(cyc_step), "sclk_mhz": sclk_mhz, "kernel_shape": shape,
             "per_wave_step": {"fp64_insts": fp64, "ds_write_b128": w, "ds_read_b128": r, "ds_bpermute_b32": b,
                               "lds_pipe_cycles": round(lds_cyc)},
@@ -184,8 +190,8 @@ def pipe_busy(pset, shape, launch_ms, steps_per_launch, sclk_mhz):
                     "lds_pipe_busy = (ds_write_b128 x 13.6 + ds_read_b128 x 4.2 + ds_bpermute_b32 x 6.2 cycles) x 8 waves per "
                     "CU / cycles per step, at the shader clock sampled during the timed steps.  The CU's LDS STORE path "
                     "(~79 B/clk: address + data VGPRs of a ds_write_b128 take 13.6 cycles per KiB) is the busier of the two "
-                    "and the one the ablations move most (DESIGN.md 5.1): bound_primary.  `bound` keeps naming the FP64 "
-                    "roofline the fraction is quoted against"}
+                    "and the one the ablations move most (DESIGN_HISTORY.md 5.1).  `bound` keeps naming the FP64 roofline the "
+                    "fraction is quoted against"}
 
 
 def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_launch_ms=None, sclk_mhz=None,

@@ -56,6 +56,7 @@ struct eoc_engine {
         // recorded behind the consumers of the ring's last quarter (ring_mark): what the wrap-around waits for
         hipEvent_t ring_ev = nullptr;
         bool ring_ev_set = false;
+        bool ring_pushed_since_mark = false; // descriptors were queued behind the last recorded mark (or no mark exists)
         // descriptors sent while the stream is being captured into a hipGraph live in blocks that are never re-used:
         // the captured copy node reads its pinned source again at every replay
         // (allocated with the ring -- nothing may be allocated while a stream captures -- four times its size)
@@ -753,6 +754,11 @@ static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, 
         // a neighbouring batch's copy streams and captures elsewhere in the process are left alone.
         if (W.ring_ev_set) HIP_TRY(hipEventSynchronize(W.ring_ev));
         else HIP_TRY(hipDeviceSynchronize()); // one push filled three quarters of the ring by itself: no mark yet
+        // The mark covers what was queued BEFORE it.  Descriptor copies queued behind it -- earlier pushes of the SAME level
+        // (a free-gate push followed by boot slices), or levels that ended before the ring was three quarters full -- may still
+        // be reading their pinned slots: drain this stream too (only this engine's stream, still no device-wide
+        // synchronise; in the common case -- the wrap is the first push after the mark -- nothing is queued and this is skipped)
+        if (W.ring_ev_set && W.ring_pushed_since_mark) HIP_TRY(hipStreamSynchronize(st));
         W.ring_ev_set = false;
         W.desc_pos = 0;
     }
@@ -761,6 +767,7 @@ static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, 
                            hipMemcpyHostToDevice, st));
     *d_out = W.d_descs + W.desc_pos;
     W.desc_pos += count;
+    W.ring_pushed_since_mark = true;
     return EOC_OK;
 }
 
@@ -770,7 +777,10 @@ static int push_descs(WS &W, const GateDesc *src, size_t count, hipStream_t st, 
 static void ring_mark(WS &W, hipStream_t st)
 {
     if (!W.ring_ev || W.desc_pos * 4 < W.ws_descs * 3 || stream_is_capturing(st)) return;
-    if (hipEventRecord(W.ring_ev, st) == hipSuccess) W.ring_ev_set = true;
+    if (hipEventRecord(W.ring_ev, st) == hipSuccess) {
+        W.ring_ev_set = true;
+        W.ring_pushed_since_mark = false;
+    }
 }
 
 // One "level": a set of gates that all run over the same S instances.  descs are host-side and

@@ -12,16 +12,20 @@ All quantities are in torus units (int32 / 2^32).  N = 1024, k = 1.
 Blind rotation (tfhe_blindRotateAndExtract_FFT), error of the extracted sample under the
 extracted key, over many input ciphertexts and ONE key:
 
-  V_BR = n * 2l * N * E[d^2] * sigma_bk^2                (the TLWE-zero rows of BK_i, every step; E[d^2] = (Bg^2 + 2)/12:
-                                                          digits uniform on [-Bg/2, Bg/2), mean -1/2; two per-cent-level
-                                                          refinements in `predict`: gaussian32 truncates toward zero, so
-                                                          the stored noise has variance sigma^2 - sigma sqrt(2/pi) 2^-32 +
-                                                          2^-64/3, and step 0 works on the trivial accumulator)
-       + w * (1 + |s'|) * q^2 / 12                        (w = Hamming weight of the LWE key, |s'| of the TLWE key:
-                                                          the decomposition's remainder, q = Bg^-l)
-       + (w - 1) * (q/2)^2 * G(s')                        (the remainder is a TRUNCATION: upstream's offset
+  V_BR = n_eff * 2l * N * E[d^2] * sigma_eff^2           (the TLWE-zero rows of BK_i, every step; E[d^2] = (Bg^2 + 2)/12:
+                                                          digits uniform on [-Bg/2, Bg/2), mean -1/2.  As `predict` computes
+                                                          it: sigma_eff^2 = sigma_bk^2 - sigma_bk sqrt(2/pi) 2^-32 + 2^-64/3
+                                                          -- gaussian32 truncates toward zero -- and n_eff = (n - 1 + f0)
+                                                          (1 - 1/2N): step 0 works on the trivial accumulator and counts as
+                                                          the fraction f0 of a regular step; a step whose amount is 0 adds
+                                                          nothing)
+       + w_eff * (1 + |s'|) * q^2 / 12                    (w_eff = w - s_0, w = Hamming weight of the LWE key: step 0's
+                                                          remainder is exactly zero; |s'| = weight of the TLWE key; the
+                                                          decomposition's remainder, q = Bg^-l)
+       + (w_eff - 1) * (q/2)^2 * G(s')                    (the remainder is a TRUNCATION: upstream's offset
                                                           sum_p (Bg/2) 2^(32 - p Bgbit) centres the digits, not the
-                                                          remainder, which is uniform on [0, q) with mean q/2)
+                                                          remainder, which is uniform on [0, q) with mean q/2; the LAST
+                                                          active step contributes the constant M_BR below, not variance)
 
 The third term is what CGGI's worst-case bound hides and the average-case textbook formula omits.  At a step with
 s_i = 1 the update adds  -(low_b - low_a * s')  to the accumulator, low_x[j] in [0, q).  Its mean is the polynomial
@@ -44,6 +48,12 @@ Key switch (lweKeySwitch; A.6), added error for ONE key whose row
 
 The textbook average over keys, kN t (1 - 1/base) sigma_ks^2, is ~ 4/3 of V_KS for a fixed key: a quarter of the
 rows' second moment is the per-key constant M_KS, not spread.
+
+How much of this is fitted: the three refinements (sigma_eff, n_eff / f0, w_eff) were added in round 5 while looking at
+twelve 262 144-sample cases -- keys 1, 2, 3, 4, 5, 9 on both parameter sets (profiles/r05_noise_262144.txt) -- so the
+0.9986 +- 0.0029 agreement on THOSE keys is partly tuned (each refinement is derived, none has a free parameter, but which
+ones to derive was chosen by looking).  Key 77 was never looked at while the model was written: it is the asserted
+HOLD-OUT of tests/test_gpu_noise.py and tests/test_noise_cpu.py.
 """
 import numpy as np
 

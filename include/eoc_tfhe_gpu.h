@@ -186,8 +186,10 @@ uint64_t eoc_engine_workspace_grows(eoc_engine *e);
 /* k_blind_rotate kernel launches so far (eoc_engine_kernel_times counts one span per blind-rotate CALL; a wide level is
  * cut into single-round launches and a gadget-length-3 blind rotation into two parts, so launches >= spans) */
 uint64_t eoc_engine_blind_rotate_launches(eoc_engine *e);
-/* ... of which launches of the one-wave-per-ciphertext kernel (k_blind_rotate_wide: gadget length 2, levels of at least
- * 6 blind rotations per compute unit -- 1 536 on MI355X; bit-identical to the pair kernel, tests/test_gpu_parity.py) */
+/* ... of which launches of the one-wave-per-ciphertext kernel (k_blind_rotate_wide, gadget length 2; bit-identical to the
+ * pair kernel, tests/test_gpu_parity.py).  The shipped rule: a level of more than 4 x CUs blind rotations (1 024 on MI355X)
+ * runs as full wide launches of 8 x CUs (2 048) and a remainder, which runs wide when it exceeds 4 x CUs and on the pair
+ * kernel otherwise; a level of at most 4 x CUs runs on the pair kernel */
 uint64_t eoc_engine_blind_rotate_wide_launches(eoc_engine *e);
 /* blind rotations that fill the device in ONE launch: 8 x compute units where the one-wave-per-ciphertext kernel applies
  * (gadget length 2), 4 x otherwise.  A host that cuts a long job into pieces should cut at multiples of this (the

@@ -58,12 +58,18 @@ def run_noise(eoc, pset, count=COUNT, seed=1):
     return r
 
 
-@pytest.mark.parametrize("pset,seed", [(0, 1), (1, 1), (0, 5)], ids=["setA", "setB", "setA-key5"])
+@pytest.mark.parametrize("pset,seed", [(0, 1), (1, 1), (0, 5), (0, 77), (1, 77)],
+                         ids=["setA", "setB", "setA-key5", "setA-holdout-key77", "setB-holdout-key77"])
 def test_gpu_noise_matches_prediction(eoc, pset, seed):
     """(a second key for Set A: the key switch's bias and variance are properties of the KEY's rows -- predicted per key,
-    not fitted)"""
+    not fitted.  Key 77 is the HOLD-OUT: the model's refinements were chosen while looking at keys 1, 2, 3, 4, 5, 9
+    (profiles/r05_noise_262144.txt); key 77 was first measured after eoc_tfhe_amd/noise.py was frozen, and is held to a
+    window of six standard errors of the variance estimate instead of [0.8, 1.25])"""
     r = run_noise(eoc, pset, seed=seed)
     print({k: (f"{v:.4e}" if isinstance(v, float) else v) for k, v in r.items()})
+    if seed == 77:
+        se = np.sqrt(2.0 / r["count"])
+        assert abs(r["br_ratio"] - 1) < 6 * se and abs(r["ks_ratio"] - 1) < 6 * se, (se, r)
     assert 0.8 < r["br_ratio"] < 1.25, r
     assert 0.8 < r["ks_ratio"] < 1.25, r
     assert abs(r["br_mean_z"]) < 5 and abs(r["ks_mean_z"]) < 5, r

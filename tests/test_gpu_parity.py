@@ -584,6 +584,34 @@ def test_descriptor_ring_wraps_without_a_device_synchronise(eoc, rig_small):
         assert np.array_equal(got[k], want[k % 3]), k
 
 
+def test_ring_wrap_inside_a_level_behind_an_earlier_push(eoc):
+    """the wrap event is recorded at the END of a level; a level whose free-gate push fits behind the mark but
+    whose boot push wraps waits for that mark AND, because a push was queued behind it, drains its own stream before
+    rewriting slots.  A fresh engine (ring of 1 024 slots): call 1 = one level of 900 NAND gates (ring position 900, mark
+    recorded); call 2 = 60 COPY gates (fit: position 960) + 900 XOR gates (wrap inside the level); call 3 repeats call 2
+    (the wrap is now its first push).  Every output against the oracle."""
+    torch = torch_cuda()
+    r = Rig(eoc, 0, 7, n_override=16)
+    _, base = _rand_cts(r, 8, 201)
+    n_in, nb, nf = 8, 900, 60
+    g1 = [eoc.Gate(eoc.OPS["NAND"], k % n_in, (3 * k + 1) % n_in, -1, n_in + k) for k in range(nb)]
+    g2 = [eoc.Gate(eoc.OPS["COPY"], k % n_in, -1, -1, n_in + nb + k) for k in range(nf)] + \
+         [eoc.Gate(eoc.OPS["XOR"], (5 * k) % n_in, (k + 2) % n_in, -1, n_in + k) for k in range(nb)]
+    n_wires = n_in + nb + nf
+    wires = dev_empty((n_wires, 1, r.n + 1), torch.int32)
+    wires.zero_()
+    wires[:n_in, 0] = to_dev(base)
+    ref = np.zeros((n_wires, 1, r.n + 1), np.int32)
+    ref[:n_in, 0] = base
+    for gates in (g1, g2, g2):
+        r.eng.circuit_run_device(gates, wires.data_ptr(), n_wires, 1)
+        for g in gates:
+            ref[g.out] = ref[g.in0] if g.op == eoc.OPS["COPY"] else r.orc.gate_batch(g.op, ref[g.in0], ref[g.in1])
+    sync()
+    assert np.array_equal(wires.cpu().numpy(), ref)
+    r.eng.close()
+
+
 @pytest.mark.parametrize("cnt", [700, 1500, 2300])
 def test_in_place_batches_with_the_folded_prologue(eoc, rig_a, cnt):
     """out aliases an operand (d_out == d_in0, then d_out == d_in1).  Since round 5 the blind rotation's own prologue reads
