@@ -330,6 +330,19 @@ def less_than_for(nbits=8, instances=1, resident_jobs=1024):
     return pick_form(LESS_THAN_FORMS, nbits, instances, resident_jobs)[1]
 
 
+def min_max_for(nbits=8, instances=1, resident_jobs=1024):
+    """(min, max) on the comparator picked for this many instances, one MUX per output bit behind it.
+    Returns (gates, n_wires, a_wires, b_wires, min_wires, max_wires)."""
+    gates, nxt, a, b, lt = less_than_for(nbits, instances, resident_jobs)
+    gates = list(gates)
+    mn = list(range(nxt, nxt + nbits))
+    mx = list(range(nxt + nbits, nxt + 2 * nbits))
+    for i in range(nbits):
+        gates.append(Gate(OPS["MUX"], lt, a[i], b[i], mn[i]))
+        gates.append(Gate(OPS["MUX"], lt, b[i], a[i], mx[i]))
+    return gates, nxt + 2 * nbits, a, b, mn, mx
+
+
 # ---- plaintext semantics and netlist rewriting -----------------------------------------------------
 
 _NAMES = {v: k for k, v in OPS.items()}

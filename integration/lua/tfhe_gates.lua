@@ -205,6 +205,16 @@ end
 function Tfhe.lessThanNetlistFor(nbits, instances)
   return cheapest({ Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
 end
+-- min / max on the comparator picked for this many instances: one MUX per output bit behind it
+function Tfhe.minMaxNetlistFor(nbits, instances)
+  local nl, a, b, lt = Tfhe.lessThanNetlistFor(nbits, instances)
+  local mn, mx = {}, {}
+  for i = 0, nbits - 1 do
+    mn[#mn + 1] = nl.gate(OP.MUX, lt, a + i, b + i)
+    mx[#mx + 1] = nl.gate(OP.MUX, lt, b + i, a + i)
+  end
+  return nl, a, b, lt, mn, mx
+end
 -- a * b -> 2 nbits bits, LSB first: nbits^2 AND partial products, nbits - 1 shifted ripple-carry rows
 function Tfhe.multiplierNetlist(nbits)
   local nl = newNetlist()
@@ -316,7 +326,7 @@ function Tfhe.lessThanBits(A, B)                          -- -> one ciphertext: 
   return wires and sampleToStr(planes(wires, lt, 1, 1))
 end
 function Tfhe.minMaxBits(A, B)                            -- -> min, max (arrays of #A ciphertexts)
-  local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlist(#A)
+  local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlistFor(#A, 1)
   local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1)
   if not wires then return nil end
   return pick(wires, mn), pick(wires, mx)
@@ -364,7 +374,7 @@ function Tfhe.encryptStringBits(str)
 end
 function Tfhe.equalStrings(X, Y) return Tfhe.equalBits(X, Y) end
 function Tfhe.minMaxBitsBatch(A, B, nbits, instances)
-  local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlist(nbits)
+  local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlistFor(nbits, instances)
   local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
   if not wires then return nil end
   local lo, hi = {}, {}

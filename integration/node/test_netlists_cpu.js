@@ -47,6 +47,15 @@ for (let t = 0; t < 300; t++) {
   const { nl, a, b, lt } = tfhe.lessThanTreeNetlist(8);
   assert.strictEqual(run(nl, { [a]: bitsOf(x, 8), [b]: bitsOf(y, 8) })[lt], x < y ? 1 : 0);
 }
+for (const inst of [1, 5000]) {
+  for (let x = 0; x < 8; x++) for (let y = 0; y < 8; y++) {
+    const { nl, a, b, lt, min, max } = tfhe.minMaxNetlistFor(3, inst);
+    const w = run(nl, { [a]: bitsOf(x, 3), [b]: bitsOf(y, 3) });
+    assert.deepStrictEqual([w[lt], valueOf(w, min), valueOf(w, max)], [x < y ? 1 : 0, Math.min(x, y), Math.max(x, y)]);
+  }
+}
+assert.deepStrictEqual(shape(tfhe.minMaxNetlistFor(8, 1).nl), [29 + 32, 5]);
+assert.deepStrictEqual(shape(tfhe.minMaxNetlistFor(8, 4096).nl), [22 + 32, 9]);
 // bootstraps / dependent levels of the 8-bit forms (eoc_tfhe_amd/circuits.py states the same numbers)
 assert.deepStrictEqual(shape(tfhe.adderNetlist(8).nl), [37, 15]);
 assert.deepStrictEqual(shape(tfhe.adderNetlist(8, true).nl), [40, 17]);

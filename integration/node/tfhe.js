@@ -210,6 +210,12 @@ const cheapest = (builders, nbits, instances) => {
 };
 Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
 Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
+// min / max on the comparator picked for this many instances: one MUX per output bit behind it
+Tfhe.minMaxNetlistFor = (nbits, instances) => {
+  const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances), min = [], max = [];
+  for (let i = 0; i < nbits; i++) { min.push(nl.gate(OP.MUX, lt, a + i, b + i)); max.push(nl.gate(OP.MUX, lt, b + i, a + i)); }
+  return { nl, a, b, lt, min, max };
+};
 // run a netlist over `instances` instances: inputs = {firstWire: Buffer [k][instances][n+1]}; returns the wire Buffer
 Tfhe.runNetlist = (nl, inputs, instances, outputs) => {
   const w = B.sampleInts() * 4, plane = instances * w;
@@ -241,7 +247,7 @@ Tfhe.lessThanBits = (A, Bs) => {   // one instance: the log-depth form
   return wires && unstack(planes(wires, lt, 1, 1), 1)[0];
 };
 Tfhe.minMaxBits = (A, Bs) => {
-  const { nl, a, b, min, max } = Tfhe.minMaxNetlist(A.length);
+  const { nl, a, b, min, max } = Tfhe.minMaxNetlistFor(A.length, 1);
   const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1);
   const pick = ws => ws.map(wi => unstack(planes(wires, wi, 1, 1), 1)[0]);
   return wires && { min: pick(min), max: pick(max) };
@@ -263,7 +269,7 @@ Tfhe.multiplyBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [2 nbits][i
   return wires && Buffer.concat(prod.map(wi => planes(wires, wi, 1, instances)));
 };
 Tfhe.minMaxBitsBatch = (Abuf, Bbuf, nbits, instances) => {     // -> { min, max: [nbits][instances][n+1], lt: [instances][n+1] }
-  const { nl, a, b, lt, min, max } = Tfhe.minMaxNetlist(nbits);
+  const { nl, a, b, lt, min, max } = Tfhe.minMaxNetlistFor(nbits, instances);
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
   const pick = ws => Buffer.concat(ws.map(wi => planes(wires, wi, 1, instances)));
   return wires && { min: pick(min), max: pick(max), lt: planes(wires, lt, 1, instances) };

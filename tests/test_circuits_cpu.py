@@ -388,6 +388,16 @@ def test_form_is_picked_by_instance_count():
     for S in (1024, 4096, 100000):
         assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k != "ripple"}, 8, S)[0] == "mux"
         assert c.pick_form(c.LESS_THAN_FORMS, 8, S)[0] == "ripple"
+    for S, depth in ((1, 5), (4096, 9)):
+        gates, nw, a, b, mn, mx = c.min_max_for(8, S)
+        assert c.bootstrap_depth(gates) == depth
+        rng = np.random.default_rng(S)
+        A, B = rng.integers(0, 256, 500), rng.integers(0, 256, 500)
+        w = np.zeros((nw, 500), np.uint8)
+        _load(w, a, A)
+        _load(w, b, B)
+        r = c.evaluate_plain(gates, w)
+        assert np.array_equal(_value(r, mn), np.minimum(A, B)) and np.array_equal(_value(r, mx), np.maximum(A, B))
     small, wide = c.adder(8, 8)[0], c.adder(8, 4096)[0]
     assert c.bootstrap_depth(small) == 5 and circuit_bootstraps(wide) == 30
     # the estimate: below a quarter of the resident set a level costs the same whatever its width

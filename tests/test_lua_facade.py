@@ -255,7 +255,12 @@ def test_forms_are_picked_by_instance_count(facade):
     for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (30, 8), (22, 8))):
         assert shape(call(it, tf, "adderNetlistFor", 8, inst)[0]) == add_want, inst
         assert shape(call(it, tf, "lessThanNetlistFor", 8, inst)[0]) == lt_want, inst
+    assert shape(call(it, tf, "minMaxNetlistFor", 8, 1)[0]) == (29 + 32, 5)
+    assert shape(call(it, tf, "minMaxNetlistFor", 8, 4096)[0]) == (22 + 32, 9)
     A = np.array([200, 13, 255]); B = np.array([100, 250, 255])
+    lo, hi, lt = call(it, tf, "minMaxBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)
+    assert np.array_equal(value_of(lo, 3), np.minimum(A, B)) and np.array_equal(value_of(hi, 3), np.maximum(A, B))
+    assert np.array_equal(value_of(lt, 3), (A < B).astype(np.int64))
     out = call(it, tf, "addBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)[0]
     assert np.array_equal(value_of(out, 3), A + B)
     assert be.calls[-1][:2] == ("circuitRun", len(circuits.prefix_adder(8)[0]))
