@@ -1,4 +1,4 @@
-"""The committed evidence under profiles/ agrees with itself (round 5's set): what the judge cross-checks by hand.
+"""The committed evidence under profiles/ agrees with itself (round 6's set): what the judge cross-checks by hand.
 
   * profiles/traffic.json IS tools/traffic_json.py applied to the committed PMC summaries;
   * the bench lines carry the contract's keys (metric / value / unit / roofline {bound, achieved, peak, unit, frac,
@@ -16,8 +16,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = "r05_final"          # the set DESIGN.md section 7 quotes (one box, one collect_profiles.sh call)
-TAGS = ["r05_final", "r05_last"]   # ... and the same collection repeated on the round's last library (another box)
+TAG = "r06_final"          # the set DESIGN.md section 7 quotes (one box, one collect_profiles.sh call on the final library)
+TAGS = ["r06_final"]
 
 
 def line(name):
@@ -37,18 +37,17 @@ def test_traffic_json_is_reproducible_from_the_committed_pmc_summaries():
     assert want["cobounds_A"]["lds_bank_conflict_cycles"] == 0.0 and want["cobounds_A_wide"]["lds_bank_conflict_cycles"] == 0.0
 
 
-@pytest.mark.parametrize("tag", TAGS)
-def test_the_second_collection_reproduces_the_stored_pmc_figures(tag):
-    """r05_last_traffic.json (the last library, another box) against profiles/traffic.json (r05_final): byte counts per launch
-    within 1 %, the instruction mix identical"""
-    if tag != "r05_last":
-        pytest.skip("the reference set itself")
-    a, b = json.load(open(os.path.join(P, "traffic.json"))), json.load(open(os.path.join(P, f"{tag}_traffic.json")))
+def test_round_5s_collection_is_reproduced_by_round_6s():
+    """r05_last_traffic.json (round 5's last library, another box) against profiles/traffic.json (r06_final): byte counts per
+    launch within 1 %, the FP64 / LDS-store mix identical, and exactly ONE more LDS instruction per wave-step -- the
+    ds_read_u16 that replaced the scalar load of the rotation amount (round 6)"""
+    a, b = json.load(open(os.path.join(P, "traffic.json"))), json.load(open(os.path.join(P, "r05_last_traffic.json")))
     for k in ("blind_rotate_A_1024", "blind_rotate_B_1024", "blind_rotate_A_wide_2048"):
         assert b[k] == pytest.approx(a[k], rel=0.01), k
     for k in ("cobounds_A", "cobounds_B", "cobounds_A_wide"):
         for f in ("fp64_insts_per_wave_step", "ds_write_b128_per_wave_step", "lds_bank_conflict_cycles"):
             assert a[k][f] == b[k][f], (k, f)
+        assert a[k]["lds_insts_per_wave_step"] == pytest.approx(b[k]["lds_insts_per_wave_step"] + 1.0, abs=0.05), k
         assert b[k]["lds_wait_frac"] == pytest.approx(a[k]["lds_wait_frac"], abs=0.005)
 
 
@@ -69,7 +68,7 @@ def test_bench_lines_carry_the_contract_and_add_up(name, pset):
     assert r["unit"] == "TFLOP/s" and r["peak"] == 78.6
     assert r["achieved"] == pytest.approx(r["flop_per_job"] * r["jobs_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=2e-3)
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4)
-    assert r["bound_primary"] == "lds_store_path" and 0.4 < r["pipes"]["fp64_pipe_busy"] < r["pipes"]["lds_pipe_busy"] < 0.9
+    assert r["bound_primary"] == "lds_pipe (store path)" and 0.4 < r["pipes"]["fp64_pipe_busy"] < r["pipes"]["lds_pipe_busy"] < 0.9
     k = d["kernels_ms"]
     assert k["blind_rotate"] + k["keyswitch"] + k["prepare"] <= d["ms_per_step"]
     assert d["ms_per_step"] - (k["blind_rotate"] + k["keyswitch"] + k["prepare"]) < 0.03      # launch residue < 30 us
@@ -82,6 +81,12 @@ def test_bench_lines_carry_the_contract_and_add_up(name, pset):
         assert s["nand16384_wide"]["of_which_wide"] == s["nand16384_wide"]["blind_rotate_launches"] == 8
         assert s["nand16384_wide"]["bootstraps_per_s"] > 1.04 * d["value"]                # the wide kernel's gain
         assert s["adder8"]["bootstraps"] == 163840 and all(s[w]["decrypt_ok"] for w in ("adder8", "streq32", "mixed", "nand16384_wide"))
+        # round 6 (VERDICT r5 task 1): the rewritten literal adder against the netlist as written, and the 8-instance latency
+        assert s["adder8_optimized"]["bootstraps"] == 30 * 4096 and s["adder8_optimized"]["decrypt_ok"]
+        assert s["adder8_optimized"]["pairs_per_s_over_adder8"] >= 1.2
+        lat = s["latency_8_instances_ms"]
+        assert lat["decrypt_ok"] and lat["prefix_over_ripple"] <= 0.4 and lat["prefix_log_depth"] < lat["ripple_rewritten"] < lat["ripple_as_written"]
+        assert s["mixed"]["blind_rotate_spans"] == 1                                       # one pooled blind rotation per mixed call
         for key in ("setA", "setB"):
             n = s["noise_measured_vs_predicted"][key]
             assert n["within_window"] and 0.9 < n["br_ratio"] < 1.1 and 0.9 < n["ks_ratio"] < 1.1 and n["count"] == 16384
@@ -97,14 +102,14 @@ def stats_avg_ms(csv_name, kernel_prefix):
 @pytest.mark.parametrize("TAG", TAGS)
 def test_rocprof_kernel_averages_agree_with_the_hip_events_of_the_traced_runs(TAG):
     d = line(f"{TAG}_bench_under_rocprof.json")
-    avg, mn, calls = stats_avg_ms(f"{TAG}_kernel_stats.csv", "eoc::k_blind_rotate<2, 10>")
+    avg, mn, calls = stats_avg_ms(f"{TAG}_kernel_stats.csv", "eoc::k_blind_rotate<2, 10, false>")
     ev = d["kernels_ms"]["blind_rotate"]
     assert calls == 16 + d["warmup"] + d["steps"]                  # pre-flight + warm-up + timed: the resident steps only
     assert mn <= ev <= avg and avg / ev < 1.04, (mn, ev, avg)     # the average carries one clock ramp (pre-flight)
     avg_ks, _, _ = stats_avg_ms(f"{TAG}_kernel_stats.csv", "eoc::k_keyswitch_waves<8, 8, 32>")
     assert avg_ks == pytest.approx(d["kernels_ms"]["keyswitch"], rel=0.05)
     w = line(f"{TAG}_bench_wide_under_rocprof.json")
-    avg_w, mn_w, calls_w = stats_avg_ms(f"{TAG}_kernel_stats_wide.csv", "eoc::k_blind_rotate_wide<10>")
+    avg_w, mn_w, calls_w = stats_avg_ms(f"{TAG}_kernel_stats_wide.csv", "eoc::k_blind_rotate_wide<10, false>")
     per_launch = w["kernels_ms"]["blind_rotate"] / 8               # 16 384 gates = eight 2048-job launches
     assert avg_w == pytest.approx(per_launch, rel=0.01), (avg_w, per_launch)
     assert calls_w == 8 * (16 + w["warmup"] + w["steps"])
