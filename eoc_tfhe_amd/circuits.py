@@ -215,18 +215,18 @@ def mux_carry_adder(nbits=8):
     return gates, nxt, a, b, s
 
 
-def prefix_adder(nbits=8):
-    """a + b in logarithmic depth: a Sklansky parallel-prefix network over (generate, propagate) pairs.  A group's G and P
-    exclude each other, so the prefix cell (G, P) = (G_hi OR (P_hi AND G_lo), P_hi AND P_lo) is ONE MUX and one AND on the
-    same level: G = MUX(P_hi, G_lo, G_hi).  A single bit as the upper operand needs no generate wire of its own
-    (MUX(p_i, G_lo, a_i)), a prefix that already starts at bit 0 needs no P.  Levels: 1 (p_i, g_i) + ceil(log2 nbits)
-    + 1 (sums) -- 5 for 8 bits, 6 for 16 -- at 48 bootstraps per 8-bit pair (mux_carry_adder: 30 on 8 levels).
-    Same wire layout as ripple_carry_adder.  Returns (gates, n_wires, a_wires, b_wires, sum_wires)."""
+def _prefix_network(nbits, sub):
+    """Sklansky parallel-prefix network over (generate, propagate) pairs, shared by prefix_adder (sub = False: G = a AND b,
+    P = a XOR b, out_i = P_i XOR carry_i) and prefix_subtractor (sub = True: G = (NOT a) AND b -- a borrow arises --,
+    P = a XNOR b -- a borrow passes --, out_i = P_i XNOR borrow_i).  Wires: a = 0..n-1, b = n..2n-1, outputs 2n..3n-1,
+    the carry / borrow out at 3n, then temporaries."""
     a = list(range(nbits))
     b = list(range(nbits, 2 * nbits))
-    s = list(range(2 * nbits, 3 * nbits + 1))
+    o = list(range(2 * nbits, 3 * nbits))
+    top = 3 * nbits
     state = {"nxt": 3 * nbits + 1}
     gates = []
+    p_op, g_op, o_op = ("XNOR", "ANDNY", "XNOR") if sub else ("XOR", "AND", "XOR")
 
     def emit(op, i0, i1, i2=-1, out=None):
         if out is None:
@@ -235,35 +235,55 @@ def prefix_adder(nbits=8):
         gates.append(Gate(OPS[op], i0, i1, i2, out))
         return out
 
+    emit("XOR", a[0], b[0], out=o[0])                     # bit 0 has no carry / borrow in
     if nbits == 1:
-        emit("XOR", a[0], b[0], out=s[0])
-        emit("AND", a[0], b[0], out=s[1])
-        return gates, state["nxt"], a, b, s
-    # which positions are combined at level k (bit k of the position set), with the last position of the block below
+        emit(g_op, a[0], b[0], out=top)
+        return gates, state["nxt"], a, b, o, top
     nlev = (nbits - 1).bit_length()
-    P = [emit("XOR", a[i], b[i], out=s[0] if i == 0 else None) for i in range(nbits)]
+    # position 0 is never an upper operand: its P is not needed (the adder's would be the sum bit itself)
+    P = [None] + [emit(p_op, a[i], b[i]) for i in range(1, nbits)]
     p_bit = list(P)
     # a generate wire only where the position serves as a LOWER operand while still a single bit (even positions)
-    G = [emit("AND", a[i], b[i]) if i % 2 == 0 and i + 1 < nbits or i == 0 else None for i in range(nbits)]
+    G = [emit(g_op, a[i], b[i]) if i % 2 == 0 and i + 1 < nbits or i == 0 else None for i in range(nbits)]
     single = [True] * nbits
     for k in range(nlev):
         newG, newP, newsingle = list(G), list(P), list(single)
         for i in range(nbits):
             if not (i >> k) & 1:
                 continue
-            j = ((i >> k) << k) - 1
+            j = ((i >> k) << k) - 1                     # last position of the block below
             final = i < (1 << (k + 1))                  # the result covers bits 0 .. i
             last = final and i == nbits - 1
-            g_hi = a[i] if single[i] else G[i]
-            newG[i] = emit("MUX", P[i], G[j], g_hi, out=s[nbits] if last else None)
+            # a single bit as the upper operand needs no generate wire: where its inputs differ (P = 0) the carry is a_i,
+            # the borrow b_i
+            g_hi = (b[i] if sub else a[i]) if single[i] else G[i]
+            newG[i] = emit("MUX", P[i], G[j], g_hi, out=top if last else None)
             # P of the combined group is read only by a later cell that uses position i (or a higher position of its
             # block) as the upper operand: never once the group starts at bit 0
             newP[i] = None if final else emit("AND", P[i], P[j])
             newsingle[i] = False
         G, P, single = newG, newP, newsingle
     for i in range(1, nbits):
-        emit("XOR", p_bit[i], G[i - 1], out=s[i])
-    return gates, state["nxt"], a, b, s
+        emit(o_op, p_bit[i], G[i - 1], out=o[i])
+    return gates, state["nxt"], a, b, o, top
+
+
+def prefix_adder(nbits=8):
+    """a + b in logarithmic depth: a Sklansky parallel-prefix network over (generate, propagate) pairs.  A group's G and P
+    exclude each other, so the prefix cell (G, P) = (G_hi OR (P_hi AND G_lo), P_hi AND P_lo) is ONE MUX and one AND on the
+    same level: G = MUX(P_hi, G_lo, G_hi).  A single bit as the upper operand needs no generate wire of its own
+    (MUX(p_i, G_lo, a_i)), a prefix that already starts at bit 0 needs no P.  Levels: 1 (p_i, g_i) + ceil(log2 nbits)
+    + 1 (sums) -- 5 for 8 bits, 6 for 16 -- at 48 bootstraps per 8-bit pair (mux_carry_adder: 30 on 8 levels).
+    Same wire layout as ripple_carry_adder.  Returns (gates, n_wires, a_wires, b_wires, sum_wires)."""
+    gates, n_wires, a, b, o, top = _prefix_network(nbits, False)
+    return gates, n_wires, a, b, o + [top]
+
+
+def prefix_subtractor(nbits=8):
+    """a - b mod 2^nbits and the final borrow (= a < b) in logarithmic depth: the prefix network of prefix_adder over
+    (a borrow arises, a borrow passes) = ((NOT a) AND b, a XNOR b); 48 bootstraps on 5 levels at 8 bits against subtractor's
+    30 on 8.  Same wire layout as subtractor (difference 2n..3n-1).  Returns (gates, n_wires, a, b, diff_wires, borrow)."""
+    return _prefix_network(nbits, True)
 
 
 def less_than_tree(nbits=8):
@@ -303,6 +323,7 @@ def less_than_tree(nbits=8):
 
 ADDER_FORMS = {"ripple": lambda n: ripple_carry_adder(n), "mux": mux_carry_adder, "prefix": prefix_adder}
 LESS_THAN_FORMS = {"ripple": less_than, "tree": less_than_tree}
+SUBTRACTOR_FORMS = {"ripple": lambda n: subtractor(n), "prefix": prefix_subtractor}
 
 
 def pick_form(forms, nbits, instances, resident_jobs=1024):
@@ -328,6 +349,10 @@ def adder(nbits=8, instances=1, resident_jobs=1024):
 
 def less_than_for(nbits=8, instances=1, resident_jobs=1024):
     return pick_form(LESS_THAN_FORMS, nbits, instances, resident_jobs)[1]
+
+
+def subtractor_for(nbits=8, instances=1, resident_jobs=1024):
+    return pick_form(SUBTRACTOR_FORMS, nbits, instances, resident_jobs)[1]
 
 
 def min_max_for(nbits=8, instances=1, resident_jobs=1024):

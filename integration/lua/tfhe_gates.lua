@@ -117,18 +117,20 @@ function Tfhe.muxAdderNetlist(nbits)
   return nl, a, b, sum
 end
 -- logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
--- 48 bootstraps on 5 levels for 8 bits
-function Tfhe.prefixAdderNetlist(nbits)
+-- 48 bootstraps on 5 levels for 8 bits.  sub = true: the same network over (a borrow arises, a borrow passes) =
+-- (ANDNY(a, b), XNOR(a, b)) computes a - b and the final borrow.  -> nl, a, b, out bits, carry / borrow out
+local function prefixNetwork(nbits, sub)
   local nl = newNetlist()
-  local a, b, sum = nl.wire(nbits), nl.wire(nbits), {}
-  if nbits == 1 then
-    sum[1] = nl.gate(OP.XOR, a, b); sum[2] = nl.gate(OP.AND, a, b)
-    return nl, a, b, sum
-  end
+  local a, b, out = nl.wire(nbits), nl.wire(nbits), {}
+  local pOp, gOp, oOp = OP.XOR, OP.AND, OP.XOR
+  if sub then pOp, gOp, oOp = OP.XNOR, OP.ANDNY, OP.XNOR end
+  out[1] = nl.gate(OP.XOR, a, b)
+  if nbits == 1 then return nl, a, b, out, nl.gate(gOp, a, b) end
   local P, G, pbit, single = {}, {}, {}, {}
-  for i = 0, nbits - 1 do P[i] = nl.gate(OP.XOR, a + i, b + i); pbit[i] = P[i]; single[i] = true end
+  for i = 1, nbits - 1 do P[i] = nl.gate(pOp, a + i, b + i); pbit[i] = P[i] end
   for i = 0, nbits - 1 do
-    if i == 0 or (i % 2 == 0 and i + 1 < nbits) then G[i] = nl.gate(OP.AND, a + i, b + i) end
+    single[i] = true
+    if i == 0 or (i % 2 == 0 and i + 1 < nbits) then G[i] = nl.gate(gOp, a + i, b + i) end
   end
   local k = 0
   while (1 << k) < nbits do
@@ -138,7 +140,9 @@ function Tfhe.prefixAdderNetlist(nbits)
       if (i >> k) & 1 == 1 then
         local j = ((i >> k) << k) - 1
         local ghi = G[i]
-        if single[i] then ghi = a + i end
+        if single[i] then
+          if sub then ghi = b + i else ghi = a + i end
+        end
         newG[i] = nl.gate(OP.MUX, P[i], G[j], ghi)
         if i < (1 << (k + 1)) then newP[i] = nil else newP[i] = nl.gate(OP.AND, P[i], P[j]) end
         newS[i] = false
@@ -147,10 +151,16 @@ function Tfhe.prefixAdderNetlist(nbits)
     G, P, single = newG, newP, newS
     k = k + 1
   end
-  sum[1] = pbit[0]
-  for i = 1, nbits - 1 do sum[#sum + 1] = nl.gate(OP.XOR, pbit[i], G[i - 1]) end
-  sum[#sum + 1] = G[nbits - 1]
+  for i = 1, nbits - 1 do out[#out + 1] = nl.gate(oOp, pbit[i], G[i - 1]) end
+  return nl, a, b, out, G[nbits - 1]
+end
+function Tfhe.prefixAdderNetlist(nbits)
+  local nl, a, b, sum, carry = prefixNetwork(nbits, false)
+  sum[#sum + 1] = carry
   return nl, a, b, sum
+end
+function Tfhe.prefixSubtractorNetlist(nbits)              -- -> nl, a, b, difference bits, borrow (= a < b)
+  return prefixNetwork(nbits, true)
 end
 -- unsigned a < b alone, ripple form: lt_0 = ANDNY(a_0, b_0); lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i); 1 + 3 (nbits - 1) bootstraps
 function Tfhe.lessThanNetlist(nbits)
@@ -204,6 +214,9 @@ function Tfhe.adderNetlistFor(nbits, instances)
 end
 function Tfhe.lessThanNetlistFor(nbits, instances)
   return cheapest({ Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
+end
+function Tfhe.subtractorNetlistFor(nbits, instances)
+  return cheapest({ Tfhe.subtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances)
 end
 -- min / max on the comparator picked for this many instances: one MUX per output bit behind it
 function Tfhe.minMaxNetlistFor(nbits, instances)
@@ -341,7 +354,7 @@ function Tfhe.addBitsBatch(A, B, nbits, instances)      -- the form is picked by
   return table.concat(out)                                -- [nbits + 1][instances][n+1]
 end
 function Tfhe.subtractBitsBatch(A, B, nbits, instances)  -- -> [nbits + 1][instances][n+1]: difference bits, then the borrow
-  local nl, a, b, diff, borrow = Tfhe.subtractorNetlist(nbits)
+  local nl, a, b, diff, borrow = Tfhe.subtractorNetlistFor(nbits, instances)
   local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
   if not wires then return nil end
   local out = {}

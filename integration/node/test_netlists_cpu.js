@@ -30,6 +30,11 @@ for (const nbits of [1, 2, 3, 4]) {
       const { nl, a, b, sum } = build(nbits);
       assert.strictEqual(valueOf(run(nl, { [a]: bitsOf(x, nbits), [b]: bitsOf(y, nbits) }), sum), x + y);
     }
+    for (const build of [tfhe.subtractorNetlist, tfhe.prefixSubtractorNetlist]) {
+      const { nl, a, b, diff, borrow } = build(nbits);
+      const w = run(nl, { [a]: bitsOf(x, nbits), [b]: bitsOf(y, nbits) });
+      assert.deepStrictEqual([valueOf(w, diff), w[borrow]], [(x - y + (1 << nbits)) % (1 << nbits), x < y ? 1 : 0]);
+    }
     for (const build of [tfhe.lessThanNetlist, tfhe.lessThanTreeNetlist, tfhe.minMaxNetlist]) {
       const { nl, a, b, lt } = build(nbits);
       assert.strictEqual(run(nl, { [a]: bitsOf(x, nbits), [b]: bitsOf(y, nbits) })[lt], x < y ? 1 : 0);
@@ -62,6 +67,10 @@ assert.deepStrictEqual(shape(tfhe.adderNetlist(8, true).nl), [40, 17]);
 assert.deepStrictEqual(shape(tfhe.muxAdderNetlist(8).nl), [30, 8]);
 assert.deepStrictEqual(shape(tfhe.prefixAdderNetlist(8).nl), [48, 5]);
 assert.deepStrictEqual(shape(tfhe.lessThanNetlist(8).nl), [22, 8]);
+assert.deepStrictEqual(shape(tfhe.subtractorNetlist(8).nl), [30, 8]);
+assert.deepStrictEqual(shape(tfhe.prefixSubtractorNetlist(8).nl), [48, 5]);
+assert.deepStrictEqual(shape(tfhe.subtractorNetlistFor(8, 3).nl), [48, 5]);
+assert.deepStrictEqual(shape(tfhe.subtractorNetlistFor(8, 4096).nl), [30, 8]);
 assert.deepStrictEqual(shape(tfhe.lessThanTreeNetlist(8).nl), [29, 4]);
 // the literal adder through the optimizer: carry rewrite + constant folding
 const lit = tfhe.adderNetlist(8, true);

@@ -147,30 +147,33 @@ Tfhe.muxAdderNetlist = nbits => {
   return { nl, a, b, sum };
 };
 // logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
-// 48 bootstraps on 5 levels for 8 bits
-Tfhe.prefixAdderNetlist = nbits => {
+// 48 bootstraps on 5 levels for 8 bits.  sub: the same network over (a borrow arises, a borrow passes) =
+// (ANDNY(a, b), XNOR(a, b)) computes a - b and the final borrow
+const prefixNetwork = (nbits, sub) => {
   const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
-  if (nbits === 1) return { nl, a, b, sum: [nl.gate(OP.XOR, a, b), nl.gate(OP.AND, a, b)] };
-  let P = [...Array(nbits).keys()].map(i => nl.gate(OP.XOR, a + i, b + i));
+  const [pOp, gOp, oOp] = sub ? [OP.XNOR, OP.ANDNY, OP.XNOR] : [OP.XOR, OP.AND, OP.XOR];
+  const out = [nl.gate(OP.XOR, a, b)];
+  if (nbits === 1) return { nl, a, b, out, top: nl.gate(gOp, a, b) };
+  let P = [null, ...[...Array(nbits - 1).keys()].map(i => nl.gate(pOp, a + i + 1, b + i + 1))];
   const pbit = P.slice();
-  let G = [...Array(nbits).keys()].map(i => (i === 0 || (i % 2 === 0 && i + 1 < nbits)) ? nl.gate(OP.AND, a + i, b + i) : null);
+  let G = [...Array(nbits).keys()].map(i => (i === 0 || (i % 2 === 0 && i + 1 < nbits)) ? nl.gate(gOp, a + i, b + i) : null);
   let single = Array(nbits).fill(true);
   for (let k = 0; (1 << k) < nbits; k++) {
     const newG = G.slice(), newP = P.slice(), newS = single.slice();
     for (let i = 0; i < nbits; i++) {
       if (!((i >> k) & 1)) continue;
       const j = ((i >> k) << k) - 1;
-      newG[i] = nl.gate(OP.MUX, P[i], G[j], single[i] ? a + i : G[i]);
+      newG[i] = nl.gate(OP.MUX, P[i], G[j], single[i] ? (sub ? b + i : a + i) : G[i]);
       newP[i] = i < (1 << (k + 1)) ? null : nl.gate(OP.AND, P[i], P[j]);
       newS[i] = false;
     }
     G = newG; P = newP; single = newS;
   }
-  const sum = [pbit[0]];
-  for (let i = 1; i < nbits; i++) sum.push(nl.gate(OP.XOR, pbit[i], G[i - 1]));
-  sum.push(G[nbits - 1]);
-  return { nl, a, b, sum };
+  for (let i = 1; i < nbits; i++) out.push(nl.gate(oOp, pbit[i], G[i - 1]));
+  return { nl, a, b, out, top: G[nbits - 1] };
 };
+Tfhe.prefixAdderNetlist = nbits => { const { nl, a, b, out, top } = prefixNetwork(nbits, false); return { nl, a, b, sum: [...out, top] }; };
+Tfhe.prefixSubtractorNetlist = nbits => { const { nl, a, b, out, top } = prefixNetwork(nbits, true); return { nl, a, b, diff: out, borrow: top }; };
 // unsigned a < b alone, ripple form: lt_0 = ANDNY(a_0, b_0); lt_i = MUX(a_i XNOR b_i, lt_{i-1}, b_i); 1 + 3 (nbits - 1) bootstraps
 Tfhe.lessThanNetlist = nbits => {
   const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
@@ -210,6 +213,7 @@ const cheapest = (builders, nbits, instances) => {
 };
 Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
 Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
+Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.subtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances);
 // min / max on the comparator picked for this many instances: one MUX per output bit behind it
 Tfhe.minMaxNetlistFor = (nbits, instances) => {
   const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances), min = [], max = [];
@@ -259,7 +263,7 @@ Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // the form is picked 
   return wires && Buffer.concat(sum.map(wi => planes(wires, wi, 1, instances)));   // [nbits + 1][instances][n+1]
 };
 Tfhe.subtractBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [nbits + 1][instances][n+1]: difference bits, then the borrow
-  const { nl, a, b, diff, borrow } = Tfhe.subtractorNetlist(nbits);
+  const { nl, a, b, diff, borrow } = Tfhe.subtractorNetlistFor(nbits, instances);
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
   return wires && Buffer.concat([...diff, borrow].map(wi => planes(wires, wi, 1, instances)));
 };

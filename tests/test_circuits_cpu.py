@@ -276,6 +276,22 @@ def test_adder_forms_all_inputs(nbits):
         assert 1 + (nbits - 1).bit_length() <= c.bootstrap_depth(c.prefix_adder(nbits)[0]) <= 2 + (nbits - 1).bit_length()
 
 
+@pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5, 6])
+def test_prefix_subtractor_all_inputs(nbits):
+    A, B, S = _words(nbits)
+    for build in c.SUBTRACTOR_FORMS.values():
+        gates, nw, a, b, d, br = build(nbits)
+        c._check_ssa(gates)
+        w = np.zeros((nw, S), np.uint8)
+        _load(w, a, A)
+        _load(w, b, B)
+        r = c.evaluate_plain(gates, w)
+        assert np.array_equal(_value(r, d), (A - B) % (1 << nbits)) and np.array_equal(r[br], (A < B).astype(np.uint8))
+    g8 = c.prefix_subtractor(8)[0]
+    assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (48, 5)
+    assert c.pick_form(c.SUBTRACTOR_FORMS, 8, 8)[0] == "prefix" and c.pick_form(c.SUBTRACTOR_FORMS, 8, 4096)[0] == "ripple"
+
+
 def test_adder_forms_eight_bits_counts():
     ripple, mux, prefix = (f(8)[0] for f in (c.ADDER_FORMS["ripple"], c.mux_carry_adder, c.prefix_adder))
     assert (circuit_bootstraps(ripple), c.bootstrap_depth(ripple)) == (37, 15)

@@ -453,7 +453,9 @@ def test_subtractor_and_multiplier_bit_exact(eoc):
     p, sk, eng, orc = _setup(eoc, 0, 6, 28)
     S = 21
     rng = np.random.default_rng(12)
-    for build, nbits, expect in ((circuits.subtractor, 5, lambda a, b: (a - b) % 32), (circuits.multiplier, 3, lambda a, b: a * b)):
+    for build, nbits, expect in ((circuits.subtractor, 5, lambda a, b: (a - b) % 32), (circuits.multiplier, 3, lambda a, b: a * b),
+                                 (circuits.prefix_subtractor, 5, lambda a, b: (a - b) % 32),        # round 6: log-depth form
+                                 (circuits.prefix_subtractor, 8, lambda a, b: (a - b) % 256)):
         res = build(nbits)
         gates, n_wires, aw, bw, outw = res[0], res[1], res[2], res[3], res[4]
         A, B = rng.integers(0, 1 << nbits, S), rng.integers(0, 1 << nbits, S)
@@ -467,3 +469,5 @@ def test_subtractor_and_multiplier_bit_exact(eoc):
             assert np.array_equal(got[g.out], want[g.out]), (build.__name__, g.out)
         val = sum(sk.decrypt_bits(got[w]).astype(np.int64) << i for i, w in enumerate(outw))
         assert np.array_equal(val, expect(A, B)), build.__name__
+        if "subtractor" in build.__name__:
+            assert np.array_equal(sk.decrypt_bits(got[res[5]]), (A < B).astype(np.uint8)), build.__name__   # the final borrow

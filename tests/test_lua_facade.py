@@ -158,7 +158,7 @@ def value_of(buf, instances):
 def test_facade_defines_its_functions_and_passes_through(facade):
     it, tf, be = facade
     for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
-                 "muxAdderNetlist", "prefixAdderNetlist", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
+                 "muxAdderNetlist", "prefixAdderNetlist", "prefixSubtractorNetlist", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
                  "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
                  "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
         assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
@@ -214,6 +214,11 @@ def test_netlist_builders_on_plaintext(facade, nbits):
         assert np.array_equal(word(bits, ml.to_python(s)), A + B), lua_name
         pg = py(nbits)[0]
         assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 1 for g in pg)), lua_name
+    nl, a, b, diff, br = call(it, tf, "prefixSubtractorNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(word(bits, ml.to_python(diff)), (A - B) % (1 << nbits)) and np.array_equal(bits[br], (A < B).astype(np.int64))
+    pg = circuits.prefix_subtractor(nbits)[0]
+    assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 1 for g in pg))
     nl, a, b, lt = call(it, tf, "lessThanTreeNetlist", nbits)
     bits, (ngates, boots) = evaluate(nl, a, b)
     assert np.array_equal(bits[lt], (A < B).astype(np.int64))
@@ -255,6 +260,8 @@ def test_forms_are_picked_by_instance_count(facade):
     for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (30, 8), (22, 8))):
         assert shape(call(it, tf, "adderNetlistFor", 8, inst)[0]) == add_want, inst
         assert shape(call(it, tf, "lessThanNetlistFor", 8, inst)[0]) == lt_want, inst
+    assert shape(call(it, tf, "subtractorNetlistFor", 8, 2)[0]) == (48, 5)
+    assert shape(call(it, tf, "subtractorNetlistFor", 8, 4096)[0]) == (30, 8)
     assert shape(call(it, tf, "minMaxNetlistFor", 8, 1)[0]) == (29 + 32, 5)
     assert shape(call(it, tf, "minMaxNetlistFor", 8, 4096)[0]) == (22 + 32, 9)
     A = np.array([200, 13, 255]); B = np.array([100, 250, 255])
