@@ -903,6 +903,23 @@ class Tfhe:
         return Tfhe._run(built, A, B, A.shape[1], [built[4]])[0]
 
     @staticmethod
+    def subtractBitsBatch(A, B):
+        """A, B: samples [nbits][instances][n+1] -> [nbits + 1][instances][n+1]: difference bits, then the borrow (= A < B)"""
+        from . import circuits
+        A, B = np.ascontiguousarray(A, np.int32), np.ascontiguousarray(B, np.int32)
+        built = circuits.subtractor_for(A.shape[0], A.shape[1])
+        return Tfhe._run(built, A, B, A.shape[1], list(built[4]) + [built[5]])
+
+    @staticmethod
+    def minMaxBitsBatch(A, B):
+        """A, B: samples [nbits][instances][n+1] -> (min, max), each [nbits][instances][n+1]"""
+        from . import circuits
+        A, B = np.ascontiguousarray(A, np.int32), np.ascontiguousarray(B, np.int32)
+        built = circuits.min_max_for(A.shape[0], A.shape[1])
+        out = Tfhe._run(built, A, B, A.shape[1], list(built[4]) + list(built[5]))
+        return out[: A.shape[0]], out[A.shape[0]:]
+
+    @staticmethod
     def addBits(A, B):
         """arrays of base64 bit ciphertexts (LSB first) -> len(A) + 1 ciphertext strings (the log-depth adder)"""
         return Tfhe._strings(Tfhe.addBitsBatch(Tfhe._samples(A), Tfhe._samples(B)))

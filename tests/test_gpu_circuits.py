@@ -176,6 +176,11 @@ def test_string_api_and_host_batch_api(eoc):
         assert eoc.stats()["bootstraps"] - st0["bootstraps"] == 30 * 1200                               # MUX-carry adder
         assert np.array_equal(sum(eoc.global_decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9)), Av + Bv)
         assert np.array_equal(eoc.global_decrypt_bits(T.lessThanBitsBatch(planes(Av), planes(Bv))), (Av < Bv).astype(np.uint8))
+        word = lambda w: sum(eoc.global_decrypt_bits(w[i]).astype(np.int64) << i for i in range(w.shape[0]))
+        diff = T.subtractBitsBatch(planes(Av[:9]), planes(Bv[:9]))                                   # 9 instances: prefix form
+        assert np.array_equal(word(diff[:8]), (Av[:9] - Bv[:9]) % 256) and np.array_equal(word(diff[8:]), (Av[:9] < Bv[:9]))
+        mn, mx = T.minMaxBitsBatch(planes(Av[:9]), planes(Bv[:9]))
+        assert np.array_equal(word(mn), np.minimum(Av[:9], Bv[:9])) and np.array_equal(word(mx), np.maximum(Av[:9], Bv[:9]))
     finally:
         T.resetGateKey()
 
