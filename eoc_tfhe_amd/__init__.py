@@ -911,6 +911,15 @@ class Tfhe:
         return Tfhe._run(built, A, B, A.shape[1], list(built[4]) + [built[5]])
 
     @staticmethod
+    def multiplyBitsBatch(A, B):
+        """A, B: samples [nbits][instances][n+1] -> [2 nbits][instances][n+1]: column compression + one prefix addition for
+        small batches, the row-by-row form for wide ones (both through the netlist optimizer)"""
+        from . import circuits
+        A, B = np.ascontiguousarray(A, np.int32), np.ascontiguousarray(B, np.int32)
+        built = circuits.multiplier_for(A.shape[0], A.shape[1])
+        return Tfhe._run(built, A, B, A.shape[1], built[4])
+
+    @staticmethod
     def minMaxBitsBatch(A, B):
         """A, B: samples [nbits][instances][n+1] -> (min, max), each [nbits][instances][n+1]"""
         from . import circuits

@@ -936,10 +936,13 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
     const int32_t *in0 = d_in0, *in1 = d_in1, *in2 = d_in2;
     int32_t *out = d_out;
     const bool gather = runs > 15; // more runs than opcodes: sorting pays
-    // every bootstrapped row of the call is one job of ONE blind rotation (run_pool), a MUX row two
+    // every bootstrapped row of the call is one job of ONE blind rotation (run_pool), a MUX row two -- up to 2^20 jobs
+    // (9.6 GB of extracted samples and rotation amounts: the bound eoc_circuit_run_device puts on a level); a wider call,
+    // or EOC_TFHE_NO_POOL=1 (diagnostics), runs every opcode group as a level of its own, as before round 6
     size_t max_jobs = 0;
     for (size_t k = 0; k < count; k++) max_jobs += ops[k] == OP_MUX ? 2 : (op_free(ops[k]) ? 0 : 1);
-    if (e->no_pool) { // diagnostics (EOC_TFHE_NO_POOL=1): every opcode run is a level of its own, as before round 6
+    const bool use_pool = !e->no_pool && max_jobs <= ((size_t)1 << 20);
+    if (!use_pool) {
         size_t cnt_op[OP_CONST1 + 1] = {0}, run = 0;
         max_jobs = 0;
         for (size_t k = 0; k < count; k++) {
@@ -1024,7 +1027,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         while (j < count && run_ops[j] < OP_MUX) j++;
         if (j > 0 && run_ops[0] != run_ops[j - 1]) {
             GateDesc d{OP_MULTI, 0, in0, in1, reinterpret_cast<const int32_t *>(d_perm), out};
-            if (e->no_pool) {
+            if (!use_pool) {
                 rc = flush_one(d, j);
                 if (rc) return rc;
             } else pool.push_back({d, j});
@@ -1037,7 +1040,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         int o = run_ops[i];
         GateDesc d{o, 0, in0 ? in0 + i * stride : nullptr, in1 ? in1 + i * stride : nullptr,
                    in2 ? in2 + i * stride : nullptr, out + i * stride};
-        if (op_free(o) || e->no_pool) {
+        if (op_free(o) || !use_pool) {
             rc = flush_one(d, j - i);
             if (rc) return rc;
         } else pool.push_back({d, j - i});

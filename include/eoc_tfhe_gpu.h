@@ -178,7 +178,8 @@ int eoc_engine_cloud_key_device(eoc_engine *e, const void **d_bkfft, const void 
  * a permutation takes count / 10 slots), because the captured copy nodes read their pinned sources again at every
  * replay; when the arena is exhausted the call fails with EOC_ERR_STATE.
  *   max_jobs       : blind rotations of the widest level (instances x gates of the level, MUX counts twice; in a mixed
- *                    batch with more than 15 opcode runs ALL rows with two-input opcodes form one level)
+ *                    batch ALL bootstrapped rows of the call share one pooled blind rotation -- rows with two-input opcodes
+ *                    + 2 x MUX rows -- unless that exceeds 2^20 jobs, beyond which every opcode group is a level of its own)
  *   max_descs      : gate descriptors sent between two wrap-arounds of the ring (>= gates of the netlist)
  *   max_mixed_rows : rows of the largest mixed (ops != NULL) batch, 0 if none */
 int eoc_engine_reserve(eoc_engine *e, size_t max_jobs, size_t max_descs, size_t max_mixed_rows);
@@ -201,9 +202,10 @@ const eoc_params *eoc_engine_params(eoc_engine *e);
  * one homogeneous or mixed batch of independent gates, all operands resident on the device.
  *   op      : opcode when ops == NULL
  *   ops     : HOST array [count] of opcodes in any order, or NULL (rows are grouped on the device: gather into
- *             opcode-sorted order; the ten two-input opcodes -- which differ only in their linear stage -- run as one
- *             batch, MUX as another, NOT / COPY / CONSTANT without a bootstrap; scatter back).  At most 2^28 - 1 rows
- *             per call with ops != NULL (EOC_ERR_ARG beyond)
+ *             opcode-sorted order; the ten two-input opcodes -- which differ only in their linear stage -- form one
+ *             group, MUX rows another, and both share ONE blind rotation over the concatenated jobs; NOT / COPY /
+ *             CONSTANT take no bootstrap; scatter back).  At most 2^28 - 1 rows per call with ops != NULL (EOC_ERR_ARG
+ *             beyond)
  *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX)
  *   d_out   : DEVICE array  [count][n+1] int32
  * bootsNAND ... bootsMUX over a batch.  Asynchronous on hip_stream (NULL = default stream). */

@@ -119,18 +119,18 @@ end
 -- logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
 -- 48 bootstraps on 5 levels for 8 bits.  sub = true: the same network over (a borrow arises, a borrow passes) =
 -- (ANDNY(a, b), XNOR(a, b)) computes a - b and the final borrow.  -> nl, a, b, out bits, carry / borrow out
-local function prefixNetwork(nbits, sub)
-  local nl = newNetlist()
-  local a, b, out = nl.wire(nbits), nl.wire(nbits), {}
+local function prefixCells(nl, a, b, sub)                 -- a, b: 0-based arrays of wires, LSB first -> out bits (1-based), top
+  local nbits = #a + 1
+  local out = {}
   local pOp, gOp, oOp = OP.XOR, OP.AND, OP.XOR
   if sub then pOp, gOp, oOp = OP.XNOR, OP.ANDNY, OP.XNOR end
-  out[1] = nl.gate(OP.XOR, a, b)
-  if nbits == 1 then return nl, a, b, out, nl.gate(gOp, a, b) end
+  out[1] = nl.gate(OP.XOR, a[0], b[0])
+  if nbits == 1 then return out, nl.gate(gOp, a[0], b[0]) end
   local P, G, pbit, single = {}, {}, {}, {}
-  for i = 1, nbits - 1 do P[i] = nl.gate(pOp, a + i, b + i); pbit[i] = P[i] end
+  for i = 1, nbits - 1 do P[i] = nl.gate(pOp, a[i], b[i]); pbit[i] = P[i] end
   for i = 0, nbits - 1 do
     single[i] = true
-    if i == 0 or (i % 2 == 0 and i + 1 < nbits) then G[i] = nl.gate(gOp, a + i, b + i) end
+    if i == 0 or (i % 2 == 0 and i + 1 < nbits) then G[i] = nl.gate(gOp, a[i], b[i]) end
   end
   local k = 0
   while (1 << k) < nbits do
@@ -141,7 +141,7 @@ local function prefixNetwork(nbits, sub)
         local j = ((i >> k) << k) - 1
         local ghi = G[i]
         if single[i] then
-          if sub then ghi = b + i else ghi = a + i end
+          if sub then ghi = b[i] else ghi = a[i] end
         end
         newG[i] = nl.gate(OP.MUX, P[i], G[j], ghi)
         if i < (1 << (k + 1)) then newP[i] = nil else newP[i] = nl.gate(OP.AND, P[i], P[j]) end
@@ -152,7 +152,14 @@ local function prefixNetwork(nbits, sub)
     k = k + 1
   end
   for i = 1, nbits - 1 do out[#out + 1] = nl.gate(oOp, pbit[i], G[i - 1]) end
-  return nl, a, b, out, G[nbits - 1]
+  return out, G[nbits - 1]
+end
+local function prefixNetwork(nbits, sub)
+  local nl = newNetlist()
+  local a, b, A, B = nl.wire(nbits), nl.wire(nbits), {}, {}
+  for i = 0, nbits - 1 do A[i] = a + i; B[i] = b + i end
+  local out, top = prefixCells(nl, A, B, sub)
+  return nl, a, b, out, top
 end
 function Tfhe.prefixAdderNetlist(nbits)
   local nl, a, b, sum, carry = prefixNetwork(nbits, false)
@@ -215,6 +222,9 @@ end
 function Tfhe.lessThanNetlistFor(nbits, instances)
   return cheapest({ Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
 end
+function Tfhe.multiplierNetlistFor(nbits, instances)
+  return cheapest({ Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist }, nbits, instances)
+end
 function Tfhe.subtractorNetlistFor(nbits, instances)
   return cheapest({ Tfhe.subtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances)
 end
@@ -261,6 +271,91 @@ function Tfhe.multiplierNetlist(nbits)
   if top == nil then top = nl.gate(OP.CONST0, -1) end
   prod[#prod + 1] = top
   return nl, a, b, prod
+end
+-- a * b in logarithmic depth: partial products in columns by weight, column compression by full adders (sum = (x ^ y) ^ z,
+-- carry = MUX(x ^ y, z, x); the latest arriving wire of a triple is its z) until no column holds more than two wires, then
+-- ONE parallel-prefix addition of the two remaining rows; 8 bits: 16 levels against the row-by-row form's 40
+function Tfhe.wallaceMultiplierNetlist(nbits)
+  local nl = newNetlist()
+  local a, b = nl.wire(nbits), nl.wire(nbits)
+  if nbits == 1 then return nl, a, b, { nl.gate(OP.AND, a, b), nl.gate(OP.CONST0, -1) } end
+  local ncol = 2 * nbits
+  local cols = {}
+  for c = 0, ncol - 1 do cols[c] = {} end
+  for r = 0, nbits - 1 do
+    for j = 0, nbits - 1 do
+      local col = cols[r + j]
+      col[#col + 1] = { 1, nl.gate(OP.AND, a + j, b + r) }
+    end
+  end
+  local function sorted(col)                            -- by (level, wire): insertion sort (columns hold a handful of wires)
+    local t = {}
+    for i = 1, #col do
+      local e, k = col[i], i - 1
+      while k >= 1 and (t[k][1] > e[1] or (t[k][1] == e[1] and t[k][2] > e[2])) do t[k + 1] = t[k]; k = k - 1 end
+      t[k + 1] = e
+    end
+    return t
+  end
+  local function tallest()
+    local m = 0
+    for c = 0, ncol - 1 do if #cols[c] > m then m = #cols[c] end end
+    return m
+  end
+  while tallest() > 2 do
+    local new = {}
+    for c = 0, ncol - 1 do new[c] = {} end
+    for c = 0, ncol - 1 do
+      local col = sorted(cols[c])
+      local i = 1
+      while #col - i + 1 >= 3 do
+        local x, y, z = col[i], col[i + 1], col[i + 2]
+        local p = nl.gate(OP.XOR, x[2], y[2])
+        local lp = x[1]
+        if y[1] > lp then lp = y[1] end
+        lp = lp + 1
+        local lv = lp
+        if z[1] > lv then lv = z[1] end
+        lv = lv + 1
+        local nc, nc1 = new[c], new[c + 1]
+        nc[#nc + 1] = { lv, nl.gate(OP.XOR, p, z[2]) }
+        nc1[#nc1 + 1] = { lv, nl.gate(OP.MUX, p, z[2], x[2]) }
+        i = i + 3
+      end
+      local nc = new[c]
+      for k = i, #col do nc[#nc + 1] = col[k] end
+    end
+    cols = new
+  end
+  local prod, c0 = {}, 0
+  while c0 < ncol and #cols[c0] <= 1 do                  -- low columns that are already final
+    if #cols[c0] == 1 then prod[#prod + 1] = cols[c0][1][2] else prod[#prod + 1] = -1 end
+    c0 = c0 + 1
+  end
+  local hi = ncol - 1
+  while hi >= c0 and #cols[hi] == 0 do hi = hi - 1 end
+  if hi >= c0 then
+    local zero, xs, ys = nil, {}, {}
+    for c = c0, hi do
+      local col = sorted(cols[c])
+      xs[c - c0] = col[1][2]
+      if #col > 1 then ys[c - c0] = col[2][2]
+      else
+        if zero == nil then zero = nl.gate(OP.CONST0, -1) end
+        ys[c - c0] = zero
+      end
+    end
+    local out, top = prefixCells(nl, xs, ys, false)
+    for i = 1, #out do prod[#prod + 1] = out[i] end
+    prod[#prod + 1] = top
+  end
+  local res = {}
+  for k = 1, ncol do
+    local w = prod[k]
+    if w == nil or w == -1 then w = nl.gate(OP.CONST0, -1) end
+    res[k] = w
+  end
+  return nl, a, b, res
 end
 -- run a netlist over `instances` instances; inputs = { [firstWire] = samples [k][instances][n+1] };
 -- outputs (optional): the wires the caller reads afterwards -- the netlist is then rewritten first (NOT folding, MUX fusion)
@@ -363,8 +458,8 @@ function Tfhe.subtractBitsBatch(A, B, nbits, instances)  -- -> [nbits + 1][insta
   return table.concat(out)
 end
 function Tfhe.multiplyBitsBatch(A, B, nbits, instances)  -- -> [2 nbits][instances][n+1]
-  local nl, a, b, prod = Tfhe.multiplierNetlist(nbits)
-  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  local nl, a, b, prod = Tfhe.multiplierNetlistFor(nbits, instances)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances, prod)    -- through netlistOptimize (carry rewrite, constants)
   if not wires then return nil end
   local out = {}
   for i = 1, #prod do out[i] = planes(wires, prod[i], 1, instances) end

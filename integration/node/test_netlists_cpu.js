@@ -23,12 +23,17 @@ const run = (nl, inputs) => {            // inputs: { firstWire: [bit, bit, ...]
 const bitsOf = (v, n) => [...Array(n).keys()].map(i => (v >> i) & 1);
 const valueOf = (w, wires) => wires.reduce((acc, wi, i) => acc + w[wi] * 2 ** i, 0);
 const shape = nl => [B.circuitBootstraps(nl.packed()), B.netlistDepth(nl.packed())];
+const WALLACE8 = [328, 16];
 
 for (const nbits of [1, 2, 3, 4]) {
   for (let x = 0; x < 1 << nbits; x++) for (let y = 0; y < 1 << nbits; y++) {
     for (const build of [tfhe.adderNetlist, tfhe.muxAdderNetlist, tfhe.prefixAdderNetlist]) {
       const { nl, a, b, sum } = build(nbits);
       assert.strictEqual(valueOf(run(nl, { [a]: bitsOf(x, nbits), [b]: bitsOf(y, nbits) }), sum), x + y);
+    }
+    for (const build of [tfhe.multiplierNetlist, tfhe.wallaceMultiplierNetlist]) {
+      const { nl, a, b, prod } = build(nbits);
+      assert.strictEqual(valueOf(run(nl, { [a]: bitsOf(x, nbits), [b]: bitsOf(y, nbits) }), prod), x * y);
     }
     for (const build of [tfhe.subtractorNetlist, tfhe.prefixSubtractorNetlist]) {
       const { nl, a, b, diff, borrow } = build(nbits);
@@ -51,6 +56,8 @@ for (let t = 0; t < 300; t++) {
   }
   const { nl, a, b, lt } = tfhe.lessThanTreeNetlist(8);
   assert.strictEqual(run(nl, { [a]: bitsOf(x, 8), [b]: bitsOf(y, 8) })[lt], x < y ? 1 : 0);
+  const wm = tfhe.wallaceMultiplierNetlist(8);
+  assert.strictEqual(valueOf(run(wm.nl, { [wm.a]: bitsOf(x, 8), [wm.b]: bitsOf(y, 8) }), wm.prod), x * y);
 }
 for (const inst of [1, 5000]) {
   for (let x = 0; x < 8; x++) for (let y = 0; y < 8; y++) {
@@ -67,6 +74,12 @@ assert.deepStrictEqual(shape(tfhe.adderNetlist(8, true).nl), [40, 17]);
 assert.deepStrictEqual(shape(tfhe.muxAdderNetlist(8).nl), [30, 8]);
 assert.deepStrictEqual(shape(tfhe.prefixAdderNetlist(8).nl), [48, 5]);
 assert.deepStrictEqual(shape(tfhe.lessThanNetlist(8).nl), [22, 8]);
+assert.deepStrictEqual(shape(tfhe.multiplierNetlist(8).nl), [320, 40]);
+assert.deepStrictEqual(shape(tfhe.wallaceMultiplierNetlist(8).nl), WALLACE8);
+assert.deepStrictEqual(shape(tfhe.multiplierNetlistFor(8, 2).nl), WALLACE8);
+assert.deepStrictEqual(shape(tfhe.multiplierNetlistFor(8, 4096).nl), [320, 40]);
+const wopt = B.netlistOptimize(tfhe.wallaceMultiplierNetlist(8).nl.packed(), Int32Array.from(tfhe.wallaceMultiplierNetlist(8).prod));
+assert.deepStrictEqual([B.circuitBootstraps(wopt), B.netlistDepth(wopt)], [315, 16]);
 assert.deepStrictEqual(shape(tfhe.subtractorNetlist(8).nl), [30, 8]);
 assert.deepStrictEqual(shape(tfhe.prefixSubtractorNetlist(8).nl), [48, 5]);
 assert.deepStrictEqual(shape(tfhe.subtractorNetlistFor(8, 3).nl), [48, 5]);

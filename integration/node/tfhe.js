@@ -149,28 +149,35 @@ Tfhe.muxAdderNetlist = nbits => {
 // logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
 // 48 bootstraps on 5 levels for 8 bits.  sub: the same network over (a borrow arises, a borrow passes) =
 // (ANDNY(a, b), XNOR(a, b)) computes a - b and the final borrow
-const prefixNetwork = (nbits, sub) => {
-  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+const prefixCells = (nl, a, b, sub) => {               // a, b: arrays of wires, LSB first -> { out, top }
+  const nbits = a.length;
   const [pOp, gOp, oOp] = sub ? [OP.XNOR, OP.ANDNY, OP.XNOR] : [OP.XOR, OP.AND, OP.XOR];
-  const out = [nl.gate(OP.XOR, a, b)];
-  if (nbits === 1) return { nl, a, b, out, top: nl.gate(gOp, a, b) };
-  let P = [null, ...[...Array(nbits - 1).keys()].map(i => nl.gate(pOp, a + i + 1, b + i + 1))];
+  const out = [nl.gate(OP.XOR, a[0], b[0])];
+  if (nbits === 1) return { out, top: nl.gate(gOp, a[0], b[0]) };
+  let P = [null];
+  for (let i = 1; i < nbits; i++) P.push(nl.gate(pOp, a[i], b[i]));
   const pbit = P.slice();
-  let G = [...Array(nbits).keys()].map(i => (i === 0 || (i % 2 === 0 && i + 1 < nbits)) ? nl.gate(gOp, a + i, b + i) : null);
+  let G = [];
+  for (let i = 0; i < nbits; i++) G.push((i === 0 || (i % 2 === 0 && i + 1 < nbits)) ? nl.gate(gOp, a[i], b[i]) : null);
   let single = Array(nbits).fill(true);
   for (let k = 0; (1 << k) < nbits; k++) {
     const newG = G.slice(), newP = P.slice(), newS = single.slice();
     for (let i = 0; i < nbits; i++) {
       if (!((i >> k) & 1)) continue;
       const j = ((i >> k) << k) - 1;
-      newG[i] = nl.gate(OP.MUX, P[i], G[j], single[i] ? (sub ? b + i : a + i) : G[i]);
+      newG[i] = nl.gate(OP.MUX, P[i], G[j], single[i] ? (sub ? b[i] : a[i]) : G[i]);
       newP[i] = i < (1 << (k + 1)) ? null : nl.gate(OP.AND, P[i], P[j]);
       newS[i] = false;
     }
     G = newG; P = newP; single = newS;
   }
   for (let i = 1; i < nbits; i++) out.push(nl.gate(oOp, pbit[i], G[i - 1]));
-  return { nl, a, b, out, top: G[nbits - 1] };
+  return { out, top: G[nbits - 1] };
+};
+const prefixNetwork = (nbits, sub) => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), idx = [...Array(nbits).keys()];
+  const { out, top } = prefixCells(nl, idx.map(i => a + i), idx.map(i => b + i), sub);
+  return { nl, a, b, out, top };
 };
 Tfhe.prefixAdderNetlist = nbits => { const { nl, a, b, out, top } = prefixNetwork(nbits, false); return { nl, a, b, sum: [...out, top] }; };
 Tfhe.prefixSubtractorNetlist = nbits => { const { nl, a, b, out, top } = prefixNetwork(nbits, true); return { nl, a, b, diff: out, borrow: top }; };
@@ -213,12 +220,58 @@ const cheapest = (builders, nbits, instances) => {
 };
 Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
 Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
+Tfhe.multiplierNetlistFor = (nbits, instances) => cheapest([Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist], nbits, instances);
 Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.subtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances);
 // min / max on the comparator picked for this many instances: one MUX per output bit behind it
 Tfhe.minMaxNetlistFor = (nbits, instances) => {
   const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances), min = [], max = [];
   for (let i = 0; i < nbits; i++) { min.push(nl.gate(OP.MUX, lt, a + i, b + i)); max.push(nl.gate(OP.MUX, lt, b + i, a + i)); }
   return { nl, a, b, lt, min, max };
+};
+// a * b in logarithmic depth: partial products in columns by weight, column compression by full adders (sum = (x ^ y) ^ z,
+// carry = MUX(x ^ y, z, x); the latest arriving wire of a triple is its z) until no column holds more than two wires, then
+// ONE parallel-prefix addition of the two remaining rows; 8 bits: 16 levels against the row-by-row form's 40
+Tfhe.wallaceMultiplierNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  if (nbits === 1) return { nl, a, b, prod: [nl.gate(OP.AND, a, b), nl.gate(OP.CONST0, -1)] };
+  const ncol = 2 * nbits, byLevel = (p, q) => p[0] - q[0] || p[1] - q[1];
+  let cols = [...Array(ncol)].map(() => []);
+  for (let r = 0; r < nbits; r++) for (let j = 0; j < nbits; j++) cols[r + j].push([1, nl.gate(OP.AND, a + j, b + r)]);
+  while (Math.max(...cols.map(c => c.length)) > 2) {
+    const next = [...Array(ncol)].map(() => []);
+    cols.forEach((raw, c) => {
+      const col = raw.slice().sort(byLevel);
+      let i = 0;
+      for (; col.length - i >= 3; i += 3) {
+        const [x, y, z] = [col[i], col[i + 1], col[i + 2]];
+        const p = nl.gate(OP.XOR, x[1], y[1]), lv = Math.max(Math.max(x[0], y[0]) + 1, z[0]) + 1;
+        next[c].push([lv, nl.gate(OP.XOR, p, z[1])]);
+        next[c + 1].push([lv, nl.gate(OP.MUX, p, z[1], x[1])]);
+      }
+      next[c].push(...col.slice(i));
+    });
+    cols = next;
+  }
+  const prod = [];
+  let c0 = 0;
+  for (; c0 < ncol && cols[c0].length <= 1; c0++) prod.push(cols[c0].length ? cols[c0][0][1] : null);   // already final
+  let hi = ncol - 1;
+  while (hi >= c0 && cols[hi].length === 0) hi--;
+  if (hi >= c0) {
+    let zero = null;
+    const xs = [], ys = [];
+    for (let c = c0; c <= hi; c++) {
+      const col = cols[c].slice().sort(byLevel);
+      xs.push(col[0][1]);
+      if (col.length > 1) ys.push(col[1][1]);
+      else { if (zero === null) zero = nl.gate(OP.CONST0, -1); ys.push(zero); }
+    }
+    const { out, top } = prefixCells(nl, xs, ys, false);
+    prod.push(...out, top);
+  }
+  prod.length = ncol;
+  for (let k = 0; k < ncol; k++) if (prod[k] === null || prod[k] === undefined) prod[k] = nl.gate(OP.CONST0, -1);
+  return { nl, a, b, prod };
 };
 // run a netlist over `instances` instances: inputs = {firstWire: Buffer [k][instances][n+1]}; returns the wire Buffer
 Tfhe.runNetlist = (nl, inputs, instances, outputs) => {
@@ -268,8 +321,8 @@ Tfhe.subtractBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [nbits + 1]
   return wires && Buffer.concat([...diff, borrow].map(wi => planes(wires, wi, 1, instances)));
 };
 Tfhe.multiplyBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [2 nbits][instances][n+1]
-  const { nl, a, b, prod } = Tfhe.multiplierNetlist(nbits);
-  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  const { nl, a, b, prod } = Tfhe.multiplierNetlistFor(nbits, instances);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, prod);   // through netlistOptimize (carry rewrite, constants)
   return wires && Buffer.concat(prod.map(wi => planes(wires, wi, 1, instances)));
 };
 Tfhe.minMaxBitsBatch = (Abuf, Bbuf, nbits, instances) => {     // -> { min, max: [nbits][instances][n+1], lt: [instances][n+1] }

@@ -292,6 +292,29 @@ def test_prefix_subtractor_all_inputs(nbits):
     assert c.pick_form(c.SUBTRACTOR_FORMS, 8, 8)[0] == "prefix" and c.pick_form(c.SUBTRACTOR_FORMS, 8, 4096)[0] == "ripple"
 
 
+@pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5])
+def test_wallace_multiplier_all_inputs(nbits):
+    A, B, S = _words(nbits)
+    for build in (c.wallace_multiplier, c.MULTIPLIER_FORMS["wallace"], c.MULTIPLIER_FORMS["rows"]):
+        gates, nw, a, b, p = build(nbits)
+        c._check_ssa(gates)
+        w = np.zeros((nw, S), np.uint8)
+        _load(w, a, A)
+        _load(w, b, B)
+        assert np.array_equal(_value(c.evaluate_plain(gates, w), p), A * B)
+    g8 = c.MULTIPLIER_FORMS["wallace"](8)[0]
+    r8 = c.MULTIPLIER_FORMS["rows"](8)[0]
+    assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (315, 16) and (circuit_bootstraps(r8), c.bootstrap_depth(r8)) == (272, 27)
+    assert c.pick_form(c.MULTIPLIER_FORMS, 8, 8)[0] == "wallace" and c.pick_form(c.MULTIPLIER_FORMS, 8, 4096)[0] == "rows"
+    rng = np.random.default_rng(nbits)
+    A, B = rng.integers(0, 256, 1500), rng.integers(0, 256, 1500)
+    gates, nw, a, b, p = c.multiplier_for(8, 4)
+    w = np.zeros((nw, 1500), np.uint8)
+    _load(w, a, A)
+    _load(w, b, B)
+    assert np.array_equal(_value(c.evaluate_plain(gates, w), p), A * B)
+
+
 def test_adder_forms_eight_bits_counts():
     ripple, mux, prefix = (f(8)[0] for f in (c.ADDER_FORMS["ripple"], c.mux_carry_adder, c.prefix_adder))
     assert (circuit_bootstraps(ripple), c.bootstrap_depth(ripple)) == (37, 15)

@@ -179,6 +179,8 @@ def test_string_api_and_host_batch_api(eoc):
         word = lambda w: sum(eoc.global_decrypt_bits(w[i]).astype(np.int64) << i for i in range(w.shape[0]))
         diff = T.subtractBitsBatch(planes(Av[:9]), planes(Bv[:9]))                                   # 9 instances: prefix form
         assert np.array_equal(word(diff[:8]), (Av[:9] - Bv[:9]) % 256) and np.array_equal(word(diff[8:]), (Av[:9] < Bv[:9]))
+        pl4 = lambda vals: np.stack([eoc.global_encrypt_bits(((vals >> i) & 1).astype(np.uint8)) for i in range(4)])
+        assert np.array_equal(word(T.multiplyBitsBatch(pl4(Av[:5] & 15), pl4(Bv[:5] & 15))), (Av[:5] & 15) * (Bv[:5] & 15))
         mn, mx = T.minMaxBitsBatch(planes(Av[:9]), planes(Bv[:9]))
         assert np.array_equal(word(mn), np.minimum(Av[:9], Bv[:9])) and np.array_equal(word(mx), np.maximum(Av[:9], Bv[:9]))
     finally:
@@ -460,7 +462,9 @@ def test_subtractor_and_multiplier_bit_exact(eoc):
     rng = np.random.default_rng(12)
     for build, nbits, expect in ((circuits.subtractor, 5, lambda a, b: (a - b) % 32), (circuits.multiplier, 3, lambda a, b: a * b),
                                  (circuits.prefix_subtractor, 5, lambda a, b: (a - b) % 32),        # round 6: log-depth form
-                                 (circuits.prefix_subtractor, 8, lambda a, b: (a - b) % 256)):
+                                 (circuits.prefix_subtractor, 8, lambda a, b: (a - b) % 256),
+                                 (circuits.wallace_multiplier, 4, lambda a, b: a * b),             # column compression + prefix addition
+                                 (lambda n: circuits.multiplier_for(n, S), 4, lambda a, b: a * b)): # ... after eoc_netlist_optimize
         res = build(nbits)
         gates, n_wires, aw, bw, outw = res[0], res[1], res[2], res[3], res[4]
         A, B = rng.integers(0, 1 << nbits, S), rng.integers(0, 1 << nbits, S)
@@ -472,6 +476,8 @@ def test_subtractor_and_multiplier_bit_exact(eoc):
         want = _oracle_run(orc, gates, wires)
         for g in gates:
             assert np.array_equal(got[g.out], want[g.out]), (build.__name__, g.out)
+        if build.__name__ == "<lambda>":
+            assert eoc.circuit_bootstraps(gates) == 65 and eoc.netlist_levels(gates)[2] == 10      # the Wallace form, optimized
         val = sum(sk.decrypt_bits(got[w]).astype(np.int64) << i for i, w in enumerate(outw))
         assert np.array_equal(val, expect(A, B)), build.__name__
         if "subtractor" in build.__name__:

@@ -121,8 +121,15 @@ class PlainBackend:
             g = [Gate(*map(int, row)) for row in np.frombuffer(gates, "<i4").reshape(-1, 5)]
             self.calls.append(("netlistCost", len(g), instances))
             return circuits.netlist_cost(g, instances, 1024)
+        def netlist_optimize(gates, outputs):
+            """the binding's l_netlistOptimize on the Python twin of eoc_netlist_optimize"""
+            from eoc_tfhe_amd import Gate, circuits
+            g = [Gate(*map(int, row)) for row in np.frombuffer(gates, "<i4").reshape(-1, 5)]
+            outs = [int(v) for v in np.frombuffer(outputs, "<i4")]
+            self.calls.append(("netlistOptimize", len(g), len(outs)))
+            return b"".join(struct.pack("<5i", x.op, x.in0, x.in1, x.in2, x.out) for x in circuits.optimize(g, outs))
         return ml.table_from({"sampleInts": lambda: ROW, "circuitRun": circuit_run, "encryptBits": encrypt_bits,
-                              "netlistCost": netlist_cost,
+                              "netlistCost": netlist_cost, "netlistOptimize": netlist_optimize,
                               "gateNAND": lambda a, b, pk=None: b"NAND(" + a + b"," + b + b")",
                               "setDevices": lambda *d: len(d)})
 
@@ -158,7 +165,7 @@ def value_of(buf, instances):
 def test_facade_defines_its_functions_and_passes_through(facade):
     it, tf, be = facade
     for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
-                 "muxAdderNetlist", "prefixAdderNetlist", "prefixSubtractorNetlist", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
+                 "muxAdderNetlist", "prefixAdderNetlist", "prefixSubtractorNetlist", "wallaceMultiplierNetlist", "multiplierNetlistFor", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
                  "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
                  "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
         assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
@@ -214,6 +221,13 @@ def test_netlist_builders_on_plaintext(facade, nbits):
         assert np.array_equal(word(bits, ml.to_python(s)), A + B), lua_name
         pg = py(nbits)[0]
         assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 1 for g in pg)), lua_name
+    nl, a, b, prod = call(it, tf, "wallaceMultiplierNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(word(bits, ml.to_python(prod)), A * B)
+    pg = circuits.wallace_multiplier(nbits)[0]
+    assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 0 if g.op >= 11 else 1 for g in pg))
+    # ... gate for gate the Python builder's netlist (same wire numbering: the (level, wire) order of a column is part of it)
+    assert it.call(nl.get(b"packed"), [])[0] == b"".join(struct.pack("<5i", g.op, g.in0, g.in1, g.in2, g.out) for g in pg)
     nl, a, b, diff, br = call(it, tf, "prefixSubtractorNetlist", nbits)
     bits, (ngates, boots) = evaluate(nl, a, b)
     assert np.array_equal(word(bits, ml.to_python(diff)), (A - B) % (1 << nbits)) and np.array_equal(bits[br], (A < B).astype(np.int64))
@@ -260,6 +274,8 @@ def test_forms_are_picked_by_instance_count(facade):
     for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (30, 8), (22, 8))):
         assert shape(call(it, tf, "adderNetlistFor", 8, inst)[0]) == add_want, inst
         assert shape(call(it, tf, "lessThanNetlistFor", 8, inst)[0]) == lt_want, inst
+    assert shape(call(it, tf, "multiplierNetlistFor", 8, 2)[0]) == (328, 16)
+    assert shape(call(it, tf, "multiplierNetlistFor", 8, 4096)[0]) == (320, 40)
     assert shape(call(it, tf, "subtractorNetlistFor", 8, 2)[0]) == (48, 5)
     assert shape(call(it, tf, "subtractorNetlistFor", 8, 4096)[0]) == (30, 8)
     assert shape(call(it, tf, "minMaxNetlistFor", 8, 1)[0]) == (29 + 32, 5)
