@@ -2,7 +2,8 @@
 
 Round 3's only real bug -- a NULL-stream hipMemset racing launches on hipStreamNonBlocking streams when a fresh global
 context grew its workspace (7 wrong host-path results in 20 124 cases, profiles/r03_soak_parity.txt) -- was found by
-tools/soak_parity.py, which nothing ran automatically.  Here: a fixed-seed slice of that soak over all five kinds, and
+tools/soak_parity.py, which nothing ran automatically.  Here: a fixed-seed slice of that soak over all six kinds (round 6:
+netlists through eoc_netlist_optimize -- rewritten netlist vs oracle bit for bit, outputs vs the original's plaintext), and
 a targeted regression that hammers exactly the racing shape (fresh context, first call = host-buffer batch that grows
 the workspace).  Everything is compared bit for bit with the CPU oracle.
 """
@@ -28,10 +29,10 @@ def eoc(built_lib):
     return eoc_tfhe_amd
 
 
-def test_soak_slice_all_five_kinds(eoc):
+def test_soak_slice_all_six_kinds(eoc):
     import soak_parity
     lines = []
-    cases, bad, per_kind = soak_parity.soak(budget_s=25.0, seed=4, round_robin=True, log=lines.append)
+    cases, bad, per_kind = soak_parity.soak(budget_s=30.0, seed=4, round_robin=True, log=lines.append)
     assert bad == 0, [ln for ln in lines if "MISMATCH" in ln]
     assert set(per_kind) == set(soak_parity.KINDS) and min(per_kind.values()) >= 5, per_kind
     assert cases >= 40

@@ -6,7 +6,10 @@ oracle.
   soak(...) below                                   what tests/test_gpu_soak.py calls with a fixed seed: a bounded,
                                                     repeatable slice that visits all five kinds
 
-Kinds: uniform (one opcode, device pointers), mixed (opcode per row), circuit (random netlist with hazards), host
+Kinds: uniform (one opcode, device pointers), mixed (opcode per row), circuit (random netlist with hazards), optimized
+(round 6: a random SINGLE-ASSIGNMENT netlist with constants, NOT / COPY chains, MUXes and textbook full-adder carries sent
+through eoc_netlist_optimize; the rewritten netlist runs on the GPU and must equal the oracle's evaluation of that rewritten
+netlist bit for bit, and its outputs must DECRYPT to what the ORIGINAL netlist computes on the plaintext bits), host
 (a FRESH global context whose first call is a host-buffer batch: the path that grows the workspace -- where round 3's
 NULL-stream memset race lived), async (fresh context, three submissions two deep on pinned buffers)."""
 import os
@@ -19,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-KINDS = ("uniform", "mixed", "circuit", "host", "async")
+KINDS = ("uniform", "mixed", "circuit", "optimized", "host", "async")
 
 
 def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_context=4, round_robin=False, log=print):
@@ -76,6 +79,50 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
                 torch.cuda.synchronize()
                 got = d.cpu().numpy()
                 desc = f"circuit gates={n_gates} S={S}"
+            elif kind == "optimized":
+                from eoc_tfhe_amd import circuits
+                S = int(rng.choice([1, 5, 33, 130]))
+                n_in, n_gates = 5, int(rng.integers(6, 40))
+                gates, avail = [], list(range(n_in))
+                pick = lambda: int(avail[int(rng.integers(0, len(avail)))])
+                while len(gates) < n_gates:
+                    out = n_in + len(gates)
+                    r = int(rng.integers(0, 20))
+                    if r == 0 and n_gates - len(gates) >= 4:       # a textbook full-adder carry: the rewrite's pattern
+                        x, y, z = pick(), pick(), pick()
+                        gates += [eoc.Gate(eoc.OPS["XOR"], x, y, -1, out), eoc.Gate(eoc.OPS["AND"], x, y, -1, out + 1),
+                                  eoc.Gate(eoc.OPS["AND"], out, z, -1, out + 2), eoc.Gate(eoc.OPS["OR"], out + 1, out + 2, -1, out + 3)]
+                        avail += [out, out + 3]
+                        continue
+                    op = int(rng.choice(BOOT + FREE + [eoc.OPS["NOT"], eoc.OPS["MUX"]]))
+                    ni = (0 if op in (eoc.OPS["CONST0"], eoc.OPS["CONST1"]) else 1 if op in (eoc.OPS["NOT"], eoc.OPS["COPY"])
+                          else 3 if op == eoc.OPS["MUX"] else 2)
+                    gates.append(eoc.Gate(op, pick() if ni >= 1 else -1, pick() if ni >= 2 else -1, pick() if ni >= 3 else -1, out))
+                    avail.append(out)
+                n_wires = n_in + len(gates)
+                outs = [int(v) for v in rng.choice(avail[n_in:], size=min(4, len(avail) - n_in), replace=False)]
+                opt = eoc.netlist_optimize(gates, outs)
+                bits = rng.integers(0, 2, (n_in, S)).astype(np.uint8)
+                wires = np.zeros((n_wires, S, n + 1), np.int32)
+                for w_ in range(n_in):
+                    wires[w_] = sk.encrypt_bits(bits[w_], int(rng.integers(1, 1 << 30)), 0)
+                want = wires.copy()
+                for g in opt:
+                    i0 = want[g.in0] if g.in0 >= 0 else np.zeros_like(want[g.out])
+                    want[g.out] = orc.gate_batch(g.op, i0, None if g.in1 < 0 else want[g.in1], None if g.in2 < 0 else want[g.in2])
+                d = torch.from_numpy(wires).to(dev)
+                if opt:
+                    eng.circuit_run_device(opt, d.data_ptr(), n_wires, S)
+                torch.cuda.synchronize()
+                got = d.cpu().numpy()
+                plain = np.zeros((n_wires, S), np.uint8)
+                plain[:n_in] = bits
+                plain = circuits.evaluate_plain(gates, plain)
+                for o in outs:                                      # the rewritten netlist computes what the original does
+                    if not np.array_equal(sk.decrypt_bits(got[o]), plain[o]):
+                        got = got.copy()
+                        got[o, 0, 0] ^= 1                           # reported as a mismatch below
+                desc = f"optimized gates={len(gates)}->{len(opt)} boots={eoc.circuit_bootstraps(gates)}->{eoc.circuit_bootstraps(opt)} S={S}"
             else:
                 ops = None
                 op = int(rng.choice(BOOT))
