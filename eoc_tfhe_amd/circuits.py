@@ -750,3 +750,39 @@ def netlist_cost(gates, instances, resident_jobs=1024):
         if rem:
             cost += 14 + (16 * max(rem, R // 4) + R - 1) // R
     return cost
+
+
+def noise_margin(gates, n_inputs_var, v_br, v_ks, v_modswitch):
+    """Smallest decision margin, in standard deviations, over every blind rotation of a netlist -- the noise budget a
+    rewrite must not exhaust.  Variances in torus units: fresh inputs carry n_inputs_var (sigma_ks^2); a two-input gate's
+    output V_BR + V_KS, a MUX's 2 V_BR + V_KS (two rotations summed before ONE key switch), NOT / COPY pass their input's
+    on, constants have none.  The phase a blind rotation sees: AND / OR family  +-1/8 + a + b  (margin 1/8 to the nearest
+    decision boundary, variance V_a + V_b), XOR / XNOR  +-1/4 + 2 (a + b)  (margin 1/4, variance 4 (V_a + V_b)), MUX two
+    AND-type rotations (selector + one branch each); every rotation adds the mod-switch rounding v_modswitch =
+    (1 + |s|) / (48 N^2).  Returns (min margin in sigmas, index of the gate that has it)."""
+    var = {}
+    worst, where = float("inf"), -1
+    for k, g in enumerate(gates):
+        name = _NAMES[g.op]
+        v = lambda w: var.get(w, n_inputs_var)
+        if name in ("CONST0", "CONST1"):
+            var[g.out] = 0.0
+            continue
+        if name in ("NOT", "COPY"):
+            var[g.out] = v(g.in0)
+            continue
+        if name == "MUX":
+            rot = [(0.125, v(g.in0) + v(g.in1)), (0.125, v(g.in0) + v(g.in2))]
+            var[g.out] = 2 * v_br + v_ks
+        elif name in ("XOR", "XNOR"):
+            rot = [(0.25, 4 * (v(g.in0) + v(g.in1)))]
+            var[g.out] = v_br + v_ks
+        else:
+            rot = [(0.125, v(g.in0) + v(g.in1))]
+            var[g.out] = v_br + v_ks
+        for margin, vin in rot:
+            s = margin / (vin + v_modswitch) ** 0.5
+            if s < worst:
+                worst, where = s, k
+    return worst, where
+

@@ -92,3 +92,38 @@ def test_prediction_terms_setA_by_hand():
     assert 4.5e-6 < p["br_var_truncation_bias"] < 5.5e-6
     assert p["br_mean"] == pytest.approx(-(2.0**-21) * 511, rel=1e-12)        # 1 + |s'| - 2 s'_0, s'_0 = 1
     assert p["ks_var_textbook"] == pytest.approx(1024 * 8 * 0.75 * 2.44e-5**2 + 512 * 2.0**-34 / 3, rel=1e-12)
+
+
+def test_every_circuit_form_stays_inside_the_noise_budget():
+    """round 6: the netlist compiler chains MUX outputs (2 V_BR + V_KS) into selectors and XORs more than the textbook
+    forms do.  With the per-key predicted V_BR / V_KS of both default sets every blind rotation of every shipped form --
+    as written and after eoc_netlist_optimize -- keeps at least 12 standard deviations to its decision boundary (failure
+    probability below 1e-32 per gate); the worst input in the library is an XOR of two MUX outputs (~15 sigma on Set A)"""
+    from eoc_tfhe_amd import circuits as c
+    for pset in (0, 1):
+        o = ol.Oracle(pset, 1)
+        pred = noise.predict(o.p, o.lwe_key, o.tlwe_key, o.ksk)
+        v_ms = (1 + int(np.asarray(o.lwe_key).sum())) / (48.0 * N * N)
+        fresh = float(o.p.ks_stdev) ** 2
+        forms = [c.ripple_carry_adder(8, carry_in_zero=True), c.mux_carry_adder(8), c.prefix_adder(8), c.prefix_adder(16),
+                 c.subtractor(8), c.prefix_subtractor(8), c.less_than(8), c.less_than_tree(8), c.min_max_for(8, 1),
+                 c.multiplier(4), c.wallace_multiplier(8), c.string_equal(4)]
+        worst = []
+        for built in forms:
+            gates = built[0]
+            outs = built[-1] if isinstance(built[-1], list) else [built[-1]]
+            for nl in (gates, c.optimize(gates, outs)):
+                m, k = c.noise_margin(nl, fresh, pred["br_var"], pred["ks_var"], v_ms)
+                worst.append(m)
+                assert m > 12.0, (pset, len(nl), m, k)
+        # the single worst case by construction: XOR of two MUX outputs
+        g = [Gate_(10, 0, 1, 2, 6), Gate_(10, 3, 4, 5, 7), Gate_(4, 6, 7, -1, 8)]
+        m, k = c.noise_margin(g, fresh, pred["br_var"], pred["ks_var"], v_ms)
+        assert k == 2 and 12.0 < m <= min(worst) + 1e-9, (m, min(worst))
+        print(f"set {'AB'[pset]}: smallest margin over the shipped forms {min(worst):.1f} sigma, XOR of two MUX outputs {m:.1f} sigma")
+
+
+def Gate_(op, i0, i1, i2, out):
+    from eoc_tfhe_amd import Gate
+    return Gate(op, i0, i1, i2, out)
+
