@@ -1007,54 +1007,75 @@ inline bool same_netlist(const Netlist &a, const Netlist &b)
     return true;
 }
 
-// argument checks shared by the netlist entry points; n_wires = 1 + the largest wire id
+// argument checks shared by the netlist entry points; n_wires = 1 + the largest wire id.  Input slots an opcode does not
+// use are ignored whatever they hold (only USED slots must name a wire); wire ids are bounded (the entry points size host
+// vectors by them: an id of 2^31 - 1 in a hostile netlist must be an error, not a 16 GB allocation)
+constexpr int32_t kMaxWireId = (1 << 24) - 1;
 int check_netlist(const eoc_gate *gates, size_t n_gates, size_t &n_wires)
 {
     if (!gates && n_gates) return EOC_ERR_ARG;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &g = gates[k];
-        const bool is_const = g.op == EOC_CONST0 || g.op == EOC_CONST1;
-        if (g.op < EOC_NAND || g.op > EOC_CONST1 || g.out < 0 || (g.in0 < 0 && !is_const)) return EOC_ERR_ARG;
-        if (g.op <= EOC_MUX && g.in1 < 0) return EOC_ERR_ARG;
-        if (g.op == EOC_MUX && g.in2 < 0) return EOC_ERR_ARG;
-        for (int32_t i : {g.in0, g.in1, g.in2, g.out}) n_wires = std::max(n_wires, (size_t)(i + 1));
+        if (g.op < EOC_NAND || g.op > EOC_CONST1 || g.out < 0 || g.out > kMaxWireId) return EOC_ERR_ARG;
+        const int nin = nl_inputs(g.op);
+        const int32_t ins[3] = {g.in0, g.in1, g.in2};
+        for (int a = 0; a < nin; a++) {
+            if (ins[a] < 0 || ins[a] > kMaxWireId) return EOC_ERR_ARG;
+            n_wires = std::max(n_wires, (size_t)ins[a] + 1);
+        }
+        n_wires = std::max(n_wires, (size_t)g.out + 1);
     }
     return EOC_OK;
 }
 } // namespace
 
+// nothing is thrown across the ABI (the reference is built -fno-exceptions, ao-tfhe/build.sh:23): an allocation failure inside
+// the netlist entry points becomes EOC_ERR_ALLOC
+static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
+                                     eoc_gate *gates_out);
 extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs,
                                         size_t n_outputs, eoc_gate *gates_out)
+{
+    try {
+        return netlist_optimize_impl(gates, n_gates, outputs, n_outputs, gates_out);
+    } catch (...) {
+        return EOC_ERR_ALLOC;
+    }
+}
+static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
+                                     eoc_gate *gates_out)
 {
     if ((!outputs && n_outputs) || (!gates_out && n_gates)) return EOC_ERR_ARG;
     size_t n_wires = 0;
     if (check_netlist(gates, n_gates, n_wires)) return EOC_ERR_ARG;
     for (size_t k = 0; k < n_outputs; k++) {
-        if (outputs[k] < 0) return EOC_ERR_ARG;
+        if (outputs[k] < 0 || outputs[k] > kMaxWireId) return EOC_ERR_ARG;
         n_wires = std::max(n_wires, (size_t)outputs[k] + 1);
     }
-    // single assignment: every wire written at most once, never read before its write, no gate reads its own output
-    std::vector<int64_t> src(n_wires, -1);
-    for (size_t k = 0; k < n_gates; k++) {
-        const eoc_gate &g = gates[k];
-        if (src[g.out] >= 0) return EOC_ERR_ARG;
-        for (int k2 = 0; k2 < nl_inputs(g.op); k2++)
-            if ((k2 == 0 ? g.in0 : k2 == 1 ? g.in1 : g.in2) == g.out) return EOC_ERR_ARG;
-        src[g.out] = (int64_t)k;
-    }
-    for (size_t k = 0; k < n_gates; k++)
-        for (int32_t i : {gates[k].in0, gates[k].in1, gates[k].in2})
-            if (i >= 0 && src[i] >= (int64_t)k) return EOC_ERR_ARG;
-    std::vector<char> keep(n_wires, 0);
-    for (size_t k = 0; k < n_outputs; k++) keep[outputs[k]] = 1;
-
+    // unused input slots are normalised to -1 first (the caller may leave anything in them; the passes compare gates field by
+    // field and index vectors by every slot that is not -1)
     Netlist cur;
     cur.reserve(n_gates);
-    for (size_t k = 0; k < n_gates; k++) { // unused input slots are normalised to -1 (the passes compare gates field by field)
+    for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &g = gates[k];
         const int nin = nl_inputs(g.op);
         cur.push_back(mk(g.op, nin > 0 ? g.in0 : -1, nin > 1 ? g.in1 : -1, nin > 2 ? g.in2 : -1, g.out));
     }
+    // single assignment: every wire written at most once, never read before its write, no gate reads its own output
+    std::vector<int64_t> src(n_wires, -1);
+    for (size_t k = 0; k < n_gates; k++) {
+        const eoc_gate &g = cur[k];
+        if (src[g.out] >= 0) return EOC_ERR_ARG;
+        for (int32_t i : {g.in0, g.in1, g.in2})
+            if (i == g.out) return EOC_ERR_ARG;
+        src[g.out] = (int64_t)k;
+    }
+    for (size_t k = 0; k < n_gates; k++)
+        for (int32_t i : {cur[k].in0, cur[k].in1, cur[k].in2})
+            if (i >= 0 && src[i] >= (int64_t)k) return EOC_ERR_ARG;
+    std::vector<char> keep(n_wires, 0);
+    for (size_t k = 0; k < n_outputs; k++) keep[outputs[k]] = 1;
+
     for (int round = 0; round < 8; round++) {
         Netlist nxt = pass_fuse_carry(
             pass_fuse_mux(pass_fold_nots(pass_fold_constants(cur, keep, n_wires), keep, n_wires), keep, n_wires), keep, n_wires);
@@ -1088,7 +1109,7 @@ int eoc_levelise(const eoc_gate *gates, size_t n_gates, size_t n_wires, int *lev
 }
 
 extern "C" int64_t eoc_netlist_levels(const eoc_gate *gates, size_t n_gates, int32_t *level_of, int64_t *bootstrap_levels)
-{
+try {
     size_t n_wires = 0;
     if (check_netlist(gates, n_gates, n_wires)) return EOC_ERR_ARG;
     std::vector<int> lev(n_gates, 0);
@@ -1102,10 +1123,12 @@ extern "C" int64_t eoc_netlist_levels(const eoc_gate *gates, size_t n_gates, int
         *bootstrap_levels = std::count(has.begin(), has.end(), (char)1);
     }
     return nlev;
+} catch (...) {
+    return EOC_ERR_ALLOC;
 }
 
 extern "C" int64_t eoc_netlist_cost(const eoc_gate *gates, size_t n_gates, size_t instances, size_t resident_jobs)
-{
+try {
     size_t n_wires = 0;
     if (check_netlist(gates, n_gates, n_wires)) return EOC_ERR_ARG;
     const uint64_t R = std::max<uint64_t>(4, resident_jobs ? resident_jobs : 1024);
@@ -1120,4 +1143,6 @@ extern "C" int64_t eoc_netlist_cost(const eoc_gate *gates, size_t n_gates, size_
         if (rem) cost += 14 + (16 * std::max(rem, R / 4) + R - 1) / R;
     }
     return (int64_t)cost;
+} catch (...) {
+    return EOC_ERR_ALLOC;
 }

@@ -233,7 +233,8 @@ size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
  *   MUX fusion  OR(AND(s, b), ANDNY(s, c)) with single-use inner wires -> MUX(s, b, c)
  *   carry       OR(AND(a, b), AND(XOR(a, b), c)) with single-use AND wires -> MUX(XOR(a, b), c, a): the textbook full adder's
  *               carry as ONE gate on ONE level (the literal 8-bit ripple-carry adder: 40 bootstraps / 17 levels -> 30 / 8)
- * and gates nobody reads are dropped.  `outputs` are the wires the caller reads afterwards.  Single-assignment netlists
+ * and gates nobody reads are dropped.  `outputs` are the wires the caller reads afterwards.  Input slots an opcode does not
+ * use are ignored whatever they hold (and come back as -1); wire ids must be below 2^24.  Single-assignment netlists
  * only (every wire written at most once, after its readers' inputs): otherwise EOC_ERR_ARG.  gates_out has room for n_gates
  * entries; returns the number of gates written.  Same wire numbering, never more bootstraps, never more levels. */
 int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,

@@ -51,6 +51,12 @@ int main(int argc, char **argv)
         CHECK(lev[0] == 1 && lev[1] == 1 && lev[2] == 2 && lev[3] == 3);
         CHECK(eoc_netlist_cost(nl, 4, 3, 0) == 54 && eoc_netlist_cost(nl, 4, 1024, 1024) == 90);
         CHECK(eoc_netlist_levels(bad, 2, NULL, NULL) == 2);                     /* running needs no single assignment */
+        /* slots an opcode does not use may hold anything (here: far out of range, negative): ignored, never indexed */
+        const eoc_gate sloppy[4] = {{EOC_NOT, 0, 31000, -7, 3}, {EOC_AND, 0, 1, 99999, 4}, {EOC_AND, 3, 2, -5, 5}, {EOC_OR, 4, 5, 77, 6}};
+        CHECK(eoc_netlist_optimize(sloppy, 4, outs, 1, opt) == 1 && opt[0].op == EOC_MUX && opt[0].in2 == 2);
+        CHECK(eoc_netlist_levels(sloppy, 4, lev, &depth) == 3 && eoc_netlist_cost(sloppy, 4, 3, 0) == 54);
+        const eoc_gate huge[1] = {{EOC_AND, 0, 1, -1, 2147483647}};
+        CHECK(eoc_netlist_optimize(huge, 1, outs, 1, opt) == EOC_ERR_ARG && eoc_netlist_levels(huge, 1, NULL, NULL) == EOC_ERR_ARG);
         const eoc_gate junk[1] = {{99, 0, 1, -1, 2}};
         CHECK(eoc_netlist_levels(junk, 1, NULL, NULL) == EOC_ERR_ARG && eoc_netlist_cost(junk, 1, 1, 0) == EOC_ERR_ARG);
     }

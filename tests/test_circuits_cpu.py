@@ -443,3 +443,42 @@ def test_form_is_picked_by_instance_count():
     g = c.prefix_adder(8)[0]
     assert c.netlist_cost(g, 1) == c.netlist_cost(g, 8) == 18 * 5
     assert c.netlist_cost(c.mux_carry_adder(8)[0], 4096) == 30 * 30 * 4
+
+
+def test_netlist_entry_points_survive_malformed_input(built_lib):
+    """round 6: a fuzz run found that a negative value in an input slot the opcode does not use (or a huge wire id) made
+    eoc_netlist_optimize size a vector by it and throw across the C ABI.  Unused slots are now ignored whatever they hold,
+    wire ids are bounded (2^24), nothing is thrown: 20 000 random gate arrays -- opcodes -2 ... 17, wires -3 ... 39, now
+    and then 2^31 - 1 -- return an error code or a valid result, and the three entry points agree on which"""
+    import ctypes as C
+    import eoc_tfhe_amd as eoc
+    L = eoc.lib()
+    rng = np.random.default_rng(1)
+    ok = err = 0
+    for trial in range(20000):
+        n = int(rng.integers(0, 30))
+        arr = (Gate * max(1, n))()
+        for k in range(n):
+            arr[k].op, arr[k].out = int(rng.integers(-2, 18)), int(rng.integers(-2, 40))
+            arr[k].in0, arr[k].in1, arr[k].in2 = (int(x) for x in rng.integers(-3, 40, 3))
+        if n and trial % 97 == 0:
+            arr[0].out = 2**31 - 1
+        outs = (C.c_int32 * 4)(*[int(x) for x in rng.integers(-1, 45, 4)])
+        out = (Gate * max(1, n))()
+        r = L.eoc_netlist_optimize(C.addressof(arr), n, C.addressof(outs), int(rng.integers(0, 5)), C.addressof(out))
+        lev = (C.c_int32 * max(1, n))()
+        depth = C.c_int64(0)
+        r2 = L.eoc_netlist_levels(C.addressof(arr), n, C.addressof(lev), C.addressof(depth))
+        r3 = L.eoc_netlist_cost(C.addressof(arr), n, int(rng.integers(0, 5000)), int(rng.integers(0, 3000)))
+        assert (r2 < 0) == (r3 < 0) and r <= n
+        if r2 < 0:
+            assert r < 0                                     # what cannot be levelised cannot be rewritten either
+        ok, err = ok + (r >= 0), err + (r < 0)
+    assert ok > 500 and err > 500
+    # garbage in the slots an opcode does not use is ignored: same result as with -1 there
+    a = [Gate(OPS["NOT"], 0, 31000, -7, 2), Gate(OPS["AND"], 2, 1, 99, 3), Gate(OPS["CONST1"], 5, 6, 7, 4), Gate(OPS["OR"], 3, 4, 123, 5)]
+    b = [Gate(OPS["NOT"], 0, -1, -1, 2), Gate(OPS["AND"], 2, 1, -1, 3), Gate(OPS["CONST1"], -1, -1, -1, 4), Gate(OPS["OR"], 3, 4, -1, 5)]
+    as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
+    assert as_t(eoc.netlist_optimize(a, [5])) == as_t(eoc.netlist_optimize(b, [5])) == as_t(c.optimize(b, [5]))
+    assert eoc.netlist_levels(a) == eoc.netlist_levels(b) and eoc.netlist_cost(a, 9) == eoc.netlist_cost(b, 9)
+
