@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("EOC_TFHE_LIB") or os.path.join(_HERE, "libeoc_tfhe_gp
 N = 1024
 
 OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9,
-           MUX=10, NOT=11, COPY=12, CONST0=13, CONST1=14)
+           MUX=10, NOT=11, COPY=12, CONST0=13, CONST1=14,
+           MAJ=15, XOR3=16)   # extension gates: majority / three-input parity, one bootstrap each (include/eoc_tfhe_gpu.h)
 
 
 class EocError(RuntimeError):
@@ -124,6 +125,7 @@ def lib():
         "eoc_circuit_run_device": (C.c_int, [vp, vp, sz, vp, sz, sz, vp]),
         "eoc_circuit_bootstraps": (sz, [vp, sz]),
         "eoc_netlist_optimize": (C.c_int64, [vp, sz, vp, sz, vp]),
+        "eoc_netlist_optimize_ex": (C.c_int64, [vp, sz, vp, sz, vp, C.c_uint]),
         "eoc_netlist_levels": (C.c_int64, [vp, sz, vp, vp]),
         "eoc_netlist_cost": (C.c_int64, [vp, sz, sz, sz]),
         "eoc_dbg_fft_fwd_device": (C.c_int, [vp, vp, vp, sz, vp]),
@@ -177,6 +179,8 @@ def lib():
         "gateXNOR": (vp, [C.c_char_p, C.c_char_p, C.c_char_p]),
         "gateNOT": (vp, [C.c_char_p, C.c_char_p]),
         "gateMUX": (vp, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateMAJ": (vp, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "gateXOR3": (vp, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
         # f1: the reference's 11 calls
         "generateSecretKey": (vp, [C.c_char_p, C.c_char_p]),
         "generatePublicKey": (vp, []),
@@ -499,13 +503,15 @@ def circuit_bootstraps(gates):
     return lib().eoc_circuit_bootstraps(C.addressof(arr), len(gates))
 
 
-def netlist_optimize(gates, outputs):
-    """eoc_netlist_optimize: constant / NOT / COPY folding, MUX and carry fusion, dead-gate removal in the native library
-    (the same rewriting as circuits.optimize).  Raises EocError for netlists that are not single-assignment."""
+def netlist_optimize(gates, outputs, extension_gates=True):
+    """eoc_netlist_optimize(_ex): constant / NOT / COPY folding, MUX and carry fusion, dead-gate removal in the native library
+    (the same rewriting as circuits.optimize).  extension_gates=False keeps the result inside libtfhe's boots* family (the
+    carry as MUX instead of MAJ, no XOR3).  Raises EocError for netlists that are not single-assignment."""
     arr = (Gate * max(1, len(gates)))(*gates)
     out = (Gate * max(1, len(gates)))()
     outs = (C.c_int32 * max(1, len(outputs)))(*outputs)
-    n = lib().eoc_netlist_optimize(C.addressof(arr), len(gates), C.addressof(outs), len(outputs), C.addressof(out))
+    n = lib().eoc_netlist_optimize_ex(C.addressof(arr), len(gates), C.addressof(outs), len(outputs), C.addressof(out),
+                                      0 if extension_gates else 1)
     if n < 0:
         raise EocError(f"eoc_netlist_optimize failed ({n}): not a single-assignment netlist?")
     return [Gate(out[k].op, out[k].in0, out[k].in1, out[k].in2, out[k].out) for k in range(n)]
@@ -864,6 +870,16 @@ class Tfhe:
     @staticmethod
     def mux(a, b, c, pk=""):
         return _take_str(lib().gateMUX(a.encode(), b.encode(), c.encode(), pk.encode()))
+
+    @staticmethod
+    def maj(a, b, c, pk=""):
+        """extension gate: the majority of three bits in ONE bootstrap (a full adder's carry)"""
+        return _take_str(lib().gateMAJ(a.encode(), b.encode(), c.encode(), pk.encode()))
+
+    @staticmethod
+    def xor3(a, b, c, pk=""):
+        """extension gate: the parity of three bits in ONE bootstrap (a full adder's sum)"""
+        return _take_str(lib().gateXOR3(a.encode(), b.encode(), c.encode(), pk.encode()))
 
     # ---- word-level circuits, one backend call each; the FORM is picked by the instance count (circuits.pick_form: ----
     # ---- fewest levels for a handful of instances, fewest bootstraps for thousands), like Tfhe.addBits in tfhe.js / .lua ----

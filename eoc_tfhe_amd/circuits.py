@@ -215,6 +215,71 @@ def mux_carry_adder(nbits=8):
     return gates, nxt, a, b, s
 
 
+def maj_adder(nbits=8):
+    """a + b with the EXTENSION gates (include/eoc_tfhe_gpu.h): a full adder is s_i = XOR3(a_i, b_i, c_i) and
+    c_{i+1} = MAJ(a_i, b_i, c_i) -- ONE bootstrap each, both on the level of c_i; bit 0 is a half adder (XOR, AND).
+    2 nbits bootstraps on nbits levels: 16 / 8 at 8 bits against the MUX-carry form's 30 / 8 and the textbook form's 37 / 15;
+    it is what optimize() makes of either.  Same wire layout as ripple_carry_adder.
+    Returns (gates, n_wires, a_wires, b_wires, sum_wires)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    s = list(range(2 * nbits, 3 * nbits + 1))
+    nxt = 3 * nbits + 1
+    gates = [Gate(OPS["XOR"], a[0], b[0], -1, s[0])]
+    carry = s[1] if nbits == 1 else nxt
+    if nbits > 1:
+        nxt += 1
+    gates.append(Gate(OPS["AND"], a[0], b[0], -1, carry))
+    for i in range(1, nbits):
+        gates.append(Gate(OPS["XOR3"], a[i], b[i], carry, s[i]))
+        newc = s[nbits] if i == nbits - 1 else nxt
+        if i != nbits - 1:
+            nxt += 1
+        gates.append(Gate(OPS["MAJ"], a[i], b[i], carry, newc))
+        carry = newc
+    return gates, nxt, a, b, s
+
+
+def maj_subtractor(nbits=8):
+    """a - b mod 2^nbits and the final borrow with the extension gates: d_i = XOR3(a_i, b_i, br_i),
+    br_{i+1} = MAJ(NOT a_i, b_i, br_i) (NOT is free); bit 0: d_0 = XOR, br_1 = ANDNY.  2 nbits bootstraps on nbits levels
+    (16 / 8 against subtractor's 30 / 8).  Same wire layout as subtractor.
+    Returns (gates, n_wires, a_wires, b_wires, diff_wires, borrow_wire)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    d = list(range(2 * nbits, 3 * nbits))
+    nxt = 3 * nbits
+    gates = [Gate(OPS["XOR"], a[0], b[0], -1, d[0]), Gate(OPS["ANDNY"], a[0], b[0], -1, nxt)]
+    br = nxt
+    nxt += 1
+    for i in range(1, nbits):
+        na, new = nxt, nxt + 1
+        nxt += 2
+        gates.append(Gate(OPS["NOT"], a[i], -1, -1, na))
+        gates.append(Gate(OPS["XOR3"], a[i], b[i], br, d[i]))
+        gates.append(Gate(OPS["MAJ"], na, b[i], br, new))
+        br = new
+    return gates, nxt, a, b, d, br
+
+
+def maj_less_than(nbits=8):
+    """unsigned a < b = the final borrow of a - b: lt_0 = ANDNY(a_0, b_0), lt_i = MAJ(NOT a_i, b_i, lt_{i-1}): ONE bootstrap
+    per bit (8 on 8 levels against less_than's 22 on 8).  Returns (gates, n_wires, a_wires, b_wires, out_wire)."""
+    a = list(range(nbits))
+    b = list(range(nbits, 2 * nbits))
+    nxt = 2 * nbits
+    gates = [Gate(OPS["ANDNY"], a[0], b[0], -1, nxt)]
+    lt = nxt
+    nxt += 1
+    for i in range(1, nbits):
+        na, new = nxt, nxt + 1
+        nxt += 2
+        gates.append(Gate(OPS["NOT"], a[i], -1, -1, na))
+        gates.append(Gate(OPS["MAJ"], na, b[i], lt, new))
+        lt = new
+    return gates, nxt, a, b, lt
+
+
 def _prefix_cells(emit, a, b, sub, outs=None, top=None):
     """Sklansky parallel-prefix network over (generate, propagate) pairs on the wire lists a, b (LSB first), shared by
     prefix_adder (sub = False: G = a AND b, P = a XOR b, out_i = P_i XOR carry_i), prefix_subtractor (sub = True:
@@ -296,11 +361,12 @@ def prefix_subtractor(nbits=8):
     return _prefix_network(nbits, True)
 
 
-def wallace_multiplier(nbits=4):
+def wallace_multiplier(nbits=4, extension_gates=True):
     """a * b -> 2 nbits product bits in logarithmic depth: nbits^2 AND partial products in columns by weight, column
-    compression by full adders (sum = (x XOR y) XOR z, carry = MUX(x XOR y, z, x): 4 bootstraps on 2 levels, the latest
-    arriving wire as z) until no column holds more than two wires, then ONE parallel-prefix addition of the two remaining
-    rows.  8 bits: 15 levels against the row-by-row multiplier's 40 (27 after eoc_netlist_optimize).
+    compression by full adders until no column holds more than two wires, then ONE parallel-prefix addition of the two
+    remaining rows.  A full adder is XOR3(x, y, z) + MAJ(x, y, z) -- 2 bootstraps on ONE level (extension gates, default)
+    -- or, inside libtfhe's gate family, (x XOR y) XOR z + MUX(x XOR y, z, x): 4 bootstraps on 2 levels, the latest
+    arriving wire as z.  8 bits: 11 levels (16 without the extension gates) against the row-by-row multiplier's 40.
     Returns (gates, n_wires, a_wires, b_wires, product_wires)."""
     a = list(range(nbits))
     b = list(range(nbits, 2 * nbits))
@@ -313,18 +379,38 @@ def wallace_multiplier(nbits=4):
     for r in range(nbits):
         for j in range(nbits):
             cols[r + j].append((1, emit("AND", a[j], b[r])))
-    while max(len(c) for c in cols) > 2:
+
+    def full_adder(x, y, z):                            # -> (level, sum wire), (level, carry wire)
+        (lx, wx), (ly, wy), (lz, wz) = x, y, z
+        if extension_gates:
+            lv = max(lx, ly, lz) + 1
+            return (lv, emit("XOR3", wx, wy, wz)), (lv, emit("MAJ", wx, wy, wz))
+        p = emit("XOR", wx, wy)
+        lv = max(max(lx, ly) + 1, lz) + 1
+        return (lv, emit("XOR", p, wz)), (lv, emit("MUX", p, wz, wx))
+
+    # Dadda's schedule: column heights come down through 9, 6, 4, 3, 2; in a layer every column is reduced to the target
+    # height with as few adders as possible (a full adder removes two wires, a half adder one), counting the carries the
+    # column below sends up in the same layer
+    targets = [2]
+    while targets[-1] * 3 // 2 < nbits:
+        targets.append(targets[-1] * 3 // 2)
+    for target in reversed(targets):
         new = [[] for _ in range(2 * nbits)]
-        for c, col in enumerate(cols):
-            col = sorted(col)                           # earliest wires first: the latest of a triple is its z
+        for c in range(2 * nbits):
+            col = sorted(cols[c])                       # earliest wires first: the latest of a triple is its z
             i = 0
-            while len(col) - i >= 3:
-                (lx, x), (ly, y), (lz, z) = col[i], col[i + 1], col[i + 2]
-                p = emit("XOR", x, y)
-                lp = max(lx, ly) + 1
-                new[c].append((max(lp, lz) + 1, emit("XOR", p, z)))
-                new[c + 1].append((max(lp, lz) + 1, emit("MUX", p, z, x)))
-                i += 3
+            while len(col) - i + len(new[c]) > target:
+                if len(col) - i + len(new[c]) >= target + 2 and len(col) - i >= 3:
+                    sm, cy = full_adder(col[i], col[i + 1], col[i + 2])
+                    i += 3
+                else:                                   # half adder: XOR + AND on one level
+                    (lx, wx), (ly, wy) = col[i], col[i + 1]
+                    lv = max(lx, ly) + 1
+                    sm, cy = (lv, emit("XOR", wx, wy)), (lv, emit("AND", wx, wy))
+                    i += 2
+                new[c].append(sm)
+                new[c + 1].append(cy)
             new[c].extend(col[i:])
         cols = new
     prod = []
@@ -393,9 +479,9 @@ def less_than_tree(nbits=8):
     return gates, state["nxt"], a, b, lt
 
 
-ADDER_FORMS = {"ripple": lambda n: ripple_carry_adder(n), "mux": mux_carry_adder, "prefix": prefix_adder}
-LESS_THAN_FORMS = {"ripple": less_than, "tree": less_than_tree}
-SUBTRACTOR_FORMS = {"ripple": lambda n: subtractor(n), "prefix": prefix_subtractor}
+ADDER_FORMS = {"ripple": lambda n: ripple_carry_adder(n), "mux": mux_carry_adder, "maj": maj_adder, "prefix": prefix_adder}
+LESS_THAN_FORMS = {"ripple": less_than, "maj": maj_less_than, "tree": less_than_tree}
+SUBTRACTOR_FORMS = {"ripple": lambda n: subtractor(n), "maj": maj_subtractor, "prefix": prefix_subtractor}
 MULTIPLIER_FORMS = {"rows": lambda n: _optimized(multiplier(n)), "wallace": lambda n: _optimized(wallace_multiplier(n))}
 
 
@@ -411,8 +497,7 @@ def pick_form(forms, nbits, instances, resident_jobs=1024):
     best = None
     for name, build in forms.items():
         r = build(nbits)
-        boots = sum(2 if _NAMES[g.op] == "MUX" else 0 if _NAMES[g.op] in ("NOT", "COPY", "CONST0", "CONST1") else 1
-                    for g in r[0])
+        boots = sum(_boots(g) for g in r[0])
         key = (netlist_cost(r[0], instances, resident_jobs), boots)
         if best is None or key < best[0]:
             best = (key, name, r)
@@ -420,9 +505,10 @@ def pick_form(forms, nbits, instances, resident_jobs=1024):
 
 
 def adder(nbits=8, instances=1, resident_jobs=1024):
-    """the adder form to run for `instances` input pairs: mux_carry_adder for wide batches, prefix_adder for small ones
-    (ripple_carry_adder is never chosen: it is the textbook form BASELINE configs[2] is timed on, kept as written)"""
-    forms = {k: v for k, v in ADDER_FORMS.items() if k != "ripple"}
+    """the adder form to run for `instances` input pairs: maj_adder (fewest bootstraps) for wide batches, prefix_adder
+    (fewest levels) for small ones.  ripple_carry_adder is never chosen (it is the textbook form BASELINE configs[2] is
+    timed on, kept as written), nor mux_carry_adder (the best form inside libtfhe's gate family: maj_adder beats it)"""
+    forms = {k: v for k, v in ADDER_FORMS.items() if k in ("maj", "prefix")}
     return pick_form(forms, nbits, instances, resident_jobs)[1]
 
 
@@ -464,6 +550,25 @@ _SEM2 = {
 }
 
 
+_SEM3 = {"MAJ": lambda a, b, c: ((a + b + c) >= 2) * 1, "XOR3": lambda a, b, c: a ^ b ^ c}
+_FREE = ("NOT", "COPY", "CONST0", "CONST1")
+
+
+def _inputs(g):
+    """the wires a gate reads (unused slots are ignored whatever they hold)"""
+    name = _NAMES[g.op]
+    if name in ("CONST0", "CONST1"):
+        return []
+    if name in ("NOT", "COPY"):
+        return [g.in0]
+    return [g.in0, g.in1, g.in2] if name in ("MUX", "MAJ", "XOR3") else [g.in0, g.in1]
+
+
+def _boots(g):
+    name = _NAMES[g.op]
+    return 2 if name == "MUX" else 0 if name in _FREE else 1
+
+
 def evaluate_plain(gates, wires):
     """Run a netlist on plaintext bits: wires is an integer array [n_wires][instances] (modified copy is
     returned).  The truth tables are those of the boots* gates."""
@@ -479,6 +584,8 @@ def evaluate_plain(gates, wires):
             w[g.out] = 1 if name == "CONST1" else 0
         elif name == "MUX":
             w[g.out] = np.where(w[g.in0] == 1, w[g.in1], w[g.in2])
+        elif name in _SEM3:
+            w[g.out] = _SEM3[name](w[g.in0].astype(np.int64), w[g.in1].astype(np.int64), w[g.in2].astype(np.int64))
         else:
             w[g.out] = _SEM2[name](w[g.in0], w[g.in1])
     return w
@@ -497,22 +604,23 @@ def _check_ssa(gates):
     for g in gates:
         if g.out in written:
             raise ValueError("netlist rewriting needs single-assignment wires (wire %d is written twice)" % g.out)
-        for i in (g.in0, g.in1, g.in2):
-            if i >= 0 and i == g.out:
+        for i in _inputs(g):
+            if i == g.out:
                 raise ValueError("gate reads its own output wire %d" % g.out)
         written.add(g.out)
-    for k, g in enumerate(gates):
-        for i in (g.in0, g.in1, g.in2):
-            if i >= 0 and i in written and not any(h.out == i for h in gates[:k]):
+    seen = set()
+    for g in gates:
+        for i in _inputs(g):
+            if i in written and i not in seen:
                 raise ValueError("wire %d is read before it is written" % i)
+        seen.add(g.out)
 
 
 def _uses(gates):
     u = {}
     for g in gates:
-        for i in (g.in0, g.in1, g.in2):
-            if i >= 0:
-                u[i] = u.get(i, 0) + 1
+        for i in _inputs(g):
+            u[i] = u.get(i, 0) + 1
     return u
 
 
@@ -554,6 +662,23 @@ def fold_constants(gates, outputs):
             res.append(constant(1 if name == "CONST1" else 0, g.out))
         elif name in ("NOT", "COPY"):
             res.append(unary(g.in0, 1 if name == "NOT" else 0, g.out))
+        elif name in _SEM3:
+            # MAJ / XOR3 with known inputs: all three -> a constant; two -> the third, a constant (MAJ of two equal) or its
+            # negation; one -> a two-input gate (MAJ(x, y, 0) = AND, MAJ(x, y, 1) = OR, XOR3(x, y, 0) = XOR, XOR3(x, y, 1) = XNOR)
+            ins = [g.in0, g.in1, g.in2]
+            unk = [i for i in ins if i not in const]
+            ones = sum(const[i] for i in ins if i in const)
+            nk = 3 - len(unk)
+            maj = name == "MAJ"
+            if nk == 3:
+                res.append(constant(int(ones >= 2) if maj else ones & 1, g.out))
+            elif nk == 2:
+                res.append(constant(int(ones == 2), g.out) if maj and ones != 1 else unary(unk[0], 0 if maj else ones & 1, g.out))
+            elif nk == 1:
+                op2 = ("OR" if ones else "AND") if maj else ("XNOR" if ones else "XOR")
+                res.append(Gate(OPS[op2], unk[0], unk[1], -1, g.out))
+            else:
+                res.append(Gate(g.op, g.in0, g.in1, g.in2, g.out))
         elif name == "MUX":
             s, b, c = g.in0, g.in1, g.in2
             kb, kc = const.get(b), const.get(c)
@@ -612,6 +737,12 @@ def fold_nots(gates, outputs):
             if ns:
                 b, c = c, b
             out.append(Gate(g.op, s, b, c, g.out))
+        elif name in _SEM3:                             # inputs look through COPY; a negated input stays behind its NOT
+            ins = []
+            for w in (g.in0, g.in1, g.in2):
+                sw, neg = strip(w)
+                ins.append(w if neg else sw)
+            out.append(Gate(g.op, ins[0], ins[1], ins[2], g.out))
         elif name in ("NOT", "COPY"):
             i0, n0 = strip(g.in0)
             n0 ^= 1 if name == "NOT" else 0
@@ -659,7 +790,7 @@ def fuse_mux(gates, outputs):
     return _drop_dead(out, outputs)
 
 
-def fuse_carry(gates, outputs):
+def fuse_carry(gates, outputs, extension_gates=False):
     """The carry of a textbook full adder, OR(AND(a, b), AND(XOR(a, b), c)), is MUX(XOR(a, b), c, a): where the inputs
     differ the carry-in passes, where they agree either of them is the carry.  The two AND wires must be single-use and
     not outputs; the XOR wire stays (the sum bit reads it too).  3 bootstraps on 2 dependent levels become 2 bootstraps on
@@ -683,7 +814,42 @@ def fuse_carry(gates, outputs):
                     q = src.get(p)
                     if m is None and q is not None and q.op == XOR and \
                             ((q.in0 == x.in0 and q.in1 == x.in1) or (q.in0 == x.in1 and q.in1 == x.in0)):
-                        m = Gate(OPS["MUX"], p, c, x.in0, g.out)
+                        # the carry is the MAJORITY of (a, b, c): one bootstrap as the extension gate, two as libtfhe's MUX
+                        m = Gate(OPS["MAJ"], x.in0, x.in1, c, g.out) if extension_gates else Gate(OPS["MUX"], p, c, x.in0, g.out)
+        out.append(m if m is not None else Gate(g.op, g.in0, g.in1, g.in2, g.out))
+    return _drop_dead(out, outputs)
+
+
+def fuse_maj(gates, outputs):
+    """extension gates only: MUX(XOR(x, y), c, x) (or ..., c, y) -- the carry written as one MUX -- is MAJ(x, y, c): where x
+    and y differ the third input decides, where they agree they do.  The XOR wire stays if anyone else reads it."""
+    _check_ssa(gates)
+    src = {g.out: g for g in gates}
+    out = []
+    for g in gates:
+        q = src.get(g.in0) if _NAMES[g.op] == "MUX" else None
+        if q is not None and _NAMES[q.op] == "XOR" and q.in0 != q.in1 and g.in2 in (q.in0, q.in1):
+            out.append(Gate(OPS["MAJ"], q.in0, q.in1, g.in1, g.out))
+        else:
+            out.append(Gate(g.op, g.in0, g.in1, g.in2, g.out))
+    return _drop_dead(out, outputs)
+
+
+def fuse_xor3(gates, outputs):
+    """extension gates only: XOR(XOR(a, b), c) with a single-use inner wire that is no output is XOR3(a, b, c) -- one
+    bootstrap on one level instead of two on two (a full adder's sum once its carry no longer reads a XOR b)"""
+    _check_ssa(gates)
+    src = {g.out: g for g in gates}
+    uses = _uses(gates)
+    keep = set(outputs)
+    out = []
+    for g in gates:
+        m = None
+        if _NAMES[g.op] == "XOR" and g.in0 != g.in1:
+            for p, c in ((g.in0, g.in1), (g.in1, g.in0)):
+                q = src.get(p)
+                if m is None and q is not None and _NAMES[q.op] == "XOR" and uses.get(p, 0) == 1 and p not in keep:
+                    m = Gate(OPS["XOR3"], q.in0, q.in1, c, g.out)
         out.append(m if m is not None else Gate(g.op, g.in0, g.in1, g.in2, g.out))
     return _drop_dead(out, outputs)
 
@@ -692,13 +858,26 @@ def _as_tuples(gates):
     return [(g.op, g.in0, g.in1, g.in2, g.out) for g in gates]
 
 
-def optimize(gates, outputs):
-    """fold_constants, fold_nots, fuse_mux, fuse_carry, repeated until nothing changes (a fused carry with a constant
-    carry-in folds again); returns the rewritten netlist (same wire numbering, never more bootstraps, never more
-    levels).  eoc_netlist_optimize (csrc/host.cpp) is the native twin: same passes, same order, same result."""
-    cur = list(gates)
+def _normalized(gates):
+    """unused input slots as -1 (the passes compare gates field by field)"""
+    out = []
+    for g in gates:
+        ins = _inputs(g) + [-1, -1, -1]
+        out.append(Gate(g.op, ins[0], ins[1], ins[2], g.out))
+    return out
+
+
+def optimize(gates, outputs, extension_gates=True):
+    """fold_constants, fold_nots, fuse_mux, fuse_carry (and, with the extension gates, fuse_maj and fuse_xor3), repeated
+    until nothing changes; returns the rewritten netlist (same wire numbering, never more bootstraps, never more levels).
+    With the extension gates (default) a textbook full adder becomes XOR3 + MAJ -- the literal 8-bit ripple-carry adder 40
+    bootstraps / 17 levels -> 16 / 8; extension_gates=False stays inside libtfhe's boots* family (carry as MUX: 30 / 8).
+    eoc_netlist_optimize(_ex) (csrc/host.cpp) is the native twin: same passes, same order, same result."""
+    cur = _normalized(gates)
     for _ in range(8):
-        nxt = fuse_carry(fuse_mux(fold_nots(fold_constants(cur, outputs), outputs), outputs), outputs)
+        nxt = fuse_carry(fuse_mux(fold_nots(fold_constants(cur, outputs), outputs), outputs), outputs, extension_gates)
+        if extension_gates:
+            nxt = fuse_xor3(fuse_maj(nxt, outputs), outputs)
         if _as_tuples(nxt) == _as_tuples(cur):
             break
         cur = nxt
@@ -708,24 +887,27 @@ def optimize(gates, outputs):
 # ---- levels and the level-cost estimate (what picks a circuit form for an instance count) ------------------------
 
 def levels(gates):
-    """level of every gate as eoc_circuit_run_device assigns it (1-based; RAW, WAR and WAW hazards on wires)"""
+    """level of every gate as eoc_circuit_run_device assigns it (eoc_levelise, csrc/host.cpp; 1-based).  A level is two
+    time slots -- 2L - 1: its pre-pass (free gates), 2L: its bootstrapped gates -- and a gate takes the earliest slot of
+    its kind after the writers of its inputs (RAW), the readers of its output's old value (WAR) and that output's last
+    writer (WAW): a free gate costs no level."""
     wr, rd, lev = {}, {}, []
     for g in gates:
-        name = _NAMES[g.op]
-        ins = [] if name in ("CONST0", "CONST1") else [g.in0] if name in ("NOT", "COPY") else \
-            [g.in0, g.in1, g.in2] if name == "MUX" else [g.in0, g.in1]
-        lv = max([wr.get(g.out, 0), rd.get(g.out, 0)] + [wr.get(i, 0) for i in ins]) + 1
+        ins = _inputs(g)
+        t = max([wr.get(g.out, 0), rd.get(g.out, 0)] + [wr.get(i, 0) for i in ins]) + 1
+        if (t & 1 == 1) != (_boots(g) == 0):
+            t += 1
         for i in ins:
-            rd[i] = max(rd.get(i, 0), lv)
-        wr[g.out] = lv
-        lev.append(lv)
+            rd[i] = max(rd.get(i, 0), t)
+        wr[g.out] = t
+        lev.append((t + 1) // 2)
     return lev
 
 
 def bootstrap_depth(gates):
     """dependent levels that hold at least one blind rotation (free gates ride along)"""
     lev = levels(gates)
-    return len({lv for g, lv in zip(gates, lev) if _NAMES[g.op] not in ("NOT", "COPY", "CONST0", "CONST1")})
+    return len({lv for g, lv in zip(gates, lev) if _boots(g)})
 
 
 def netlist_cost(gates, instances, resident_jobs=1024):
@@ -738,8 +920,7 @@ def netlist_cost(gates, instances, resident_jobs=1024):
     R = max(4, int(resident_jobs))
     jobs = {}
     for g, lv in zip(gates, levels(gates)):
-        name = _NAMES[g.op]
-        w = 2 if name == "MUX" else 0 if name in ("NOT", "COPY", "CONST0", "CONST1") else 1
+        w = _boots(g)
         if w:
             jobs[lv] = jobs.get(lv, 0) + w
     cost = 0
@@ -776,6 +957,12 @@ def noise_margin(gates, n_inputs_var, v_br, v_ks, v_modswitch):
             var[g.out] = 2 * v_br + v_ks
         elif name in ("XOR", "XNOR"):
             rot = [(0.25, 4 * (v(g.in0) + v(g.in1)))]
+            var[g.out] = v_br + v_ks
+        elif name == "XOR3":                            # -2 (a + b + c): phases +-1/4
+            rot = [(0.25, 4 * (v(g.in0) + v(g.in1) + v(g.in2)))]
+            var[g.out] = v_br + v_ks
+        elif name == "MAJ":                             # a + b + c: phases +-1/8, +-3/8
+            rot = [(0.125, v(g.in0) + v(g.in1) + v(g.in2))]
             var[g.out] = v_br + v_ks
         else:
             rot = [(0.125, v(g.in0) + v(g.in1))]

@@ -572,7 +572,8 @@ typedef eoc_engine::Workspace WS;
 // workgroups within half a per cent of each other (3.0 ms per 1024 jobs), while a launch of several rounds settles at
 // a 10 % lower rate (the arbiter's age bias), so wide levels are cut into back-to-back single-round launches.
 static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipStream_t st,
-                               const GateDesc *fold_descs = nullptr, uint32_t fold_S = 0, const GateDesc *inline_desc = nullptr)
+                               const GateDesc *fold_descs = nullptr, uint32_t fold_S = 0, const GateDesc *inline_desc = nullptr,
+                               bool fold_prep = true)
 {
     SpanGuard span(e, st, KIND_BLIND_ROTATE);
     // Two kernel shapes (kernels.hip.h).  The pair kernel (one ciphertext = one wave pair) fills the chip with 4 x CUs
@@ -623,7 +624,7 @@ static int launch_blind_rotate(eoc_engine *e, WS &W, uint32_t njobs_total, hipSt
             a.mu = (int32_t)(1u << 29);
             a.stamps = e->d_stamps;
             a.ks_descs = fold_descs;
-            a.prep = fold_descs != nullptr;
+            a.prep = fold_descs != nullptr && fold_prep; // false: k_prepare wrote the rotation amounts (three-operand gates)
             a.inline_desc = inline_desc != nullptr;
             if (inline_desc) {
                 a.desc0 = *inline_desc;
@@ -718,8 +719,9 @@ static int launch_keyswitch(eoc_engine *e, WS &W, const GateDesc *d_descs, uint3
 
 static inline bool op_const(int op) { return op == OP_CONST0 || op == OP_CONST1; }
 static inline bool op_free(int op) { return op == OP_NOT || op == OP_COPY || op_const(op); }
-static inline bool op_valid(int op) { return (op >= 0 && op <= OP_CONST1); }
-static inline int op_inputs(int op) { return op_const(op) ? 0 : (op_free(op) ? 1 : (op == OP_MUX ? 3 : 2)); }
+static inline bool op_valid(int op) { return (op >= 0 && op <= OP_XOR3); }
+static inline bool op_lin3(int op) { return op == OP_MAJ || op == OP_XOR3; } // one bootstrap, three-operand linear stage
+static inline int op_inputs(int op) { return op_const(op) ? 0 : (op_free(op) ? 1 : (op == OP_MUX || op_lin3(op) ? 3 : 2)); }
 
 // kernels index gates with a grid dimension (y or z <= 65535): wider levels are cut into slices of this many gates
 constexpr size_t kMaxGatesPerLaunch = 32768;
@@ -803,7 +805,7 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
     size_t g0 = 0;
     while (g0 < boot.size()) {
         uint32_t jobs = 0;
-        bool any_mux = false;
+        bool any_mux = false, any_lin3 = false;
         size_t g1 = g0;
         while (g1 < boot.size() && g1 - g0 < kMaxGatesPerLaunch) {
             const uint32_t w = (uint32_t)S * (boot[g1].op == OP_MUX ? 2u : 1u);
@@ -811,6 +813,7 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
             boot[g1].job_base = jobs;
             jobs += w;
             any_mux |= boot[g1].op == OP_MUX;
+            any_lin3 |= op_lin3(boot[g1].op);
             g1++;
         }
         if (jobs > W.ws_jobs) {
@@ -820,7 +823,7 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
         const size_t cnt = g1 - g0;
         // a level of ONE gate without MUX -- the plain eoc_gate_batch_device call -- sends its descriptor as a kernel
         // argument: no copy into the descriptor ring precedes the two launches (and nothing is consumed from the ring)
-        const bool inline_one = cnt == 1 && !any_mux && !e->no_fold;
+        const bool inline_one = cnt == 1 && !any_mux && !any_lin3 && !e->no_fold;
         GateDesc *dd = nullptr;
         int rc = inline_one ? EOC_OK : push_descs(W, boot.data() + g0, cnt, st, &dd);
         if (rc) return rc;
@@ -828,15 +831,19 @@ static int run_level(eoc_engine *e, WS &W, std::vector<GateDesc> &boot, std::vec
         // rotation amounts from the operand rows (k_prepare folded away) and its epilogue sets the key switch up
         // (k_ks_init folded away) -- one launch per level besides the key switch; EOC_TFHE_NO_FOLD=1 keeps the separate
         // launches (diagnostics)
+        // The extension gates MAJ / XOR3 (three-operand linear stage) take their rotation amounts from k_prepare -- the
+        // folded prologue stays the two-operand code it was -- but keep the folded key-switch set-up (every gate of the slice
+        // has S jobs: job = gate * S + instance)
         const bool fold = !any_mux && !e->no_fold;
-        if (!fold) {
+        const bool fold_prep = fold && !any_lin3;
+        if (!fold_prep) {
             dim3 grid((unsigned)(S * (any_mux ? 2 : 1)), (unsigned)((n + 1 + 255) / 256), (unsigned)cnt);
             SpanGuard span(e, st, KIND_PREPARE);
             hipLaunchKernelGGL(k_prepare, grid, dim3(256), 0, st, dd, n, (uint32_t)S, W.d_bara, e->bara_stride);
             HIP_TRY(hipGetLastError());
         }
         const GateDesc *one = inline_one ? boot.data() + g0 : nullptr;
-        rc = launch_blind_rotate(e, W, jobs, st, fold ? dd : nullptr, (uint32_t)S, one);
+        rc = launch_blind_rotate(e, W, jobs, st, fold ? dd : nullptr, (uint32_t)S, one, fold_prep);
         if (rc) return rc;
         rc = launch_keyswitch(e, W, dd, (uint32_t)cnt, (uint32_t)S, st, fold, one);
         if (rc) return rc;
@@ -906,7 +913,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
     const size_t stride = (size_t)e->p.n + 1;
     std::vector<GateDesc> boot, freeg;
     if (!ops) {
-        if (!op_valid(op) || (!op_free(op) && !d_in1) || (op == OP_MUX && !d_in2)) {
+        if (!op_valid(op) || (!op_free(op) && !d_in1) || (op_inputs(op) == 3 && !d_in2)) {
             eoc_set_error("eoc_gate_batch_device: bad opcode %d or missing operand", op);
             return EOC_ERR_ARG;
         }
@@ -924,7 +931,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
             eoc_set_error("eoc_gate_batch_device: bad opcode %d at %zu", (int)ops[k], k);
             return EOC_ERR_ARG;
         }
-        if ((!op_free(ops[k]) && !d_in1) || (ops[k] == OP_MUX && !d_in2) || (!op_const(ops[k]) && !d_in0)) {
+        if ((!op_free(ops[k]) && !d_in1) || (op_inputs(ops[k]) == 3 && !d_in2) || (!op_const(ops[k]) && !d_in0)) {
             eoc_set_error("eoc_gate_batch_device: missing operand for opcode %d", (int)ops[k]);
             return EOC_ERR_ARG;
         }
@@ -943,7 +950,7 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
     for (size_t k = 0; k < count; k++) max_jobs += ops[k] == OP_MUX ? 2 : (op_free(ops[k]) ? 0 : 1);
     const bool use_pool = !e->no_pool && max_jobs <= ((size_t)1 << 20);
     if (!use_pool) {
-        size_t cnt_op[OP_CONST1 + 1] = {0}, run = 0;
+        size_t cnt_op[OP_XOR3 + 1] = {0}, run = 0;
         max_jobs = 0;
         for (size_t k = 0; k < count; k++) {
             cnt_op[ops[k]]++;
@@ -953,14 +960,14 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         if (gather) {
             size_t two_input = 0;
             for (int o = 0; o < OP_MUX; o++) two_input += cnt_op[o];
-            max_jobs = std::max(two_input, 2 * cnt_op[OP_MUX]);
+            max_jobs = std::max({two_input, 2 * cnt_op[OP_MUX], cnt_op[OP_MAJ], cnt_op[OP_XOR3]});
         }
     }
     if (gather && count > (size_t)kPermIndexMask) {
         eoc_set_error("eoc_gate_batch_device: a mixed batch holds at most %u gates", kPermIndexMask);
         return EOC_ERR_ARG;
     }
-    int rc = ensure_ws(e, W, max_jobs, 2 * (gather ? OP_CONST1 + 1 : runs) + 64, gather ? count : 0, st);
+    int rc = ensure_ws(e, W, max_jobs, 2 * (gather ? OP_XOR3 + 1 : runs) + 64, gather ? count : 0, st);
     if (rc) return rc;
     uint32_t *d_perm = nullptr;
     if (gather) {
@@ -986,9 +993,9 @@ static int gate_batch_ws(eoc_engine *e, WS &W, int op, const uint8_t *ops, const
         } else {
             HIP_TRY(hipEventSynchronize(W.perm_ev)); // the previous mixed batch's copy out of h_perm (long done, normally)
         }
-        size_t bucket[OP_CONST1 + 2] = {0};
+        size_t bucket[OP_XOR3 + 2] = {0};
         for (size_t k = 0; k < count; k++) bucket[ops[k] + 1]++;
-        for (int o = 1; o < OP_CONST1 + 2; o++) bucket[o] += bucket[o - 1];
+        for (int o = 1; o < OP_XOR3 + 2; o++) bucket[o] += bucket[o - 1];
         sorted_ops.resize(count);
         for (size_t k = 0; k < count; k++) {
             size_t pos = bucket[ops[k]]++;

@@ -677,7 +677,7 @@ static const char *gate_strings(int op, const char *c1, const char *c2, const ch
     const int n = c.params()->n;
     std::vector<int32_t> a, b, cc, out(n + 1);
     if (!b64_to_sample(c1, n, a, nullptr) || (op != EOC_NOT && !b64_to_sample(c2, n, b, nullptr)) ||
-        (op == EOC_MUX && !b64_to_sample(c3, n, cc, nullptr))) {
+        ((op == EOC_MUX || op == EOC_MAJ || op == EOC_XOR3) && !b64_to_sample(c3, n, cc, nullptr))) {
         fprintf(stderr, "gate: malformed ciphertext\n");
         return nullptr;
     }
@@ -695,6 +695,9 @@ extern "C" const char *gateXOR(const char *a, const char *b, const char *) { ret
 extern "C" const char *gateXNOR(const char *a, const char *b, const char *) { return gate_strings(EOC_XNOR, a, b, nullptr); }
 extern "C" const char *gateNOT(const char *a, const char *) { return gate_strings(EOC_NOT, a, nullptr, nullptr); }
 extern "C" const char *gateMUX(const char *a, const char *b, const char *c, const char *) { return gate_strings(EOC_MUX, a, b, c); }
+// extension gates (include/eoc_tfhe_gpu.h): majority and three-input parity, one bootstrap each
+extern "C" const char *gateMAJ(const char *a, const char *b, const char *c, const char *) { return gate_strings(EOC_MAJ, a, b, c); }
+extern "C" const char *gateXOR3(const char *a, const char *b, const char *c, const char *) { return gate_strings(EOC_XOR3, a, b, c); }
 
 // ---- raw-buffer calls on the global key (what a Node/Lua batch wrapper uses) --------------------------
 extern "C" int eoc_global_params(eoc_params *out)
@@ -811,8 +814,14 @@ inline int op_with_negated_inputs(int op, int n0, int n1)
         if (table_of(o, 0, 0) == want) return o;
     return -1; // unreachable: the family is closed under input negation
 }
-inline bool nl_free(int op) { return op >= EOC_NOT; }
-inline int nl_inputs(int op) { return op >= EOC_CONST0 ? 0 : (op >= EOC_NOT ? 1 : (op == EOC_MUX ? 3 : 2)); }
+inline bool nl_lin3(int op) { return op == EOC_MAJ || op == EOC_XOR3; } // extension gates: symmetric in three inputs
+inline bool nl_free(int op) { return op >= EOC_NOT && op <= EOC_CONST1; }
+inline int nl_inputs(int op)
+{
+    if (op == EOC_CONST0 || op == EOC_CONST1) return 0;
+    if (op == EOC_NOT || op == EOC_COPY) return 1;
+    return (op == EOC_MUX || nl_lin3(op)) ? 3 : 2;
+}
 typedef std::vector<eoc_gate> Netlist;
 
 void drop_dead(Netlist &g, const std::vector<char> &keep, size_t n_wires)
@@ -867,7 +876,24 @@ Netlist pass_fold_constants(const Netlist &in, const std::vector<char> &keep, si
     for (const eoc_gate &g : in) {
         if (g.op == EOC_CONST0 || g.op == EOC_CONST1) res.push_back(constant(g.op == EOC_CONST1, g.out));
         else if (g.op == EOC_NOT || g.op == EOC_COPY) res.push_back(unary(g.in0, g.op == EOC_NOT, g.out));
-        else if (g.op == EOC_MUX) {
+        else if (nl_lin3(g.op)) {
+            // MAJ / XOR3 with known inputs: all three -> a constant; two -> the third, a constant (MAJ of two equal) or its
+            // negation; one -> a two-input gate (MAJ(x, y, 0) = AND, MAJ(x, y, 1) = OR, XOR3(x, y, 0) = XOR, XOR3(x, y, 1) = XNOR)
+            const int32_t ins[3] = {g.in0, g.in1, g.in2};
+            int32_t unk[3];
+            int nu = 0, ones = 0, nk = 0;
+            for (int a = 0; a < 3; a++) {
+                if (cst[ins[a]] >= 0) { nk++; ones += cst[ins[a]]; }
+                else unk[nu++] = ins[a];
+            }
+            const bool maj = g.op == EOC_MAJ;
+            if (nk == 3) res.push_back(constant(maj ? ones >= 2 : ones & 1, g.out));
+            else if (nk == 2) {
+                if (maj && ones != 1) res.push_back(constant(ones == 2, g.out));
+                else res.push_back(unary(unk[0], maj ? 0 : ones & 1, g.out));
+            } else if (nk == 1) res.push_back(mk(maj ? (ones ? EOC_OR : EOC_AND) : (ones ? EOC_XNOR : EOC_XOR), unk[0], unk[1], -1, g.out));
+            else res.push_back(mk(g.op, g.in0, g.in1, g.in2, g.out));
+        } else if (g.op == EOC_MUX) {
             const int32_t s = g.in0, b = g.in1, c = g.in2;
             const int kb = cst[b], kc = cst[c];
             if (cst[s] >= 0) res.push_back(unary(cst[s] ? b : c, 0, g.out));
@@ -920,6 +946,12 @@ Netlist pass_fold_nots(const Netlist &in, const std::vector<char> &keep, size_t 
             g.in1 = nb ? q.in1 : b; // a negated branch stays behind its (free) NOT
             g.in2 = nc ? q.in2 : c;
             if (n0) std::swap(g.in1, g.in2);
+        } else if (nl_lin3(g.op)) { // inputs look through COPY; a negated input stays behind its (free) NOT
+            int na, nb, nc;
+            const int32_t a = strip(q.in0, na), b = strip(q.in1, nb), c = strip(q.in2, nc);
+            g.in0 = na ? q.in0 : a;
+            g.in1 = nb ? q.in1 : b;
+            g.in2 = nc ? q.in2 : c;
         } else if (g.op == EOC_NOT || g.op == EOC_COPY) {
             g.in0 = strip(q.in0, n0);
             n0 ^= q.op == EOC_NOT;
@@ -967,7 +999,7 @@ Netlist pass_fuse_mux(const Netlist &cur, const std::vector<char> &keep, size_t 
     return fused;
 }
 
-Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
+Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_t n_wires, bool ext)
 {
     std::vector<int64_t> src;
     std::vector<int> uses;
@@ -986,9 +1018,60 @@ Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_
                     if (src[p] < 0) continue;
                     const eoc_gate &q = cur[src[p]];
                     if (q.op == EOC_XOR && ((q.in0 == x.in0 && q.in1 == x.in1) || (q.in0 == x.in1 && q.in1 == x.in0))) {
-                        res.push_back(mk(EOC_MUX, p, c, x.in0, g.out));
+                        // the carry is the MAJORITY of (a, b, c): one bootstrap as the extension gate, two as libtfhe's MUX
+                        res.push_back(ext ? mk(EOC_MAJ, x.in0, x.in1, c, g.out) : mk(EOC_MUX, p, c, x.in0, g.out));
                         done = true;
                     }
+                }
+            }
+        }
+        if (!done) res.push_back(g);
+    }
+    drop_dead(res, keep, n_wires);
+    return res;
+}
+
+// extension gates only.  MUX(XOR(x, y), c, x) (or ..., c, y) -- the carry written as one MUX -- is MAJ(x, y, c): where x and y
+// differ the third input decides, where they agree they do.  The XOR wire stays if anyone else reads it.
+Netlist pass_fuse_maj(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<int64_t> src;
+    std::vector<int> uses;
+    index_netlist(cur, n_wires, src, uses);
+    Netlist res;
+    res.reserve(cur.size());
+    for (const eoc_gate &g : cur) {
+        if (g.op == EOC_MUX && src[g.in0] >= 0) {
+            const eoc_gate &q = cur[src[g.in0]];
+            if (q.op == EOC_XOR && q.in0 != q.in1 && (g.in2 == q.in0 || g.in2 == q.in1)) {
+                res.push_back(mk(EOC_MAJ, q.in0, q.in1, g.in1, g.out));
+                continue;
+            }
+        }
+        res.push_back(g);
+    }
+    drop_dead(res, keep, n_wires);
+    return res;
+}
+// extension gates only.  XOR(XOR(a, b), c) with a single-use inner wire that is no output is XOR3(a, b, c): one bootstrap
+// on one level instead of two on two (a full adder's sum once its carry no longer reads a XOR b)
+Netlist pass_fuse_xor3(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<int64_t> src;
+    std::vector<int> uses;
+    index_netlist(cur, n_wires, src, uses);
+    Netlist res;
+    res.reserve(cur.size());
+    for (const eoc_gate &g : cur) {
+        bool done = false;
+        if (g.op == EOC_XOR && g.in0 != g.in1) {
+            for (int side = 0; side < 2 && !done; side++) {
+                const int32_t p = side ? g.in1 : g.in0, c = side ? g.in0 : g.in1;
+                if (src[p] < 0) continue;
+                const eoc_gate &q = cur[src[p]];
+                if (q.op == EOC_XOR && uses[p] == 1 && !keep[p]) {
+                    res.push_back(mk(EOC_XOR3, q.in0, q.in1, c, g.out));
+                    done = true;
                 }
             }
         }
@@ -1016,7 +1099,7 @@ int check_netlist(const eoc_gate *gates, size_t n_gates, size_t &n_wires)
     if (!gates && n_gates) return EOC_ERR_ARG;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &g = gates[k];
-        if (g.op < EOC_NAND || g.op > EOC_CONST1 || g.out < 0 || g.out > kMaxWireId) return EOC_ERR_ARG;
+        if (g.op < EOC_NAND || g.op > EOC_XOR3 || g.out < 0 || g.out > kMaxWireId) return EOC_ERR_ARG;
         const int nin = nl_inputs(g.op);
         const int32_t ins[3] = {g.in0, g.in1, g.in2};
         for (int a = 0; a < nin; a++) {
@@ -1032,18 +1115,23 @@ int check_netlist(const eoc_gate *gates, size_t n_gates, size_t &n_wires)
 // nothing is thrown across the ABI (the reference is built -fno-exceptions, ao-tfhe/build.sh:23): an allocation failure inside
 // the netlist entry points becomes EOC_ERR_ALLOC
 static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
-                                     eoc_gate *gates_out);
-extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs,
-                                        size_t n_outputs, eoc_gate *gates_out)
+                                     eoc_gate *gates_out, bool ext);
+extern "C" int64_t eoc_netlist_optimize_ex(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
+                                           eoc_gate *gates_out, unsigned flags)
 {
     try {
-        return netlist_optimize_impl(gates, n_gates, outputs, n_outputs, gates_out);
+        return netlist_optimize_impl(gates, n_gates, outputs, n_outputs, gates_out, !(flags & EOC_NL_BOOTS_GATES_ONLY));
     } catch (...) {
         return EOC_ERR_ALLOC;
     }
 }
+extern "C" int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs,
+                                        size_t n_outputs, eoc_gate *gates_out)
+{
+    return eoc_netlist_optimize_ex(gates, n_gates, outputs, n_outputs, gates_out, 0);
+}
 static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
-                                     eoc_gate *gates_out)
+                                     eoc_gate *gates_out, bool ext)
 {
     if ((!outputs && n_outputs) || (!gates_out && n_gates)) return EOC_ERR_ARG;
     size_t n_wires = 0;
@@ -1078,7 +1166,8 @@ static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, cons
 
     for (int round = 0; round < 8; round++) {
         Netlist nxt = pass_fuse_carry(
-            pass_fuse_mux(pass_fold_nots(pass_fold_constants(cur, keep, n_wires), keep, n_wires), keep, n_wires), keep, n_wires);
+            pass_fuse_mux(pass_fold_nots(pass_fold_constants(cur, keep, n_wires), keep, n_wires), keep, n_wires), keep, n_wires, ext);
+        if (ext) nxt = pass_fuse_xor3(pass_fuse_maj(nxt, keep, n_wires), keep, n_wires);
         const bool same = same_netlist(nxt, cur);
         cur.swap(nxt);
         if (same) break;
@@ -1087,22 +1176,29 @@ static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, cons
     return (int64_t)cur.size();
 }
 
-// levelisation of a netlist exactly as eoc_circuit_run_device evaluates it: RAW, WAR and WAW hazards on wires (a netlist
-// need not be single-assignment to RUN).  level_of[n_gates], 1-based; returns the number of levels.
+// Levelisation of a netlist exactly as eoc_circuit_run_device evaluates it (a netlist need not be single-assignment to RUN).
+// A level is two time slots: slot 2L - 1 = the level's PRE-PASS, where its free gates (NOT / COPY / CONSTANT: k_free_gates)
+// run, and slot 2L = its bootstrapped gates (one blind rotation over all of them).  A gate goes into the earliest slot of its
+// kind that is after the slots that wrote its inputs (RAW), after the slots that still read the old value of its output
+// (WAR) and after the slot that last wrote its output (WAW).  So a free gate costs NO level: NOT(x) sits in the pre-pass of the
+// level whose bootstrapped gates read it (round 6; before, every gate took a whole level and the reader of a NOT waited one
+// more blind rotation).  level_of[n_gates], 1-based; returns the number of levels.
 int eoc_levelise(const eoc_gate *gates, size_t n_gates, size_t n_wires, int *level_of)
 {
-    std::vector<int> wr_level(n_wires, 0), rd_level(n_wires, 0);
+    std::vector<int> wr_slot(n_wires, 0), rd_slot(n_wires, 0); // slot 0 = before the circuit (its inputs)
     int nlev = 0;
     for (size_t k = 0; k < n_gates; k++) {
         const eoc_gate &q = gates[k];
         const int nin = nl_inputs(q.op);
         const int32_t ins[3] = {q.in0, q.in1, q.in2};
-        int lv = std::max(wr_level[q.out], rd_level[q.out]);
-        for (int a = 0; a < nin; a++) lv = std::max(lv, wr_level[ins[a]]);
-        lv += 1;
+        int t = std::max(wr_slot[q.out], rd_slot[q.out]);
+        for (int a = 0; a < nin; a++) t = std::max(t, wr_slot[ins[a]]);
+        t += 1;                                       // strictly after all of them ...
+        if (((t & 1) != 0) != nl_free(q.op)) t += 1;  // ... in a slot of its kind: odd = pre-pass, even = blind rotation
+        const int lv = (t + 1) / 2;
         level_of[k] = lv;
-        for (int a = 0; a < nin; a++) rd_level[ins[a]] = std::max(rd_level[ins[a]], lv);
-        wr_level[q.out] = lv;
+        for (int a = 0; a < nin; a++) rd_slot[ins[a]] = std::max(rd_slot[ins[a]], t);
+        wr_slot[q.out] = t;
         nlev = std::max(nlev, lv);
     }
     return nlev;

@@ -482,6 +482,11 @@ struct GateDesc {
     int32_t *out;
 };
 constexpr int OP_MUX = 10, OP_NOT = 11, OP_COPY = 12, OP_CONST0 = 13, OP_CONST1 = 14, OP_RAW = 100;
+// extension gates (include/eoc_tfhe_gpu.h): one bootstrap behind a linear stage over THREE operands (in0, in1, in2).  Their
+// rotation amounts come from k_prepare (a launch of its own): the blind rotation's folded prologue stays the two-operand
+// code it was, so the hot kernels' ISA does not change for them
+constexpr int OP_MAJ = 15, OP_XOR3 = 16;
+__device__ __forceinline__ int gate_lin3(int op) { return op == OP_MAJ ? 1 : (op == OP_XOR3 ? -2 : 0); } // sign of ALL three
 // OP_MULTI (internal, mixed batches): one gate descriptor over rows of DIFFERENT two-input opcodes (0..9) -- only the
 // linear stage differs between them, so the whole opcode-sorted block runs as one level (full launches instead of one
 // partly filled launch per opcode).  `in2` then points at one 32-bit word per row whose top four bits are the row's
@@ -531,9 +536,14 @@ __global__ __launch_bounds__(256) void k_prepare(const GateDesc *__restrict__ de
     int cst8, s0, s1;
     gate_lin(op, cst8, s0, s1);
     const size_t off = (size_t)s * (n + 1) + m;
-    uint32_t t = (uint32_t)s0 * (uint32_t)a[off];
-    if (s1) t += (uint32_t)s1 * (uint32_t)b[off];
-    if (m == n) t += (uint32_t)cst8 << 29;
+    uint32_t t;
+    if (const int s3 = gate_lin3(op)) // MAJ: a + b + c; XOR3: -2 (a + b + c); no constant
+        t = (uint32_t)s3 * ((uint32_t)a[off] + (uint32_t)b[off] + (uint32_t)d.in2[off]);
+    else {
+        t = (uint32_t)s0 * (uint32_t)a[off];
+        if (s1) t += (uint32_t)s1 * (uint32_t)b[off];
+        if (m == n) t += (uint32_t)cst8 << 29;
+    }
     // modSwitchFromTorus32(t, 2N), N = 1024: round(t * 2048 / 2^32) mod 2048
     bara[(size_t)(d.job_base + y) * bara_stride + m] = (uint16_t)(((t + (1u << 20)) >> 21) & 2047u);
 }

@@ -55,7 +55,14 @@ enum eoc_op {
     EOC_NAND = 0, EOC_AND = 1, EOC_OR = 2, EOC_NOR = 3, EOC_XOR = 4, EOC_XNOR = 5,
     EOC_ANDNY = 6, EOC_ANDYN = 7, EOC_ORNY = 8, EOC_ORYN = 9, EOC_MUX = 10,
     EOC_NOT = 11, EOC_COPY = 12,
-    EOC_CONST0 = 13, EOC_CONST1 = 14 /* bootsCONSTANT(result, 0 / 1): noiseless trivial sample, no inputs (in0 = -1 / NULL) */
+    EOC_CONST0 = 13, EOC_CONST1 = 14, /* bootsCONSTANT(result, 0 / 1): noiseless trivial sample, no inputs (in0 = -1 / NULL) */
+    /* EXTENSION gates (round 6) -- not in libtfhe's boots* family, built from its primitives the way bootsXOR is: a linear
+     * stage over THREE samples (lweAddTo / lweAddMulTo, no constant), then tfhe_bootstrap_FFT with mu = 1/8.
+     *   EOC_MAJ (a, b, c)  t = a + b + c: the phases are +-1/8 or +-3/8 and the sign is the MAJORITY -- a full adder's carry
+     *                      (and, with a negated input, a subtractor's borrow / a comparator's step) in ONE bootstrap
+     *   EOC_XOR3(a, b, c)  t = -2 (a + b + c): the phases are +-1/4 and the sign is the PARITY -- a full adder's sum
+     * One blind rotation and one key switch each, like the two-input gates; same decision margins (1/8 and 1/4). */
+    EOC_MAJ = 15, EOC_XOR3 = 16
 };
 
 /* error codes (all negative) */
@@ -206,7 +213,7 @@ const eoc_params *eoc_engine_params(eoc_engine *e);
  *             group, MUX rows another, and both share ONE blind rotation over the concatenated jobs; NOT / COPY /
  *             CONSTANT take no bootstrap; scatter back).  At most 2^28 - 1 rows per call with ops != NULL (EOC_ERR_ARG
  *             beyond)
- *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX)
+ *   d_in*   : DEVICE arrays [count][n+1] int32 (d_in1 unused by NOT/COPY, d_in2 only by MUX, MAJ and XOR3)
  *   d_out   : DEVICE array  [count][n+1] int32
  * bootsNAND ... bootsMUX over a batch.  Asynchronous on hip_stream (NULL = default stream). */
 int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32_t *d_in0,
@@ -223,7 +230,7 @@ typedef struct eoc_gate {
 } eoc_gate;
 int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size_t n_gates, int32_t *d_wires,
                            size_t n_wires, size_t instances, void *hip_stream);
-/* number of bootstraps (blind rotations) a netlist costs per instance: MUX = 2, NOT/COPY = 0 */
+/* number of bootstraps (blind rotations) a netlist costs per instance: MUX = 2, NOT / COPY / CONSTANT = 0, everything else 1 */
 size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
 /* Netlist rewriting on the host (no GPU), four passes repeated until nothing changes:
  *   constants   bootsCONSTANT wires are folded into their readers (AND(x, 0) = 0, XOR(x, 1) = NOT x, MUX(s, 0, c) = ANDNY(s, c),
@@ -239,6 +246,14 @@ size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
  * entries; returns the number of gates written.  Same wire numbering, never more bootstraps, never more levels. */
 int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
                              eoc_gate *gates_out);
+/* ... with flags.  By default (flags 0, = eoc_netlist_optimize) the rewriting may use the EXTENSION gates: the full adder's
+ * carry becomes EOC_MAJ(a, b, c) (one bootstrap, not MUX's two), MUX(XOR(x, y), c, x) becomes EOC_MAJ(x, y, c), and
+ * XOR(XOR(a, b), c) with a single-use inner wire becomes EOC_XOR3(a, b, c): the literal 8-bit ripple-carry adder goes from 40
+ * bootstraps on 17 levels to 16 on 8.  EOC_NL_BOOTS_GATES_ONLY keeps the result inside libtfhe's boots* family (the carry
+ * as MUX: 30 bootstraps on 8 levels). */
+enum { EOC_NL_BOOTS_GATES_ONLY = 1 };
+int64_t eoc_netlist_optimize_ex(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
+                                eoc_gate *gates_out, unsigned flags);
 /* levels of a netlist exactly as eoc_circuit_run_device assigns them (RAW, WAR, WAW hazards; 1-based; level_of[n_gates] or
  * NULL); *bootstrap_levels (or NULL) = levels that hold at least one blind rotation -- the sequential depth a small batch
  * pays for.  Returns the number of levels. */
@@ -365,6 +380,9 @@ const char *gateXOR(const char *ct1, const char *ct2, const char *base64PublicKe
 const char *gateXNOR(const char *ct1, const char *ct2, const char *base64PublicKey);
 const char *gateNOT(const char *ct1, const char *base64PublicKey);
 const char *gateMUX(const char *ct1, const char *ct2, const char *ct3, const char *base64PublicKey);
+/* the extension gates (EOC_MAJ, EOC_XOR3), signature style of gateMUX */
+const char *gateMAJ(const char *ct1, const char *ct2, const char *ct3, const char *base64PublicKey);
+const char *gateXOR3(const char *ct1, const char *ct2, const char *ct3, const char *base64PublicKey);
 
 /* ------------------------------------------------------------------------------------------------
  * f1: the reference's own 11 calls, same symbols and signatures (ao-tfhe/eoc-tfhe-run.h:8-19,

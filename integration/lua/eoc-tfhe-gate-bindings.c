@@ -73,6 +73,17 @@ static int l_gateMUX(lua_State *L) {
                           luaL_optstring(L, 4, ""));
   lua_pushstring(L, r); free((void *)r); return 1;
 }
+/* the extension gates (EOC_MAJ, EOC_XOR3): three ciphertexts in, one out, like gateMUX */
+static int l_gateMAJ(lua_State *L) {
+  const char *r = gateMAJ(luaL_checkstring(L, 1), luaL_checkstring(L, 2), luaL_checkstring(L, 3),
+                          luaL_optstring(L, 4, ""));
+  lua_pushstring(L, r); free((void *)r); return 1;
+}
+static int l_gateXOR3(lua_State *L) {
+  const char *r = gateXOR3(luaL_checkstring(L, 1), luaL_checkstring(L, 2), luaL_checkstring(L, 3),
+                           luaL_optstring(L, 4, ""));
+  lua_pushstring(L, r); free((void *)r); return 1;
+}
 static int l_exportSecretKey(lua_State *L) {
   const char *r = exportSecretKey();
   lua_pushstring(L, r); free((void *)r); return 1;
@@ -219,6 +230,7 @@ static const luaL_Reg eoc_gate_functions[] = {
   {"constantBit", l_constantBit}, {"decryptBit", l_decryptBit},
   {"gateNAND", l_gateNAND}, {"gateAND", l_gateAND}, {"gateOR", l_gateOR}, {"gateNOR", l_gateNOR},
   {"gateXOR", l_gateXOR}, {"gateXNOR", l_gateXNOR}, {"gateNOT", l_gateNOT}, {"gateMUX", l_gateMUX},
+  {"gateMAJ", l_gateMAJ}, {"gateXOR3", l_gateXOR3},
   {"exportSecretKey", l_exportSecretKey}, {"importSecretKey", l_importSecretKey},
   {"exportCloudKey", l_exportCloudKey}, {"importCloudKey", l_importCloudKey},
   {"exportCloudKeyToFile", l_exportCloudKeyToFile}, {"importCloudKeyFromFile", l_importCloudKeyFromFile},

@@ -20,6 +20,8 @@ function Tfhe.xor(a, b, pk)                 return Tfhe.backend.gateXOR(a, b, pk
 function Tfhe.xnor(a, b, pk)                return Tfhe.backend.gateXNOR(a, b, pk) end
 function Tfhe.bnot(a, pk)                   return Tfhe.backend.gateNOT(a, pk) end
 function Tfhe.mux(a, b, c, pk)              return Tfhe.backend.gateMUX(a, b, c, pk) end
+function Tfhe.maj(a, b, c, pk)              return Tfhe.backend.gateMAJ(a, b, c, pk) end   -- extension gates (one bootstrap):
+function Tfhe.xor3(a, b, c, pk)             return Tfhe.backend.gateXOR3(a, b, c, pk) end  -- a full adder's carry and sum
 function Tfhe.exportSecretKey()             return Tfhe.backend.exportSecretKey() end
 function Tfhe.importSecretKey(k)            return Tfhe.backend.importSecretKey(k) end
 -- the cloud ("public") key: exported by the client (= generatePublicKey), all a server installs
@@ -32,7 +34,8 @@ function Tfhe.keyMode()                     return Tfhe.backend.keyMode() end   
 -- ---- circuit layer: netlists evaluated by ONE backend call (circuitRun), batched over instances ----
 -- wires travel as one binary string [nWires][instances][n+1] of int32 samples; a netlist is packed as 5 int32 per gate
 Tfhe.OP = { NAND = 0, AND = 1, OR = 2, NOR = 3, XOR = 4, XNOR = 5, ANDNY = 6, ANDYN = 7, ORNY = 8, ORYN = 9, MUX = 10,
-            NOT = 11, COPY = 12, CONST0 = 13, CONST1 = 14 }
+            NOT = 11, COPY = 12, CONST0 = 13, CONST1 = 14,
+            MAJ = 15, XOR3 = 16 }   -- extension gates: majority / three-input parity, ONE bootstrap each
 local OP = Tfhe.OP
 local function newNetlist()
   local nl = { gates = {}, nWires = 0 }
@@ -115,6 +118,41 @@ function Tfhe.muxAdderNetlist(nbits)
   end
   sum[#sum + 1] = c
   return nl, a, b, sum
+end
+-- with the extension gates a full adder is XOR3(a, b, c) + MAJ(a, b, c), one bootstrap each on the level of c:
+-- 2 nbits bootstraps on nbits levels (16 / 8 at 8 bits)
+function Tfhe.majAdderNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, sum = nl.wire(nbits), nl.wire(nbits), {}
+  sum[1] = nl.gate(OP.XOR, a, b)
+  local c = nl.gate(OP.AND, a, b)
+  for i = 1, nbits - 1 do
+    sum[#sum + 1] = nl.gate(OP.XOR3, a + i, b + i, c)
+    c = nl.gate(OP.MAJ, a + i, b + i, c)
+  end
+  sum[#sum + 1] = c
+  return nl, a, b, sum
+end
+-- a - b and the final borrow: d_i = XOR3(a_i, b_i, br_i), br_{i+1} = MAJ(NOT a_i, b_i, br_i) (NOT is free); 16 / 8 at 8 bits
+function Tfhe.majSubtractorNetlist(nbits)
+  local nl = newNetlist()
+  local a, b, diff = nl.wire(nbits), nl.wire(nbits), {}
+  diff[1] = nl.gate(OP.XOR, a, b)
+  local br = nl.gate(OP.ANDNY, a, b)
+  for i = 1, nbits - 1 do
+    local na = nl.gate(OP.NOT, a + i)
+    diff[#diff + 1] = nl.gate(OP.XOR3, a + i, b + i, br)
+    br = nl.gate(OP.MAJ, na, b + i, br)
+  end
+  return nl, a, b, diff, br
+end
+-- unsigned a < b = that borrow alone: ONE bootstrap per bit (8 / 8 at 8 bits)
+function Tfhe.majLessThanNetlist(nbits)
+  local nl = newNetlist()
+  local a, b = nl.wire(nbits), nl.wire(nbits)
+  local lt = nl.gate(OP.ANDNY, a, b)
+  for i = 1, nbits - 1 do lt = nl.gate(OP.MAJ, nl.gate(OP.NOT, a + i), b + i, lt) end
+  return nl, a, b, lt
 end
 -- logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
 -- 48 bootstraps on 5 levels for 8 bits.  sub = true: the same network over (a borrow arises, a borrow passes) =
@@ -207,26 +245,34 @@ function Tfhe.lessThanTreeNetlist(nbits)
 end
 -- the form of lowest estimated cost for this many instances (backend.netlistCost: below a quarter of the resident set a
 -- level costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
-local function cheapest(builders, nbits, instances)
+-- outPos (optional): position of the builder's output-wire list in what it returns -- the candidates are then priced AFTER
+-- backend.netlistOptimize (the multiplier: the row-by-row form shrinks from 320 to 176 bootstraps, the column form to 230)
+local function cheapest(builders, nbits, instances, outPos)
   local best, bestCost
   for i = 1, #builders do
     local r = { builders[i](nbits) }
-    local cost = Tfhe.backend.netlistCost(r[1].packed(), instances)
+    local gates = r[1].packed()
+    if outPos then
+      local o = {}
+      for k = 1, #r[outPos] do o[k] = string.pack("<i4", r[outPos][k]) end
+      gates = Tfhe.backend.netlistOptimize(gates, table.concat(o)) or gates
+    end
+    local cost = Tfhe.backend.netlistCost(gates, instances)
     if not best or (cost >= 0 and cost < bestCost) then best, bestCost = r, cost end
   end
   return table.unpack(best)
 end
 function Tfhe.adderNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist }, nbits, instances)
+  return cheapest({ Tfhe.majAdderNetlist, Tfhe.prefixAdderNetlist }, nbits, instances)
 end
 function Tfhe.lessThanNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
+  return cheapest({ Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
 end
 function Tfhe.multiplierNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist }, nbits, instances)
+  return cheapest({ Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist }, nbits, instances, 4)
 end
 function Tfhe.subtractorNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.subtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances)
+  return cheapest({ Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances)
 end
 -- min / max on the comparator picked for this many instances: one MUX per output bit behind it
 function Tfhe.minMaxNetlistFor(nbits, instances)
@@ -272,9 +318,9 @@ function Tfhe.multiplierNetlist(nbits)
   prod[#prod + 1] = top
   return nl, a, b, prod
 end
--- a * b in logarithmic depth: partial products in columns by weight, column compression by full adders (sum = (x ^ y) ^ z,
--- carry = MUX(x ^ y, z, x); the latest arriving wire of a triple is its z) until no column holds more than two wires, then
--- ONE parallel-prefix addition of the two remaining rows; 8 bits: 16 levels against the row-by-row form's 40
+-- a * b in logarithmic depth: partial products in columns by weight, Dadda column compression by full adders (XOR3 + MAJ: the
+-- extension gates, one level) and half adders until no column holds more than two wires, then ONE parallel-prefix addition of
+-- the two remaining rows; 8 bits: 244 bootstraps on 11 levels against the row-by-row form's 320 on 40
 function Tfhe.wallaceMultiplierNetlist(nbits)
   local nl = newNetlist()
   local a, b = nl.wire(nbits), nl.wire(nbits)
@@ -297,30 +343,41 @@ function Tfhe.wallaceMultiplierNetlist(nbits)
     end
     return t
   end
-  local function tallest()
-    local m = 0
-    for c = 0, ncol - 1 do if #cols[c] > m then m = #cols[c] end end
-    return m
-  end
-  while tallest() > 2 do
+  -- Dadda's schedule: column heights come down through 9, 6, 4, 3, 2; in a layer every column is reduced to the target with
+  -- as few adders as possible (a full adder = XOR3 + MAJ removes two wires, a half adder = XOR + AND one), counting the
+  -- carries the column below sends up in the same layer
+  local targets = { 2 }
+  while targets[#targets] * 3 // 2 < nbits do targets[#targets + 1] = targets[#targets] * 3 // 2 end
+  for ti = #targets, 1, -1 do
+    local target = targets[ti]
     local new = {}
     for c = 0, ncol - 1 do new[c] = {} end
     for c = 0, ncol - 1 do
       local col = sorted(cols[c])
       local i = 1
-      while #col - i + 1 >= 3 do
-        local x, y, z = col[i], col[i + 1], col[i + 2]
-        local p = nl.gate(OP.XOR, x[2], y[2])
-        local lp = x[1]
-        if y[1] > lp then lp = y[1] end
-        lp = lp + 1
-        local lv = lp
-        if z[1] > lv then lv = z[1] end
-        lv = lv + 1
+      while #col - i + 1 + #new[c] > target do
+        local sm, cy
+        if #col - i + 1 + #new[c] >= target + 2 and #col - i + 1 >= 3 then
+          local x, y, z = col[i], col[i + 1], col[i + 2]
+          local lv = x[1]
+          if y[1] > lv then lv = y[1] end
+          if z[1] > lv then lv = z[1] end
+          lv = lv + 1
+          sm = { lv, nl.gate(OP.XOR3, x[2], y[2], z[2]) }
+          cy = { lv, nl.gate(OP.MAJ, x[2], y[2], z[2]) }
+          i = i + 3
+        else
+          local x, y = col[i], col[i + 1]
+          local lv = x[1]
+          if y[1] > lv then lv = y[1] end
+          lv = lv + 1
+          sm = { lv, nl.gate(OP.XOR, x[2], y[2]) }
+          cy = { lv, nl.gate(OP.AND, x[2], y[2]) }
+          i = i + 2
+        end
         local nc, nc1 = new[c], new[c + 1]
-        nc[#nc + 1] = { lv, nl.gate(OP.XOR, p, z[2]) }
-        nc1[#nc1 + 1] = { lv, nl.gate(OP.MUX, p, z[2], x[2]) }
-        i = i + 3
+        nc[#nc + 1] = sm
+        nc1[#nc1 + 1] = cy
       end
       local nc = new[c]
       for k = i, #col do nc[#nc + 1] = col[k] end

@@ -157,6 +157,23 @@ static napi_value n_gateMUX(napi_env env, napi_callback_info info)
     free(a); free(b); free(c);
     return ret_string(env, r);
 }
+/* the extension gates (EOC_MAJ, EOC_XOR3): three ciphertexts in, one out, like gateMUX */
+static napi_value n_gateMAJ(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    char *a = arg_string(env, argv[0]), *b = arg_string(env, argv[1]), *c = arg_string(env, argv[2]);
+    const char *r = gateMAJ(a, b, c, "");
+    free(a); free(b); free(c);
+    return ret_string(env, r);
+}
+static napi_value n_gateXOR3(napi_env env, napi_callback_info info)
+{
+    ARGS(4);
+    char *a = arg_string(env, argv[0]), *b = arg_string(env, argv[1]), *c = arg_string(env, argv[2]);
+    const char *r = gateXOR3(a, b, c, "");
+    free(a); free(b); free(c);
+    return ret_string(env, r);
+}
 static napi_value n_exportSecretKey(napi_env env, napi_callback_info info) { (void)info; return ret_string(env, exportSecretKey()); }
 static napi_value n_importSecretKey(napi_env env, napi_callback_info info)
 {
@@ -462,7 +479,7 @@ static napi_value init(napi_env env, napi_value exports)
         {"generateGateKey", n_generateGateKey}, {"resetGateKey", n_resetGateKey}, {"encryptBit", n_encryptBit}, {"constantBit", n_constantBit},
         {"decryptBit", n_decryptBit}, {"gateNAND", n_gateNAND}, {"gateAND", n_gateAND}, {"gateOR", n_gateOR},
         {"gateNOR", n_gateNOR}, {"gateXOR", n_gateXOR}, {"gateXNOR", n_gateXNOR}, {"gateNOT", n_gateNOT},
-        {"gateMUX", n_gateMUX}, {"exportSecretKey", n_exportSecretKey}, {"importSecretKey", n_importSecretKey},
+        {"gateMUX", n_gateMUX}, {"gateMAJ", n_gateMAJ}, {"gateXOR3", n_gateXOR3}, {"exportSecretKey", n_exportSecretKey}, {"importSecretKey", n_importSecretKey},
         {"exportCloudKey", n_exportCloudKey}, {"importCloudKey", n_importCloudKey},
         {"exportCloudKeyToFile", n_exportCloudKeyToFile}, {"importCloudKeyFromFile", n_importCloudKeyFromFile},
         {"keyMode", n_keyMode},

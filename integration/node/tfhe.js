@@ -34,6 +34,8 @@ Tfhe.xor = (a, b, pk) => B.gateXOR(a, b, pk);
 Tfhe.xnor = (a, b, pk) => B.gateXNOR(a, b, pk);
 Tfhe.not = (a, pk) => B.gateNOT(a, pk);
 Tfhe.mux = (a, b, c, pk) => B.gateMUX(a, b, c, pk);
+Tfhe.maj = (a, b, c, pk) => B.gateMAJ(a, b, c, pk);     // extension gates (one bootstrap): a full adder's carry ...
+Tfhe.xor3 = (a, b, c, pk) => B.gateXOR3(a, b, c, pk);   // ... and its sum
 // ---- keys: the secret key stays with the client, the cloud ("public") key is all a server installs ----
 Tfhe.resetGateKey = () => B.resetGateKey();
 Tfhe.setDevices = devices => B.setDevices(Int32Array.from(devices));   // GPUs behind the next gate key / cloud key
@@ -51,7 +53,8 @@ Tfhe.engineCount = () => B.engineCount();
 // A netlist is a list of gates {op, in0, in1, in2, out} over numbered wires; wires travel as one Buffer
 // [nWires][instances][n+1] of int32 samples.  The builders mirror eoc_tfhe_amd/circuits.py.
 const OP = { NAND: 0, AND: 1, OR: 2, NOR: 3, XOR: 4, XNOR: 5, ANDNY: 6, ANDYN: 7, ORNY: 8, ORYN: 9, MUX: 10, NOT: 11, COPY: 12,
-             CONST0: 13, CONST1: 14 };
+             CONST0: 13, CONST1: 14,
+             MAJ: 15, XOR3: 16 };   // extension gates: majority / three-input parity, ONE bootstrap each
 Tfhe.OP = OP;
 class Netlist {
   constructor() { this.gates = []; this.nWires = 0; }
@@ -146,6 +149,38 @@ Tfhe.muxAdderNetlist = nbits => {
   sum.push(c);
   return { nl, a, b, sum };
 };
+// with the extension gates a full adder is XOR3(a, b, c) + MAJ(a, b, c), one bootstrap each on the level of c:
+// 2 nbits bootstraps on nbits levels (16 / 8 at 8 bits)
+Tfhe.majAdderNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), sum = [];
+  sum.push(nl.gate(OP.XOR, a, b));
+  let c = nl.gate(OP.AND, a, b);
+  for (let i = 1; i < nbits; i++) {
+    sum.push(nl.gate(OP.XOR3, a + i, b + i, c));
+    c = nl.gate(OP.MAJ, a + i, b + i, c);
+  }
+  sum.push(c);
+  return { nl, a, b, sum };
+};
+// a - b and the final borrow: d_i = XOR3(a_i, b_i, br_i), br_{i+1} = MAJ(NOT a_i, b_i, br_i) (NOT is free); 16 / 8 at 8 bits
+Tfhe.majSubtractorNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits), diff = [];
+  diff.push(nl.gate(OP.XOR, a, b));
+  let br = nl.gate(OP.ANDNY, a, b);
+  for (let i = 1; i < nbits; i++) {
+    const na = nl.gate(OP.NOT, a + i);
+    diff.push(nl.gate(OP.XOR3, a + i, b + i, br));
+    br = nl.gate(OP.MAJ, na, b + i, br);
+  }
+  return { nl, a, b, diff, borrow: br };
+};
+// unsigned a < b = that borrow alone: ONE bootstrap per bit (8 / 8 at 8 bits)
+Tfhe.majLessThanNetlist = nbits => {
+  const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
+  let lt = nl.gate(OP.ANDNY, a, b);
+  for (let i = 1; i < nbits; i++) lt = nl.gate(OP.MAJ, nl.gate(OP.NOT, a + i), b + i, lt);
+  return { nl, a, b, lt };
+};
 // logarithmic depth: Sklansky prefix network over (generate, propagate); cell = MUX(P_hi, G_lo, G_hi) + AND(P_hi, P_lo);
 // 48 bootstraps on 5 levels for 8 bits.  sub: the same network over (a borrow arises, a borrow passes) =
 // (ANDNY(a, b), XNOR(a, b)) computes a - b and the final borrow
@@ -210,46 +245,66 @@ Tfhe.lessThanTreeNetlist = nbits => {
 };
 // the form of lowest estimated cost for this many instances (B.netlistCost: below a quarter of the resident set a level
 // costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
-const cheapest = (builders, nbits, instances) => {
+// outKey (optional): the builder's output-wire list -- the candidates are then priced AFTER B.netlistOptimize (the multiplier:
+// the row-by-row form shrinks from 320 to 176 bootstraps, the column form to 230)
+const cheapest = (builders, nbits, instances, outKey) => {
   let best = null, bestCost = 0;
   for (const build of builders) {
-    const r = build(nbits), cost = B.netlistCost(r.nl.packed(), instances);
+    const r = build(nbits);
+    let gates = r.nl.packed();
+    if (outKey) gates = B.netlistOptimize(gates, Int32Array.from(r[outKey])) || gates;
+    const cost = B.netlistCost(gates, instances);
     if (best === null || (cost >= 0 && cost < bestCost)) { best = r; bestCost = cost; }
   }
   return best;
 };
-Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.muxAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
-Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.lessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
-Tfhe.multiplierNetlistFor = (nbits, instances) => cheapest([Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist], nbits, instances);
-Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.subtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances);
+Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.majAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
+Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
+Tfhe.multiplierNetlistFor = (nbits, instances) => cheapest([Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist], nbits, instances, 'prod');
+Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances);
 // min / max on the comparator picked for this many instances: one MUX per output bit behind it
 Tfhe.minMaxNetlistFor = (nbits, instances) => {
   const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances), min = [], max = [];
   for (let i = 0; i < nbits; i++) { min.push(nl.gate(OP.MUX, lt, a + i, b + i)); max.push(nl.gate(OP.MUX, lt, b + i, a + i)); }
   return { nl, a, b, lt, min, max };
 };
-// a * b in logarithmic depth: partial products in columns by weight, column compression by full adders (sum = (x ^ y) ^ z,
-// carry = MUX(x ^ y, z, x); the latest arriving wire of a triple is its z) until no column holds more than two wires, then
-// ONE parallel-prefix addition of the two remaining rows; 8 bits: 16 levels against the row-by-row form's 40
+// a * b in logarithmic depth: partial products in columns by weight, Dadda column compression by full adders (XOR3 + MAJ: the
+// extension gates, one level) and half adders until no column holds more than two wires, then ONE parallel-prefix addition of
+// the two remaining rows; 8 bits: 244 bootstraps on 11 levels against the row-by-row form's 320 on 40
 Tfhe.wallaceMultiplierNetlist = nbits => {
   const nl = new Netlist(), a = nl.wire(nbits), b = nl.wire(nbits);
   if (nbits === 1) return { nl, a, b, prod: [nl.gate(OP.AND, a, b), nl.gate(OP.CONST0, -1)] };
   const ncol = 2 * nbits, byLevel = (p, q) => p[0] - q[0] || p[1] - q[1];
   let cols = [...Array(ncol)].map(() => []);
   for (let r = 0; r < nbits; r++) for (let j = 0; j < nbits; j++) cols[r + j].push([1, nl.gate(OP.AND, a + j, b + r)]);
-  while (Math.max(...cols.map(c => c.length)) > 2) {
+  // Dadda's schedule: column heights come down through 9, 6, 4, 3, 2; in a layer every column is reduced to the target with
+  // as few adders as possible (a full adder = XOR3 + MAJ removes two wires, a half adder = XOR + AND one), counting the
+  // carries the column below sends up in the same layer
+  const targets = [2];
+  while (Math.floor(targets[targets.length - 1] * 3 / 2) < nbits) targets.push(Math.floor(targets[targets.length - 1] * 3 / 2));
+  for (const target of targets.slice().reverse()) {
     const next = [...Array(ncol)].map(() => []);
-    cols.forEach((raw, c) => {
-      const col = raw.slice().sort(byLevel);
+    for (let c = 0; c < ncol; c++) {
+      const col = cols[c].slice().sort(byLevel);
       let i = 0;
-      for (; col.length - i >= 3; i += 3) {
-        const [x, y, z] = [col[i], col[i + 1], col[i + 2]];
-        const p = nl.gate(OP.XOR, x[1], y[1]), lv = Math.max(Math.max(x[0], y[0]) + 1, z[0]) + 1;
-        next[c].push([lv, nl.gate(OP.XOR, p, z[1])]);
-        next[c + 1].push([lv, nl.gate(OP.MUX, p, z[1], x[1])]);
+      while (col.length - i + next[c].length > target) {
+        let sm, cy;
+        if (col.length - i + next[c].length >= target + 2 && col.length - i >= 3) {
+          const [x, y, z] = [col[i], col[i + 1], col[i + 2]], lv = Math.max(x[0], y[0], z[0]) + 1;
+          sm = [lv, nl.gate(OP.XOR3, x[1], y[1], z[1])];
+          cy = [lv, nl.gate(OP.MAJ, x[1], y[1], z[1])];
+          i += 3;
+        } else {
+          const [x, y] = [col[i], col[i + 1]], lv = Math.max(x[0], y[0]) + 1;
+          sm = [lv, nl.gate(OP.XOR, x[1], y[1])];
+          cy = [lv, nl.gate(OP.AND, x[1], y[1])];
+          i += 2;
+        }
+        next[c].push(sm);
+        next[c + 1].push(cy);
       }
       next[c].push(...col.slice(i));
-    });
+    }
     cols = next;
   }
   const prod = [];

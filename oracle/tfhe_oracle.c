@@ -588,6 +588,12 @@ int orc_gate(const orc_params *p, const double *bkfft, const int32_t *ksk, int o
         for (int j = 0; j <= N; j++) u1[j] = (int32_t)((uint32_t)u1[j] + (uint32_t)u2[j]);
         u1[N] = (int32_t)((uint32_t)u1[N] + (uint32_t)mu);
         orc_keyswitch(p, ksk, u1, out);
+    } else if (op == ORC_MAJ || op == ORC_XOR3) {
+        /* extension gates: lweAddTo / lweAddMulTo of THREE samples (the linear ops of SURVEY.md 8a a13), no constant, then
+         * tfhe_bootstrap_FFT exactly as bootsAND ... bootsXOR do.  MAJ: a + b + c; XOR3: -2 (a + b + c) */
+        const uint32_t s = op == ORC_MAJ ? 1u : (uint32_t)-2;
+        for (int m = 0; m <= n; m++) t[m] = (int32_t)(s * ((uint32_t)ca[m] + (uint32_t)cb[m] + (uint32_t)cc[m]));
+        orc_bootstrap(p, bkfft, ksk, t, mu, out);
     } else if (orc_gate_linear(p, op, ca, cb, t) == 0) {
         orc_bootstrap(p, bkfft, ksk, t, mu, out);
     } else {

@@ -46,7 +46,11 @@ int orc_default_params(int set, orc_params *out);
 enum {
     ORC_NAND = 0, ORC_AND = 1, ORC_OR = 2, ORC_NOR = 3, ORC_XOR = 4, ORC_XNOR = 5,
     ORC_ANDNY = 6, ORC_ANDYN = 7, ORC_ORNY = 8, ORC_ORYN = 9, ORC_MUX = 10,
-    ORC_NOT = 11, ORC_COPY = 12, ORC_CONST0 = 13, ORC_CONST1 = 14 /* bootsCONSTANT(result, 0 / 1) */
+    ORC_NOT = 11, ORC_COPY = 12, ORC_CONST0 = 13, ORC_CONST1 = 14, /* bootsCONSTANT(result, 0 / 1) */
+    /* extension gates (round 6), NOT in libtfhe's boots* family: the same tfhe_bootstrap_FFT behind a THREE-input linear
+     * stage -- MAJ(a,b,c): t = a + b + c (phases +-1/8, +-3/8: the sign is the majority = a full adder's carry in ONE
+     * bootstrap); XOR3(a,b,c): t = -2 (a + b + c) (phases +-1/4: the sign is the parity = a full adder's sum) */
+    ORC_MAJ = 15, ORC_XOR3 = 16
 };
 
 /* ---- deterministic counter-based generator (DESIGN.md "PRNG") ---- */

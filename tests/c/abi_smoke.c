@@ -44,25 +44,24 @@ int main(int argc, char **argv)
         CHECK(opt[0].op == EOC_MUX && opt[0].in0 == 0 && opt[0].in1 == 1 && opt[0].in2 == 2 && opt[0].out == 6);
         const eoc_gate bad[2] = {{EOC_AND, 0, 1, -1, 2}, {EOC_OR, 0, 1, -1, 2}};
         CHECK(eoc_netlist_optimize(bad, 2, outs, 0, opt) == EOC_ERR_ARG);
-        /* round 6: levels (the engine's: NOT is free, its reader waits a level) and the level-cost estimate */
+        /* round 6: levels (the engine's: NOT is free and sits in the pre-pass of its reader's level) and the level-cost estimate */
         int32_t lev[4];
         int64_t depth = 0;
-        CHECK(eoc_netlist_levels(nl, 4, lev, &depth) == 3 && depth == 3);
-        CHECK(lev[0] == 1 && lev[1] == 1 && lev[2] == 2 && lev[3] == 3);
-        CHECK(eoc_netlist_cost(nl, 4, 3, 0) == 54 && eoc_netlist_cost(nl, 4, 1024, 1024) == 90);
+        CHECK(eoc_netlist_levels(nl, 4, lev, &depth) == 2 && depth == 2);
+        CHECK(lev[0] == 1 && lev[1] == 1 && lev[2] == 1 && lev[3] == 2);
+        CHECK(eoc_netlist_cost(nl, 4, 3, 0) == 36 && eoc_netlist_cost(nl, 4, 1024, 1024) == 60 + 30);
         CHECK(eoc_netlist_levels(bad, 2, NULL, NULL) == 2);                     /* running needs no single assignment */
         /* slots an opcode does not use may hold anything (here: far out of range, negative): ignored, never indexed */
         const eoc_gate sloppy[4] = {{EOC_NOT, 0, 31000, -7, 3}, {EOC_AND, 0, 1, 99999, 4}, {EOC_AND, 3, 2, -5, 5}, {EOC_OR, 4, 5, 77, 6}};
         CHECK(eoc_netlist_optimize(sloppy, 4, outs, 1, opt) == 1 && opt[0].op == EOC_MUX && opt[0].in2 == 2);
-        CHECK(eoc_netlist_levels(sloppy, 4, lev, &depth) == 3 && eoc_netlist_cost(sloppy, 4, 3, 0) == 54);
+        CHECK(eoc_netlist_levels(sloppy, 4, lev, &depth) == 2 && eoc_netlist_cost(sloppy, 4, 3, 0) == 36);
         const eoc_gate huge[1] = {{EOC_AND, 0, 1, -1, 2147483647}};
         CHECK(eoc_netlist_optimize(huge, 1, outs, 1, opt) == EOC_ERR_ARG && eoc_netlist_levels(huge, 1, NULL, NULL) == EOC_ERR_ARG);
         const eoc_gate junk[1] = {{99, 0, 1, -1, 2}};
         CHECK(eoc_netlist_levels(junk, 1, NULL, NULL) == EOC_ERR_ARG && eoc_netlist_cost(junk, 1, 1, 0) == EOC_ERR_ARG);
     }
     {   /* BASELINE configs[2]'s literal 8-bit adder (full adder at bit 0, carry-in bootsCONSTANT(0): 40 bootstraps on 17
-         * levels) through the optimizer: carry rewrite OR(AND(a,b), AND(XOR(a,b),c)) -> MUX(XOR(a,b),c,a) + constant
-         * folding = 30 bootstraps on 8 levels.  Wires: a 0..7, b 8..15, sum 16..24, carry-in 25, temporaries 26.. */
+         * levels) through the optimizer: the carry OR(AND(a,b), AND(XOR(a,b),c)) rewritten + constant folding.  Wires: a 0..7, b 8..15, sum 16..24, carry-in 25, temporaries 26.. */
         eoc_gate ad[41], ad_opt[41];
         int32_t sum[9], nxt = 26, carry = 25;
         size_t ng = 0;
@@ -80,14 +79,22 @@ int main(int argc, char **argv)
         for (int i = 0; i < 9; i++) sum[i] = 16 + i;
         int64_t d0 = 0, d1 = 0;
         CHECK(ng == 41 && eoc_circuit_bootstraps(ad, ng) == 40 && eoc_netlist_levels(ad, ng, NULL, &d0) > 0 && d0 == 17);
-        int64_t no = eoc_netlist_optimize(ad, ng, sum, 9, ad_opt);
+        /* inside libtfhe's gate family: the carry as MUX, the constant carry-in folded: 30 bootstraps on 8 levels */
+        int64_t no = eoc_netlist_optimize_ex(ad, ng, sum, 9, ad_opt, EOC_NL_BOOTS_GATES_ONLY);
         CHECK(no > 0 && no <= 41 && eoc_circuit_bootstraps(ad_opt, (size_t)no) == 30);
         CHECK(eoc_netlist_levels(ad_opt, (size_t)no, NULL, &d1) > 0 && d1 == 8);
-        int n_mux = 0;
+        int n_mux = 0, n_maj = 0, n_xor3 = 0;
         for (int64_t k = 0; k < no; k++) n_mux += ad_opt[k].op == EOC_MUX;
         CHECK(n_mux == 7);                                                       /* bit 0's MUX(p, 0, a) folded to ANDNY */
         CHECK(eoc_netlist_cost(ad_opt, (size_t)no, 8, 0) < eoc_netlist_cost(ad, ng, 8, 0));
         CHECK(eoc_netlist_cost(ad_opt, (size_t)no, 4096, 0) == 30 * 4 * 30 && eoc_netlist_cost(ad, ng, 4096, 0) == 40 * 4 * 30);
+        /* default: with the extension gates a full adder is XOR3 + MAJ, one bootstrap each: 16 on 8 levels */
+        no = eoc_netlist_optimize(ad, ng, sum, 9, ad_opt);
+        CHECK(no > 0 && no <= 41 && eoc_circuit_bootstraps(ad_opt, (size_t)no) == 16);
+        CHECK(eoc_netlist_levels(ad_opt, (size_t)no, NULL, &d1) > 0 && d1 == 8);
+        for (int64_t k = 0; k < no; k++) { n_maj += ad_opt[k].op == EOC_MAJ; n_xor3 += ad_opt[k].op == EOC_XOR3; }
+        CHECK(n_maj == 7 && n_xor3 == 7);                                        /* bit 0 folds to XOR + AND */
+        CHECK(eoc_netlist_cost(ad_opt, (size_t)no, 4096, 0) == 16 * 4 * 30);
     }
     /* f2, server side: the cloud key alone as the process-global context (no secret in it) */
     size_t ck_len = eoc_cloud_key_blob_bytes(&p);

@@ -14,7 +14,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 N = 1024
 
 OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9,
-           MUX=10, NOT=11, COPY=12, CONST0=13, CONST1=14)
+           MUX=10, NOT=11, COPY=12, CONST0=13, CONST1=14, MAJ=15, XOR3=16)
 
 
 class OrcParams(C.Structure):

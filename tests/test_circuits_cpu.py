@@ -145,8 +145,8 @@ def test_fuse_mux_keeps_shared_inner_wires():
 
 def test_random_netlists_rewrite_is_equivalent():
     rng = np.random.default_rng(11)
-    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "MUX", "COPY", "CONST0", "CONST1"]
-    for trial in range(300):
+    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "MUX", "COPY", "CONST0", "CONST1", "MAJ", "XOR3", "XOR", "AND"]
+    for trial in range(400):
         n_in, n_g = 4, int(rng.integers(5, 40))
         gates, avail = [], list(range(n_in))
         for k in range(n_g):
@@ -157,22 +157,24 @@ def test_random_netlists_rewrite_is_equivalent():
                 gates.append(Gate(OPS[name], -1, -1, -1, out))
             elif name in ("NOT", "COPY"):
                 gates.append(Gate(OPS[name], pick(), -1, -1, out))
-            elif name == "MUX":
+            elif name in ("MUX", "MAJ", "XOR3"):
                 gates.append(Gate(OPS[name], pick(), pick(), pick(), out))
             else:
                 gates.append(Gate(OPS[name], pick(), pick(), -1, out))
             avail.append(out)
         outs = [int(v) for v in rng.choice(avail[n_in:], size=min(3, n_g), replace=False)]
-        opt = c.optimize(gates, outs)
-        assert circuit_bootstraps(opt) <= circuit_bootstraps(gates)
-        assert c.bootstrap_depth(opt) <= c.bootstrap_depth(gates)
         w = np.zeros((n_in + n_g, 16), np.uint8)
         for k in range(16):
             for i in range(n_in):
                 w[i, k] = (k >> i) & 1
-        a, b = c.evaluate_plain(gates, w), c.evaluate_plain(opt, w)
-        for o in outs:
-            assert np.array_equal(a[o], b[o]), (trial, o)
+        a = c.evaluate_plain(gates, w)
+        for ext in (True, False):
+            opt = c.optimize(gates, outs, extension_gates=ext)
+            assert circuit_bootstraps(opt) <= circuit_bootstraps(gates)
+            assert c.bootstrap_depth(opt) <= c.bootstrap_depth(gates), (trial, ext)
+            b = c.evaluate_plain(opt, w)
+            for o in outs:
+                assert np.array_equal(a[o], b[o]), (trial, o, ext)
 
 
 def test_rewrites_refuse_non_ssa():
@@ -185,7 +187,7 @@ def test_native_optimizer_matches_python(built_lib):
     """eoc_netlist_optimize (C ABI, host.cpp) rewrites exactly like circuits.optimize"""
     import eoc_tfhe_amd as eoc
     rng = np.random.default_rng(23)
-    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "MUX", "COPY", "CONST0", "CONST1"]
+    names = list(c._SEM2) + ["NOT", "NOT", "NOT", "MUX", "MUX", "COPY", "CONST0", "CONST1", "MAJ", "XOR3", "XOR", "AND"]
     as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
     for trial in range(400):
         n_in, n_g = 4, int(rng.integers(1, 50))
@@ -198,7 +200,7 @@ def test_native_optimizer_matches_python(built_lib):
                 gates.append(Gate(OPS[name], -1, -1, -1, out))
             elif name in ("NOT", "COPY"):
                 gates.append(Gate(OPS[name], pick(), -1, -1, out))
-            elif name == "MUX":
+            elif name in ("MUX", "MAJ", "XOR3"):
                 gates.append(Gate(OPS[name], pick(), pick(), pick(), out))
             else:
                 gates.append(Gate(OPS[name], pick(), pick(), -1, out))
@@ -211,6 +213,7 @@ def test_native_optimizer_matches_python(built_lib):
         ref, opt = c.evaluate_plain(gates, w), c.evaluate_plain(c.optimize(gates, outs), w)
         assert all(np.array_equal(ref[o], opt[o]) for o in outs), trial
         assert as_t(eoc.netlist_optimize(gates, outs)) == as_t(c.optimize(gates, outs)), trial
+        assert as_t(eoc.netlist_optimize(gates, outs, extension_gates=False)) == as_t(c.optimize(gates, outs, extension_gates=False)), trial
         lv, nlev, depth = eoc.netlist_levels(gates)
         assert lv == c.levels(gates) and nlev == max(lv) and depth == c.bootstrap_depth(gates), trial
         for S in (1, 7, 300, 5000):
@@ -289,13 +292,15 @@ def test_prefix_subtractor_all_inputs(nbits):
         assert np.array_equal(_value(r, d), (A - B) % (1 << nbits)) and np.array_equal(r[br], (A < B).astype(np.uint8))
     g8 = c.prefix_subtractor(8)[0]
     assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (48, 5)
-    assert c.pick_form(c.SUBTRACTOR_FORMS, 8, 8)[0] == "prefix" and c.pick_form(c.SUBTRACTOR_FORMS, 8, 4096)[0] == "ripple"
+    assert c.pick_form(c.SUBTRACTOR_FORMS, 8, 8)[0] == "prefix" and c.pick_form(c.SUBTRACTOR_FORMS, 8, 4096)[0] == "maj"
+    g8 = c.maj_subtractor(8)[0]
+    assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (16, 8)
 
 
 @pytest.mark.parametrize("nbits", [1, 2, 3, 4, 5])
 def test_wallace_multiplier_all_inputs(nbits):
     A, B, S = _words(nbits)
-    for build in (c.wallace_multiplier, c.MULTIPLIER_FORMS["wallace"], c.MULTIPLIER_FORMS["rows"]):
+    for build in (c.wallace_multiplier, lambda n: c.wallace_multiplier(n, False), c.MULTIPLIER_FORMS["wallace"], c.MULTIPLIER_FORMS["rows"]):
         gates, nw, a, b, p = build(nbits)
         c._check_ssa(gates)
         w = np.zeros((nw, S), np.uint8)
@@ -304,7 +309,11 @@ def test_wallace_multiplier_all_inputs(nbits):
         assert np.array_equal(_value(c.evaluate_plain(gates, w), p), A * B)
     g8 = c.MULTIPLIER_FORMS["wallace"](8)[0]
     r8 = c.MULTIPLIER_FORMS["rows"](8)[0]
-    assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (315, 16) and (circuit_bootstraps(r8), c.bootstrap_depth(r8)) == (272, 27)
+    assert (circuit_bootstraps(g8), c.bootstrap_depth(g8)) == (230, 11) and (circuit_bootstraps(r8), c.bootstrap_depth(r8)) == (176, 21)
+    b8 = c.wallace_multiplier(8, extension_gates=False)                       # inside libtfhe's gate family
+    assert (circuit_bootstraps(b8[0]), c.bootstrap_depth(b8[0])) == (314, 13)
+    o8 = c.optimize(c.multiplier(8)[0], c.multiplier(8)[4], extension_gates=False)
+    assert (circuit_bootstraps(o8), c.bootstrap_depth(o8)) == (272, 27)
     assert c.pick_form(c.MULTIPLIER_FORMS, 8, 8)[0] == "wallace" and c.pick_form(c.MULTIPLIER_FORMS, 8, 4096)[0] == "rows"
     rng = np.random.default_rng(nbits)
     A, B = rng.integers(0, 256, 1500), rng.integers(0, 256, 1500)
@@ -316,13 +325,14 @@ def test_wallace_multiplier_all_inputs(nbits):
 
 
 def test_adder_forms_eight_bits_counts():
-    ripple, mux, prefix = (f(8)[0] for f in (c.ADDER_FORMS["ripple"], c.mux_carry_adder, c.prefix_adder))
+    ripple, mux, prefix, maj = (f(8)[0] for f in (c.ADDER_FORMS["ripple"], c.mux_carry_adder, c.prefix_adder, c.maj_adder))
     assert (circuit_bootstraps(ripple), c.bootstrap_depth(ripple)) == (37, 15)
     assert (circuit_bootstraps(mux), c.bootstrap_depth(mux)) == (30, 8)
     assert (circuit_bootstraps(prefix), c.bootstrap_depth(prefix)) == (48, 5)
+    assert (circuit_bootstraps(maj), c.bootstrap_depth(maj)) == (16, 8)      # XOR3 + MAJ: one bootstrap each
     rng = np.random.default_rng(8)
     A, B = rng.integers(0, 256, 4000), rng.integers(0, 256, 4000)
-    for build in (c.mux_carry_adder, c.prefix_adder):
+    for build in (c.mux_carry_adder, c.prefix_adder, c.maj_adder):
         gates, nw, a, b, s = build(8)
         w = np.zeros((nw, 4000), np.uint8)
         _load(w, a, A)
@@ -360,11 +370,20 @@ def test_carry_rewrite_on_the_literal_adder():
     assert circuit_bootstraps(gates) == 40 and c.bootstrap_depth(gates) == 17
     assert circuit_bootstraps(only_carry) == 32 and c.bootstrap_depth(only_carry) == 9
     assert sum(1 for g in only_carry if g.op == OPS["MUX"]) == 8
-    opt = c.optimize(gates, s)
+    opt = c.optimize(gates, s, extension_gates=False)                          # inside libtfhe's gate family
     assert circuit_bootstraps(opt) == 30 and c.bootstrap_depth(opt) == 8
+    # with the extension gates the same netlist becomes XOR3 + MAJ per bit: 16 bootstraps on 8 levels (40 / 17 as written),
+    # gate for gate what maj_adder builds
+    ext = c.optimize(gates, s)
+    assert circuit_bootstraps(ext) == 16 and c.bootstrap_depth(ext) == 8
+    assert sorted(c._NAMES[g.op] for g in ext if c._boots(g)) == sorted(c._NAMES[g.op] for g in c.maj_adder(8)[0])
+    assert sum(1 for g in c.fuse_carry(gates, s, extension_gates=True) if g.op == OPS["MAJ"]) == 8
+    for written in (c.mux_carry_adder(8), c.ripple_carry_adder(8)):             # the other ways of writing it end there too
+        o = c.optimize(written[0], written[4])
+        assert (circuit_bootstraps(o), c.bootstrap_depth(o)) == (16, 8)
     rng = np.random.default_rng(6)
     A, B = rng.integers(0, 256, 3000), rng.integers(0, 256, 3000)
-    for nl in (only_carry, opt):
+    for nl in (only_carry, opt, ext):
         w = np.zeros((nw, 3000), np.uint8)
         _load(w, a, A)
         _load(w, b, B)
@@ -372,7 +391,9 @@ def test_carry_rewrite_on_the_literal_adder():
     for carry_in_zero in (False, True):
         gates, nw, a, b, s = c.ripple_carry_adder(4, carry_in_zero=carry_in_zero)
         _adder_check(c.optimize(gates, s), nw, a, b, s, 4)
+        _adder_check(c.optimize(gates, s, extension_gates=False), nw, a, b, s, 4)
         _adder_check(c.fuse_carry(gates, s), nw, a, b, s, 4)
+        _adder_check(c.fuse_carry(gates, s, extension_gates=True), nw, a, b, s, 4)
     # every operand order of the pattern; a shared AND wire blocks it
     for g_ab in ((0, 1), (1, 0)):
         for x_ab in ((0, 1), (1, 0)):
@@ -406,6 +427,18 @@ def test_constant_folding_every_gate_and_position():
                     w = np.zeros((5, 4), np.uint8)
                     w[0], w[1] = [0, 0, 1, 1], [0, 1, 0, 1]
                     assert np.array_equal(c.evaluate_plain(nl, w)[4], c.evaluate_plain(opt, w)[4]), (name, pos, v, v2)
+    for name in ("MAJ", "XOR3"):                        # every subset of known inputs, every value
+        for mask in range(1, 27):
+            k = [(mask // 3 ** i) % 3 for i in range(3)]
+            nl = [Gate(OPS["CONST0"], -1, -1, -1, 3), Gate(OPS["CONST1"], -1, -1, -1, 4)]
+            ins = [i if k[i] == 0 else 2 + k[i] for i in range(3)]
+            nl.append(Gate(OPS[name], ins[0], ins[1], ins[2], 5))
+            opt = c.fold_constants(nl, [5])
+            assert circuit_bootstraps(opt) <= (1 if k.count(0) == 2 else 0), (name, k)
+            w = np.zeros((6, 8), np.uint8)
+            for j in range(8):
+                w[0, j], w[1, j], w[2, j] = j & 1, (j >> 1) & 1, (j >> 2) & 1
+            assert np.array_equal(c.evaluate_plain(nl, w)[5], c.evaluate_plain(opt, w)[5]), (name, k)
     for mask in range(1, 27):                           # MUX: each of selector / branches unknown, 0 or 1 (base 3 digits)
         k = [(mask // 3 ** i) % 3 for i in range(3)]
         nl = [Gate(OPS["CONST0"], -1, -1, -1, 3), Gate(OPS["CONST1"], -1, -1, -1, 4)]
@@ -425,8 +458,11 @@ def test_form_is_picked_by_instance_count():
         assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k != "ripple"}, 8, S)[0] == "prefix"
         assert c.pick_form(c.LESS_THAN_FORMS, 8, S)[0] == "tree"
     for S in (1024, 4096, 100000):
-        assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k != "ripple"}, 8, S)[0] == "mux"
-        assert c.pick_form(c.LESS_THAN_FORMS, 8, S)[0] == "ripple"
+        assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k != "ripple"}, 8, S)[0] == "maj"
+        assert c.pick_form(c.LESS_THAN_FORMS, 8, S)[0] == "maj"
+        # inside libtfhe's gate family the MUX-carry adder and the ripple comparator are the wide-batch forms
+        assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k in ("mux", "prefix")}, 8, S)[0] == "mux"
+        assert c.pick_form({k: v for k, v in c.LESS_THAN_FORMS.items() if k != "maj"}, 8, S)[0] == "ripple"
     for S, depth in ((1, 5), (4096, 9)):
         gates, nw, a, b, mn, mx = c.min_max_for(8, S)
         assert c.bootstrap_depth(gates) == depth
@@ -438,7 +474,7 @@ def test_form_is_picked_by_instance_count():
         r = c.evaluate_plain(gates, w)
         assert np.array_equal(_value(r, mn), np.minimum(A, B)) and np.array_equal(_value(r, mx), np.maximum(A, B))
     small, wide = c.adder(8, 8)[0], c.adder(8, 4096)[0]
-    assert c.bootstrap_depth(small) == 5 and circuit_bootstraps(wide) == 30
+    assert c.bootstrap_depth(small) == 5 and circuit_bootstraps(wide) == 16
     # the estimate: below a quarter of the resident set a level costs the same whatever its width
     g = c.prefix_adder(8)[0]
     assert c.netlist_cost(g, 1) == c.netlist_cost(g, 8) == 18 * 5
@@ -481,4 +517,42 @@ def test_netlist_entry_points_survive_malformed_input(built_lib):
     as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
     assert as_t(eoc.netlist_optimize(a, [5])) == as_t(eoc.netlist_optimize(b, [5])) == as_t(c.optimize(b, [5]))
     assert eoc.netlist_levels(a) == eoc.netlist_levels(b) and eoc.netlist_cost(a, 9) == eoc.netlist_cost(b, 9)
+
+
+def test_levelised_execution_equals_sequential_on_netlists_with_hazards(built_lib):
+    """the engine's levels (eoc_levelise: a level = a pre-pass slot for free gates + a slot for bootstrapped gates; a gate
+    takes the earliest slot of its kind after its RAW / WAR / WAW hazards, so NOT / COPY / CONSTANT cost no level).  Property,
+    on 2 000 random netlists that re-use wires freely: running level by level -- all free gates of a level IN PARALLEL on
+    the state before the pre-pass, then all its bootstrapped gates in parallel on the state after it -- gives exactly what
+    running the gates one after the other gives.  Native and Python levelisers agree."""
+    import eoc_tfhe_amd as eoc
+    rng = np.random.default_rng(5)
+    boot = [OPS[k] for k in ("NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "MAJ", "XOR3")]
+    free = [OPS[k] for k in ("NOT", "COPY", "CONST0", "CONST1")]
+    for trial in range(2000):
+        n_wires, n_g = int(rng.integers(4, 12)), int(rng.integers(1, 30))
+        gates = []
+        for _ in range(n_g):
+            op = int(rng.choice(boot + free + free))
+            i0, i1, i2, o = (int(x) for x in rng.integers(0, n_wires, 4))
+            ni = 0 if op in (13, 14) else 1 if op in (11, 12) else 3 if op in (10, 15, 16) else 2
+            gates.append(Gate(op, i0 if ni >= 1 else -1, i1 if ni >= 2 else -1, i2 if ni >= 3 else -1, o))
+        w = rng.integers(0, 2, (n_wires, 8)).astype(np.uint8)
+        seq = c.evaluate_plain(gates, w)
+        lev, nlev, depth = eoc.netlist_levels(gates)
+        assert lev == c.levels(gates) and depth == c.bootstrap_depth(gates), trial
+        for L in range(1, nlev + 1):
+            for kind_free in (True, False):
+                snap, new = w.copy(), w.copy()
+                for g, l in zip(gates, lev):
+                    if l == L and (c._boots(g) == 0) == kind_free:
+                        new[g.out] = c.evaluate_plain([g], snap)[g.out]
+                w = new
+        assert np.array_equal(w, seq), trial
+    # a free gate costs no level: NOT s; AND(s, x); AND(NOT s, y); OR  ->  two blind rotations deep, not three
+    g = [Gate(OPS["NOT"], 0, -1, -1, 3), Gate(OPS["AND"], 0, 1, -1, 4), Gate(OPS["AND"], 3, 2, -1, 5), Gate(OPS["OR"], 4, 5, -1, 6)]
+    assert eoc.netlist_levels(g) == ([1, 1, 1, 2], 2, 2)
+    # a chain of free gates takes one pre-pass each (they run as ONE parallel launch per level)
+    g = [Gate(OPS["NOT"], 0, -1, -1, 2), Gate(OPS["COPY"], 2, -1, -1, 3), Gate(OPS["AND"], 3, 1, -1, 4)]
+    assert eoc.netlist_levels(g) == ([1, 2, 2], 2, 1)
 

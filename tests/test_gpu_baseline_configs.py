@@ -97,17 +97,22 @@ def _run_adder(eoc, rig, gates, n_wires, aw, bw, sw, S, seed):
 
 @pytest.mark.parametrize("S", [4096, 8])
 def test_config3_adder_rewritten_and_log_depth_forms(eoc, rig, S):
-    """VERDICT r5 task 1: BASELINE configs[2]'s literal 40-gate netlist through eoc_netlist_optimize (carry rewrite +
-    constant folding: 30 bootstraps on 8 levels), the MUX-carry adder written directly and the parallel-prefix adder
+    """VERDICT r5 task 1: BASELINE configs[2]'s literal 40-gate netlist through eoc_netlist_optimize -- with the extension
+    gates (a full adder = XOR3 + MAJ: 16 bootstraps on 8 levels) and inside libtfhe's gate family (the carry as MUX +
+    constant folding: 30 on 8) --, the XOR3 / MAJ and MUX-carry adders written directly and the parallel-prefix adder
     (48 bootstraps on 5 levels), over 4096 pairs and over 8: all sums decrypt, and EVERY wire the rewritten netlist writes
     equals the oracle's evaluation of that rewritten netlist on the first 16 (or all 8) instances, bit for bit"""
     from eoc_tfhe_amd import circuits
     lit, n_wires, aw, bw, sw = circuits.ripple_carry_adder(8, carry_in_zero=True)
+    as_t = lambda gs: [(g.op, g.in0, g.in1, g.in2, g.out) for g in gs]
     opt = eoc.netlist_optimize(lit, sw)
-    assert [(g.op, g.in0, g.in1, g.in2, g.out) for g in opt] == [(g.op, g.in0, g.in1, g.in2, g.out) for g in circuits.optimize(lit, sw)]
-    assert eoc.circuit_bootstraps(opt) == 30 and eoc.netlist_levels(opt)[2] == 8
+    boots_only = eoc.netlist_optimize(lit, sw, extension_gates=False)
+    assert as_t(opt) == as_t(circuits.optimize(lit, sw)) and as_t(boots_only) == as_t(circuits.optimize(lit, sw, False))
+    assert eoc.circuit_bootstraps(opt) == 16 and eoc.netlist_levels(opt)[2] == 8
+    assert eoc.circuit_bootstraps(boots_only) == 30 and eoc.netlist_levels(boots_only)[2] == 8
     forms = [("optimized literal", (opt, n_wires, aw, bw, sw)), ("mux carry", circuits.mux_carry_adder(8)),
-             ("prefix", circuits.prefix_adder(8))]
+             ("prefix", circuits.prefix_adder(8)), ("optimized literal, boots* gates only", (boots_only, n_wires, aw, bw, sw)),
+             ("maj", circuits.maj_adder(8))]
     assert eoc.netlist_levels(forms[2][1][0])[2] == 5
     orc = ol.Oracle(0, 1)
     for name, (gates, nw, a, b, s) in forms:
@@ -117,15 +122,15 @@ def test_config3_adder_rewritten_and_log_depth_forms(eoc, rig, S):
         got = wires[:, :k].cpu().numpy()
         for g in gates:
             assert np.array_equal(got[g.out], want[g.out]), f"{name}: wire {g.out} (op {g.op})"
-    # the chooser: 8 instances take the prefix form, 4096 the MUX-carry form (the engine's own resident set)
+    # the chooser: 8 instances take the prefix form, 4096 the XOR3 / MAJ form (the engine's own resident set)
     assert circuits.pick_form({k: v for k, v in circuits.ADDER_FORMS.items() if k != "ripple"}, 8, S,
-                              rig[2].resident_jobs() // 2)[0] == ("prefix" if S == 8 else "mux")
+                              rig[2].resident_jobs() // 2)[0] == ("prefix" if S == 8 else "maj")
 
 
 @pytest.mark.parametrize("S", [1024, 8])
 def test_less_than_tree_and_ripple_bit_exact(eoc, rig, S):
-    """the log-depth comparator (29 bootstraps on 4 levels) and the ripple one (22 on 8): decrypt to a < b, every written
-    wire of the first 16 instances equals the oracle's"""
+    """the log-depth comparator (29 bootstraps on 4 levels), the ripple one (22 on 8) and the MAJ chain (8 on 8: the borrow
+    of a - b, one bootstrap per bit): decrypt to a < b, every written wire of the first 16 instances equals the oracle's"""
     from eoc_tfhe_amd import circuits
     p, sk, eng = rig
     torch = torch_cuda()
@@ -133,7 +138,7 @@ def test_less_than_tree_and_ripple_bit_exact(eoc, rig, S):
     rng = np.random.default_rng(17)
     A, B = rng.integers(0, 256, S), rng.integers(0, 256, S)
     B[::5] = A[::5]                                             # equal operands: a < b is false through every EQ
-    for build in (circuits.less_than_tree, circuits.less_than):
+    for build in (circuits.less_than_tree, circuits.less_than, circuits.maj_less_than):
         gates, n_wires, aw, bw, lt = build(8)
         wires = torch.zeros((n_wires, S, p.n + 1), dtype=torch.int32, device="cuda")
         wires[aw[0]: aw[0] + 8] = to_dev(_enc_planes(sk, ((A[:, None] >> np.arange(8)) & 1).astype(np.uint8), 6000))

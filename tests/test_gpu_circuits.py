@@ -173,7 +173,7 @@ def test_string_api_and_host_batch_api(eoc):
         Av, Bv = rng.integers(0, 256, 1200), rng.integers(0, 256, 1200)
         st0 = eoc.stats()
         sums = T.addBitsBatch(planes(Av), planes(Bv))
-        assert eoc.stats()["bootstraps"] - st0["bootstraps"] == 30 * 1200                               # MUX-carry adder
+        assert eoc.stats()["bootstraps"] - st0["bootstraps"] == 16 * 1200                               # XOR3 / MAJ adder
         assert np.array_equal(sum(eoc.global_decrypt_bits(sums[i]).astype(np.int64) << i for i in range(9)), Av + Bv)
         assert np.array_equal(eoc.global_decrypt_bits(T.lessThanBitsBatch(planes(Av), planes(Bv))), (Av < Bv).astype(np.uint8))
         word = lambda w: sum(eoc.global_decrypt_bits(w[i]).astype(np.int64) << i for i in range(w.shape[0]))
@@ -460,9 +460,12 @@ def test_subtractor_and_multiplier_bit_exact(eoc):
     p, sk, eng, orc = _setup(eoc, 0, 6, 28)
     S = 21
     rng = np.random.default_rng(12)
+    w4 = circuits.MULTIPLIER_FORMS["wallace"](4)[0]
+    c4 = (eoc.circuit_bootstraps(w4), circuits.bootstrap_depth(w4))
     for build, nbits, expect in ((circuits.subtractor, 5, lambda a, b: (a - b) % 32), (circuits.multiplier, 3, lambda a, b: a * b),
                                  (circuits.prefix_subtractor, 5, lambda a, b: (a - b) % 32),        # round 6: log-depth form
                                  (circuits.prefix_subtractor, 8, lambda a, b: (a - b) % 256),
+                                 (circuits.maj_subtractor, 8, lambda a, b: (a - b) % 256),         # XOR3 + MAJ(NOT a, b, borrow)
                                  (circuits.wallace_multiplier, 4, lambda a, b: a * b),             # column compression + prefix addition
                                  (lambda n: circuits.multiplier_for(n, S), 4, lambda a, b: a * b)): # ... after eoc_netlist_optimize
         res = build(nbits)
@@ -477,7 +480,7 @@ def test_subtractor_and_multiplier_bit_exact(eoc):
         for g in gates:
             assert np.array_equal(got[g.out], want[g.out]), (build.__name__, g.out)
         if build.__name__ == "<lambda>":
-            assert eoc.circuit_bootstraps(gates) == 65 and eoc.netlist_levels(gates)[2] == 10      # the Wallace form, optimized
+            assert eoc.circuit_bootstraps(gates) == c4[0] and eoc.netlist_levels(gates)[2] == c4[1]  # the column form, optimized
         val = sum(sk.decrypt_bits(got[w]).astype(np.int64) << i for i, w in enumerate(outw))
         assert np.array_equal(val, expect(A, B)), build.__name__
         if "subtractor" in build.__name__:

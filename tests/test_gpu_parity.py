@@ -185,6 +185,34 @@ def test_gates_small_bit_exact(eoc, rig_small, name):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("pset,n,widths", [(0, 24, (1, 9, 130)), (1, 20, (7,)), (0, 500, (5, 1030, 2300))],
+                         ids=["setA-small", "setB-small", "setA-full-pair-and-wide"])
+def test_extension_gates_maj_and_xor3_bit_exact(eoc, pset, n, widths):
+    """round 6: the extension gates -- EOC_MAJ (t = a + b + c: a full adder's carry) and EOC_XOR3 (t = -2 (a + b + c): its sum),
+    one bootstrap each behind a three-operand linear stage (k_prepare; the folded key-switch set-up stays).  Bit for bit against
+    the oracle on both kernels (1 030 rows = a full pair launch + remainder, 2 300 = a wide launch + a pair remainder), both
+    parameter sets, and through the truth table on all eight input combinations; inputs that are themselves gate outputs;
+    a mixed batch and a netlist that contain them"""
+    r = Rig(eoc, pset, 13, n_override=None if n in (500, 630) else n)
+    for cnt in widths:
+        bits, cts = zip(*[_rand_cts(r, cnt, 300 + k, 40 * k) for k in range(3)])
+        sample = slice(None) if r.n < 100 else np.random.default_rng(cnt).choice(cnt, min(cnt, 24), replace=False)
+        for name, truth in (("MAJ", (bits[0].astype(int) + bits[1] + bits[2]) >= 2), ("XOR3", bits[0] ^ bits[1] ^ bits[2])):
+            got = r.gate(eoc.OPS[name], cts[0], cts[1], cts[2])
+            assert np.array_equal(r.sk.decrypt_bits(got), truth.astype(np.uint8)), (name, cnt)
+            assert np.array_equal(got[sample], r.orc.gate_batch(ol.OPS[name], cts[0][sample], cts[1][sample], cts[2][sample])), (name, cnt)
+    b8 = [np.array([(k >> j) & 1 for k in range(8)], np.uint8) for j in range(3)]
+    c8 = [r.sk.encrypt_bits(b8[j], 900 + j, 0) for j in range(3)]
+    maj, x3 = r.gate(eoc.OPS["MAJ"], *c8), r.gate(eoc.OPS["XOR3"], *c8)
+    assert np.array_equal(r.sk.decrypt_bits(maj), (b8[0] + b8[1] + b8[2] >= 2)) and np.array_equal(r.sk.decrypt_bits(x3), b8[0] ^ b8[1] ^ b8[2])
+    # outputs of bootstrapped gates as inputs (a carry chain step): MAJ(XOR3(a, b, c), MAJ(a, b, c), c)
+    got = r.gate(eoc.OPS["MAJ"], x3, maj, c8[2])
+    assert np.array_equal(got, r.orc.gate_batch(ol.OPS["MAJ"], x3, maj, c8[2]))
+    ops = np.array([15, 0, 16, 10, 16, 15, 11, 4], np.uint8)
+    assert np.array_equal(r.gate(0, *c8, ops=ops), r.orc.gate_batch(0, *c8, ops=ops))
+    r.eng.close()
+
+
 def test_mux_not_copy_small(eoc, rig_small):
     r = rig_small
     _, a = _rand_cts(r, 5, 31)
@@ -430,7 +458,7 @@ def test_mixed_ops_arbitrary_order_large(eoc, rig_small):
 
 @pytest.mark.parametrize("no_fold", [False, True], ids=["folded", "unfolded"])
 def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
-    """A mixed batch over ALL fifteen opcodes in arbitrary order: the ten two-input opcodes differ only in their linear
+    """A mixed batch over ALL seventeen opcodes (the extension gates MAJ and XOR3 are groups of their own) in arbitrary order: the ten two-input opcodes differ only in their linear
     stage and form ONE group (one descriptor, the row's opcode read per job: OP_MULTI) instead of one partly filled
     launch per opcode; the MUX run is a second group; both share ONE blind rotation over the concatenated jobs (round 6:
     one pool per call -- one partly filled last launch instead of two); NOT / COPY / CONSTANT take no bootstrap.  Row for
@@ -441,8 +469,8 @@ def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
     r = Rig(eoc, 0, 7, n_override=31)
     cnt = 700
     rng = np.random.default_rng(144)
-    ops = rng.integers(0, 15, cnt).astype(np.uint8)
-    assert len(set(ops.tolist())) == 15
+    ops = rng.integers(0, 17, cnt).astype(np.uint8)
+    assert len(set(ops.tolist())) == 17
     _, a = _rand_cts(r, cnt, 145)
     _, b = _rand_cts(r, cnt, 146)
     _, c = _rand_cts(r, cnt, 147)
@@ -458,9 +486,9 @@ def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
     assert np.array_equal(got, want)
     assert after["batches"] - before["batches"] == 1                  # the two-input block and the MUX run: one pool
     assert kt["blind_rotate"]["launches"] == 1, kt                    # ONE blind-rotate span for the whole mixed call
-    assert kt["keyswitch"]["launches"] == 2, kt                       # a key switch per group (j rows, m rows)
+    assert kt["keyswitch"]["launches"] == 4, kt                       # a key switch per group: two-input, MUX, MAJ, XOR3
     n_mux = int((ops == eoc.OPS["MUX"]).sum())
-    assert after["bootstraps"] - before["bootstraps"] == int((ops < 10).sum()) + 2 * n_mux
+    assert after["bootstraps"] - before["bootstraps"] == int((ops < 10).sum()) + 2 * n_mux + int((ops >= 15).sum())
     # few runs (no gather): every bootstrapped run is a group of the same pool -- NAND run, MUX run, XOR run, free run
     ops3 = np.concatenate([np.full(200, 0), np.full(150, 10), np.full(250, 4), np.full(100, 11)]).astype(np.uint8)
     r.eng.set_profiling(True)
@@ -471,7 +499,7 @@ def test_mixed_all_opcodes_run_as_one_level(eoc, no_fold, monkeypatch):
     assert np.array_equal(got3, r.orc.gate_batch(0, a, b, c, ops=ops3))
     assert kt3["blind_rotate"]["launches"] == 1 and kt3["keyswitch"]["launches"] == 3, kt3
     # a batch with a single two-input opcode among free gates keeps its plain descriptor (and the folded single-level path)
-    ops2 = np.where(ops < 10, 4, np.where(ops == 10, 11, ops)).astype(np.uint8)
+    ops2 = np.where(ops < 10, 4, np.where((ops == 10) | (ops >= 15), 11, ops)).astype(np.uint8)
     assert np.array_equal(r.gate(0, a, b, c, ops=ops2), r.orc.gate_batch(0, a, b, c, ops=ops2))
     # in place (out = in0) through the pool: rows are independent, every group reads its rows before any group writes
     da, db, dc = to_dev(a), to_dev(b), to_dev(c)

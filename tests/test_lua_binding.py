@@ -5,7 +5,7 @@ This tests THIS REPOSITORY'S C (argument marshalling, length arithmetic, NULL ->
 real library; it does not test Lua, and the Lua facade text (integration/lua/tfhe_gates.lua) still has no interpreter
 (tests/test_binding_surfaces.py keeps it in step with the executed JS twin).
 
-  * CPU: tests/c/lua_binding_driver.c drives all 32 entries (client-side calls, cloud-key export / import through strings
+  * CPU: tests/c/lua_binding_driver.c drives all 34 entries (client-side calls, cloud-key export / import through strings
     and files, netlist helpers, every refusal and every luaL_check* error) -- plain build and ASan/UBSan build;
   * GPU: the same double driven from Python: l_generateGateKey, l_encryptBits, l_gateBatch (NAND, MUX, mixed opcodes) and
     l_circuitRun against the CPU oracle bit for bit, wrong-length and nil operands refused with nil.
@@ -48,7 +48,7 @@ def _driver(tmp_path, extra, cc="gcc"):
 def test_lua_binding_compiles_and_runs_cpu_legs(tmp_path, key_file):
     exe = _driver(tmp_path, ["-O1"])
     r = subprocess.run([exe, *key_file], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "lua_binding_driver OK: 32 entries" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "lua_binding_driver OK: 34 entries" in r.stdout, (r.stdout + r.stderr)[-3000:]
     # the reference's stderr conventions come through the binding (eoc-tfhe-run.cpp:277-278, :465-468)
     assert "Secret key not initialized" in r.stderr
 

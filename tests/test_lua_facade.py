@@ -25,7 +25,7 @@ import minilua as ml  # noqa: E402
 
 FACADE = os.path.join(ROOT, "integration", "lua", "tfhe_gates.lua")
 OPS = dict(NAND=0, AND=1, OR=2, NOR=3, XOR=4, XNOR=5, ANDNY=6, ANDYN=7, ORNY=8, ORYN=9, MUX=10, NOT=11, COPY=12, CONST0=13,
-           CONST1=14)
+           CONST1=14, MAJ=15, XOR3=16)
 
 
 # ---- the interpreter ------------------------------------------------------------------------------------------------
@@ -81,6 +81,8 @@ def gate_eval(op, a, b, c):
     if op == OPS["NOT"]: return 1 - a
     if op == OPS["COPY"]: return a
     if op == OPS["CONST0"]: return np.zeros_like(a)
+    if op == OPS["MAJ"]: return ((a + b + c) >= 2).astype(a.dtype)
+    if op == OPS["XOR3"]: return a ^ b ^ c
     return np.ones_like(a)
 
 
@@ -90,7 +92,7 @@ def run_packed(packed, bits):
     z = np.zeros_like(bits[0])
     for op, i0, i1, i2, out in g:
         bits[out] = gate_eval(op, bits[i0] if i0 >= 0 else z, bits[i1] if i1 >= 0 else z, bits[i2] if i2 >= 0 else z)
-    return len(g), int(sum(2 if op == OPS["MUX"] else (0 if op >= OPS["NOT"] else 1) for op, *_ in g))
+    return len(g), int(sum(2 if op == OPS["MUX"] else (0 if OPS["NOT"] <= op <= OPS["CONST1"] else 1) for op, *_ in g))
 
 
 class PlainBackend:
@@ -165,7 +167,7 @@ def value_of(buf, instances):
 def test_facade_defines_its_functions_and_passes_through(facade):
     it, tf, be = facade
     for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
-                 "muxAdderNetlist", "prefixAdderNetlist", "prefixSubtractorNetlist", "wallaceMultiplierNetlist", "multiplierNetlistFor", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
+                 "muxAdderNetlist", "majAdderNetlist", "majSubtractorNetlist", "majLessThanNetlist", "maj", "xor3", "prefixAdderNetlist", "prefixSubtractorNetlist", "wallaceMultiplierNetlist", "multiplierNetlistFor", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
                  "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
                  "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
         assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
@@ -215,7 +217,8 @@ def test_netlist_builders_on_plaintext(facade, nbits):
     assert len(prod) == 2 * nbits and np.array_equal(word(bits, prod), A * B)
     # round 6: the forms picked by instance count -- gate for gate the Python circuit layer's netlists
     from eoc_tfhe_amd import circuits
-    for lua_name, py in (("muxAdderNetlist", circuits.mux_carry_adder), ("prefixAdderNetlist", circuits.prefix_adder)):
+    for lua_name, py in (("muxAdderNetlist", circuits.mux_carry_adder), ("prefixAdderNetlist", circuits.prefix_adder),
+                         ("majAdderNetlist", circuits.maj_adder)):
         nl, a, b, s = call(it, tf, lua_name, nbits)
         bits, (ngates, boots) = evaluate(nl, a, b)
         assert np.array_equal(word(bits, ml.to_python(s)), A + B), lua_name
@@ -225,9 +228,16 @@ def test_netlist_builders_on_plaintext(facade, nbits):
     bits, (ngates, boots) = evaluate(nl, a, b)
     assert np.array_equal(word(bits, ml.to_python(prod)), A * B)
     pg = circuits.wallace_multiplier(nbits)[0]
-    assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 0 if g.op >= 11 else 1 for g in pg))
+    assert (ngates, boots) == (len(pg), sum(2 if g.op == 10 else 0 if 11 <= g.op <= 14 else 1 for g in pg))
     # ... gate for gate the Python builder's netlist (same wire numbering: the (level, wire) order of a column is part of it)
     assert it.call(nl.get(b"packed"), [])[0] == b"".join(struct.pack("<5i", g.op, g.in0, g.in1, g.in2, g.out) for g in pg)
+    nl, a, b, diff, br = call(it, tf, "majSubtractorNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(word(bits, ml.to_python(diff)), (A - B) % (1 << nbits)) and np.array_equal(bits[br], (A < B).astype(np.int64))
+    assert boots == 2 * nbits
+    nl, a, b, lt = call(it, tf, "majLessThanNetlist", nbits)
+    bits, (ngates, boots) = evaluate(nl, a, b)
+    assert np.array_equal(bits[lt], (A < B).astype(np.int64)) and boots == nbits
     nl, a, b, diff, br = call(it, tf, "prefixSubtractorNetlist", nbits)
     bits, (ngates, boots) = evaluate(nl, a, b)
     assert np.array_equal(word(bits, ml.to_python(diff)), (A - B) % (1 << nbits)) and np.array_equal(bits[br], (A < B).astype(np.int64))
@@ -269,17 +279,17 @@ def test_forms_are_picked_by_instance_count(facade):
 
     def shape(nl):
         g = [Gate(*map(int, row)) for row in np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)]
-        return sum(2 if x.op == 10 else 0 if x.op >= 11 else 1 for x in g), circuits.bootstrap_depth(g)
+        return sum(2 if x.op == 10 else 0 if 11 <= x.op <= 14 else 1 for x in g), circuits.bootstrap_depth(g)
 
-    for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (30, 8), (22, 8))):
+    for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (16, 8), (8, 8))):
         assert shape(call(it, tf, "adderNetlistFor", 8, inst)[0]) == add_want, inst
         assert shape(call(it, tf, "lessThanNetlistFor", 8, inst)[0]) == lt_want, inst
-    assert shape(call(it, tf, "multiplierNetlistFor", 8, 2)[0]) == (328, 16)
+    assert shape(call(it, tf, "multiplierNetlistFor", 8, 2)[0]) == (244, 11)
     assert shape(call(it, tf, "multiplierNetlistFor", 8, 4096)[0]) == (320, 40)
     assert shape(call(it, tf, "subtractorNetlistFor", 8, 2)[0]) == (48, 5)
-    assert shape(call(it, tf, "subtractorNetlistFor", 8, 4096)[0]) == (30, 8)
+    assert shape(call(it, tf, "subtractorNetlistFor", 8, 4096)[0]) == (16, 8)
     assert shape(call(it, tf, "minMaxNetlistFor", 8, 1)[0]) == (29 + 32, 5)
-    assert shape(call(it, tf, "minMaxNetlistFor", 8, 4096)[0]) == (22 + 32, 9)
+    assert shape(call(it, tf, "minMaxNetlistFor", 8, 4096)[0]) == (8 + 32, 9)
     A = np.array([200, 13, 255]); B = np.array([100, 250, 255])
     lo, hi, lt = call(it, tf, "minMaxBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)
     assert np.array_equal(value_of(lo, 3), np.minimum(A, B)) and np.array_equal(value_of(hi, 3), np.maximum(A, B))
@@ -297,9 +307,9 @@ def test_batch_functions_pack_and_slice_wires(facade):
     pa, pb = planes_of(A, nbits, S), planes_of(B, nbits, S)
     out = call(it, tf, "addBitsBatch", pa, pb, nbits, S)[0]
     assert len(out) == (nbits + 1) * S * ROW * 4 and np.array_equal(value_of(out, S), A + B)
-    # the form is picked by the instance count: at 4 bits the MUX-carry adder (3 nbits - 1 gates) is as shallow as the
-    # prefix form and cheaper
-    assert be.calls[-1] == ("circuitRun", 3 * nbits - 1, be.calls[-1][2], S)
+    # the form is picked by the instance count: at 4 bits the XOR3 / MAJ adder (2 nbits gates) is as shallow as the prefix
+    # form and cheaper
+    assert be.calls[-1] == ("circuitRun", 2 * nbits, be.calls[-1][2], S)
     out = call(it, tf, "subtractBitsBatch", pa, pb, nbits, S)[0]
     v = value_of(out, S)
     assert np.array_equal(v & 15, (A - B) % 16) and np.array_equal(v >> 4, (A < B).astype(np.int64))
@@ -375,10 +385,10 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
         assert np.array_equal(dec(lo), np.minimum(A, B)) and np.array_equal(dec(hi), np.maximum(A, B))
         assert np.array_equal(dec(lt), (A < B).astype(np.int64))
         # the adder's bytes against the oracle: the facade's netlist, gate by gate
-        # (the form addBitsBatch picked for 6 instances: the MUX-carry adder at 4 bits)
+        # (the form addBitsBatch picked for 6 instances: the XOR3 / MAJ adder at 4 bits)
         nl, a, b, s = call(it, tf, "adderNetlistFor", nbits, S)
         g = np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)
-        assert (g[:, 0] == OPS["MUX"]).sum() == nbits - 1
+        assert (g[:, 0] == OPS["MAJ"]).sum() == nbits - 1 and (g[:, 0] == OPS["XOR3"]).sum() == nbits - 1
         wires = np.zeros((nl.get(b"nWires"), S, 501), np.int32)
         wires[a:a + nbits] = np.frombuffer(ea, np.int32).reshape(nbits, S, 501)
         wires[b:b + nbits] = np.frombuffer(eb, np.int32).reshape(nbits, S, 501)

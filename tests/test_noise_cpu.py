@@ -97,8 +97,9 @@ def test_prediction_terms_setA_by_hand():
 def test_every_circuit_form_stays_inside_the_noise_budget():
     """round 6: the netlist compiler chains MUX outputs (2 V_BR + V_KS) into selectors and XORs more than the textbook
     forms do.  With the per-key predicted V_BR / V_KS of both default sets every blind rotation of every shipped form --
-    as written and after eoc_netlist_optimize -- keeps at least 12 standard deviations to its decision boundary (failure
-    probability below 1e-32 per gate); the worst input in the library is an XOR of two MUX outputs (~15 sigma on Set A)"""
+    as written and after eoc_netlist_optimize, with and without the extension gates -- keeps at least 12 standard deviations
+    to its decision boundary (failure probability below 1e-32 per gate); the worst input the gate set allows at all, an XOR3
+    of three MUX outputs, still has 13"""
     from eoc_tfhe_amd import circuits as c
     for pset in (0, 1):
         o = ol.Oracle(pset, 1)
@@ -107,20 +108,24 @@ def test_every_circuit_form_stays_inside_the_noise_budget():
         fresh = float(o.p.ks_stdev) ** 2
         forms = [c.ripple_carry_adder(8, carry_in_zero=True), c.mux_carry_adder(8), c.prefix_adder(8), c.prefix_adder(16),
                  c.subtractor(8), c.prefix_subtractor(8), c.less_than(8), c.less_than_tree(8), c.min_max_for(8, 1),
-                 c.multiplier(4), c.wallace_multiplier(8), c.string_equal(4)]
+                 c.multiplier(4), c.wallace_multiplier(8), c.wallace_multiplier(8, False), c.string_equal(4),
+                 c.maj_adder(8), c.maj_subtractor(8), c.maj_less_than(8), c.min_max_for(8, 4096), c.multiplier(8)]
         worst = []
         for built in forms:
             gates = built[0]
             outs = built[-1] if isinstance(built[-1], list) else [built[-1]]
-            for nl in (gates, c.optimize(gates, outs)):
+            for nl in (gates, c.optimize(gates, outs), c.optimize(gates, outs, extension_gates=False)):
                 m, k = c.noise_margin(nl, fresh, pred["br_var"], pred["ks_var"], v_ms)
                 worst.append(m)
                 assert m > 12.0, (pset, len(nl), m, k)
-        # the single worst case by construction: XOR of two MUX outputs
+        # the worst inputs the gate set allows: an XOR of two MUX outputs, and an XOR3 of three (no shipped form has the latter)
         g = [Gate_(10, 0, 1, 2, 6), Gate_(10, 3, 4, 5, 7), Gate_(4, 6, 7, -1, 8)]
-        m, k = c.noise_margin(g, fresh, pred["br_var"], pred["ks_var"], v_ms)
-        assert k == 2 and 12.0 < m <= min(worst) + 1e-9, (m, min(worst))
-        print(f"set {'AB'[pset]}: smallest margin over the shipped forms {min(worst):.1f} sigma, XOR of two MUX outputs {m:.1f} sigma")
+        m2, k = c.noise_margin(g, fresh, pred["br_var"], pred["ks_var"], v_ms)
+        g = [Gate_(10, 0, 1, 2, 6), Gate_(10, 3, 4, 5, 7), Gate_(10, 0, 3, 5, 8), Gate_(16, 6, 7, 8, 9)]
+        m3, k3 = c.noise_margin(g, fresh, pred["br_var"], pred["ks_var"], v_ms)
+        assert k == 2 and k3 == 3 and 12.0 < m3 < m2 and m3 <= min(worst) + 1e-9, (m2, m3, min(worst))
+        print(f"set {'AB'[pset]}: smallest margin over the shipped forms {min(worst):.1f} sigma; XOR of two MUX outputs {m2:.1f}, "
+              f"XOR3 of three MUX outputs {m3:.1f} sigma")
 
 
 def Gate_(op, i0, i1, i2, out):

@@ -272,6 +272,37 @@ def test_gate_linear_stage_and_modswitch_by_a_numpy_restatement():
                 assert np.array_equal(bara, ms[:o.n]) and barb[0] == ms[o.n], name
 
 
+def test_extension_gates_maj_and_xor3_linear_stage_and_truth(orc_a):
+    """round 6: the extension gates are NOT libtfhe functions -- they are libtfhe's primitives composed the way bootsXOR is
+    (lweAddTo / lweAddMulTo over the inputs, then tfhe_bootstrap_FFT with mu = 1/8): MAJ  t = a + b + c,  XOR3  t = -2 (a + b + c).
+    Restated in numpy from that one line each: for all eight input combinations the phase of t has the sign of the majority /
+    the parity with the margins the header states (|phase| within noise of 1/8 or 3/8, resp. 1/4), the oracle's output is its
+    own bootstrap of exactly that t (bit for bit), and it decrypts; then at Set A's full size through a carry chain."""
+    o = ol.Oracle(0, 3, n_override=64)
+    for k in range(8):
+        bits = [(k >> j) & 1 for j in range(3)]
+        cts = [o.encrypt_bits([bits[j]], 60 + 3 * k + j, 0)[0] for j in range(3)]
+        ssum = sum(x.astype(np.int64) for x in cts)
+        for name, scale, truth in (("MAJ", 1, int(sum(bits) >= 2)), ("XOR3", -2, bits[0] ^ bits[1] ^ bits[2])):
+            t = ((scale * ssum) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+            phase = ((int(t[o.n]) - int((t[:o.n].astype(np.int64) * o.lwe_key).sum()) + 2**31) % 2**32 - 2**31) / 2**32
+            assert (phase > 0) == bool(truth), (name, bits, phase)
+            want_abs = 0.25 if name == "XOR3" else (0.375 if sum(bits) in (0, 3) else 0.125)
+            assert abs(abs(phase) - want_abs) < 1e-3, (name, bits, phase)
+            u = o.blind_rotate_extract(t)
+            assert np.array_equal(o.gate_batch(ol.OPS[name], cts[0][None], cts[1][None], cts[2][None])[0], o.keyswitch(u)), name
+    a = orc_a
+    rng = np.random.default_rng(5)
+    b = [rng.integers(0, 2, 48).astype(np.uint8) for _ in range(3)]
+    c = [a.encrypt_bits(b[j], 70 + j, 0) for j in range(3)]
+    carry, ssum = a.gate_batch(ol.OPS["MAJ"], *c), a.gate_batch(ol.OPS["XOR3"], *c)
+    assert np.array_equal(a.decrypt_bits(carry), (b[0] + b[1] + b[2] >= 2)) and np.array_equal(a.decrypt_bits(ssum), b[0] ^ b[1] ^ b[2])
+    nxt = a.gate_batch(ol.OPS["MAJ"], np.roll(c[0], 1, axis=0), np.roll(c[1], 1, axis=0), carry)   # a carry chain step
+    assert np.array_equal(a.decrypt_bits(nxt), (np.roll(b[0], 1) + np.roll(b[1], 1) + a.decrypt_bits(carry) >= 2))
+    ph = a.phases(carry) / 2**32
+    assert np.abs(ph - np.sign(ph) * 0.125).max() < 1 / 16
+
+
 def test_blind_rotate_frame_by_a_numpy_restatement(orc_a):
     """SURVEY.md A.4 / A.5 around the CMux steps, restated in numpy: ACC_0 = (0, X^(2N - barb) * (mu, ..., mu)), the loop
     over i with rotation amount bara[i] (a zero amount is the identity), and tLweExtractLweSample at index 0:

@@ -23,12 +23,17 @@ rng = np.random.default_rng(9)
 
 OPS = [
     ("add8", {"ripple as written": lambda: c.ripple_carry_adder(8, carry_in_zero=True), "mux-carry": lambda: c.mux_carry_adder(8),
-              "prefix": lambda: c.prefix_adder(8)}, lambda A, B: A + B, 8),
-    ("sub8", {"ripple": lambda: c.subtractor(8)[:5], "prefix": lambda: c.prefix_subtractor(8)[:5]}, lambda A, B: (A - B) % 256, 8),
-    ("lt8", {"ripple": lambda: c.less_than(8), "tree": lambda: c.less_than_tree(8)}, lambda A, B: (A < B).astype(np.int64), 8),
-    ("mul8", {"rows (optimized)": lambda: c.MULTIPLIER_FORMS["rows"](8), "wallace (optimized)": lambda: c.MULTIPLIER_FORMS["wallace"](8)},
-     lambda A, B: A * B, 8),
+              "xor3/maj": lambda: c.maj_adder(8), "prefix": lambda: c.prefix_adder(8)}, lambda A, B: A + B, 8),
+    ("sub8", {"ripple": lambda: c.subtractor(8)[:5], "xor3/maj": lambda: c.maj_subtractor(8)[:5],
+              "prefix": lambda: c.prefix_subtractor(8)[:5]}, lambda A, B: (A - B) % 256, 8),
+    ("lt8", {"ripple": lambda: c.less_than(8), "maj": lambda: c.maj_less_than(8), "tree": lambda: c.less_than_tree(8)},
+     lambda A, B: (A < B).astype(np.int64), 8),
+    ("mul8", {"rows as written": lambda: c.multiplier(8), "rows (optimized)": lambda: c.MULTIPLIER_FORMS["rows"](8),
+              "columns (optimized)": lambda: c.MULTIPLIER_FORMS["wallace"](8)}, lambda A, B: A * B, 8),
 ]
+# the forms the facades choose between (the others are shown for comparison)
+CANDIDATES = {"add8": ("xor3/maj", "prefix"), "sub8": ("xor3/maj", "prefix"), "lt8": ("maj", "tree"),
+              "mul8": ("rows (optimized)", "columns (optimized)")}
 worst = 0.0
 agree = total = 0
 for name, forms, truth, nbits in OPS:
@@ -57,8 +62,9 @@ for name, forms, truth, nbits in OPS:
             ok = bool(np.array_equal(got, truth(A, B)))
             est = eoc.netlist_cost(gates, S, R) / 10.0
             row[fname] = (ms, est, ok, eoc.circuit_bootstraps(gates), eoc.netlist_levels(gates)[2])
-        picked = min(row, key=lambda k: (row[k][1], row[k][3]))
-        fastest = min(row, key=lambda k: row[k][0])
+        cand = CANDIDATES[name]
+        picked = min(cand, key=lambda k: (row[k][1], row[k][3]))
+        fastest = min(cand, key=lambda k: row[k][0])
         total += 1
         agree += picked == fastest or row[picked][0] <= 1.03 * row[fastest][0]
         cells = []
@@ -66,5 +72,6 @@ for name, forms, truth, nbits in OPS:
             worst = max(worst, abs(ms / est - 1))
             cells.append(f"{k} [{boots}/{depth}] {ms:8.2f} ms (est {est:7.1f}){'*' if k == picked else ' '}{'<' if k == fastest else ' '}{'' if ok else ' WRONG'}")
         print(f"  S={S:5d}  " + " | ".join(cells), flush=True)
-print(f"picked form = measured-fastest (or within 3 % of it) in {agree} of {total} cases; worst |measured / estimate - 1| = {worst:.3f}")
+print(f"picked form (* : lowest estimate among the facades' candidates) = measured-fastest candidate (<, or within 3 % of it) in "
+      f"{agree} of {total} cases; worst |measured / estimate - 1| over all forms = {worst:.3f}")
 eng.close()

@@ -33,7 +33,8 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
     import oracle_lib as ol
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda", 0)
-    BOOT = [eoc.OPS[k] for k in ("NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")]
+    BOOT = [eoc.OPS[k] for k in ("NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "MAJ", "XOR3")]
+    THREE = (eoc.OPS["MUX"], eoc.OPS["MAJ"], eoc.OPS["XOR3"])
     FREE = [eoc.OPS[k] for k in ("NOT", "COPY", "CONST0", "CONST1")]
     t_end = time.time() + budget_s
     cases = bad = contexts = 0
@@ -66,7 +67,7 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
                     op = int(rng.choice(BOOT + FREE))
                     i0, i1, i2, o = (int(x) for x in rng.integers(0, n_wires, 4))
                     ni = (0 if op in (eoc.OPS["CONST0"], eoc.OPS["CONST1"]) else 1 if op in (eoc.OPS["NOT"], eoc.OPS["COPY"])
-                          else 3 if op == eoc.OPS["MUX"] else 2)
+                          else 3 if op in THREE else 2)
                     gates.append(eoc.Gate(op, i0 if ni >= 1 else -1, i1 if ni >= 2 else -1, i2 if ni >= 3 else -1, o))
                 wires = np.stack([sk.encrypt_bits(rng.integers(0, 2, S).astype(np.uint8), int(rng.integers(1, 1 << 30)), 0)
                                   for _w in range(n_wires)])
@@ -96,12 +97,12 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
                         continue
                     op = int(rng.choice(BOOT + FREE + [eoc.OPS["NOT"], eoc.OPS["MUX"]]))
                     ni = (0 if op in (eoc.OPS["CONST0"], eoc.OPS["CONST1"]) else 1 if op in (eoc.OPS["NOT"], eoc.OPS["COPY"])
-                          else 3 if op == eoc.OPS["MUX"] else 2)
+                          else 3 if op in THREE else 2)
                     gates.append(eoc.Gate(op, pick() if ni >= 1 else -1, pick() if ni >= 2 else -1, pick() if ni >= 3 else -1, out))
                     avail.append(out)
                 n_wires = n_in + len(gates)
                 outs = [int(v) for v in rng.choice(avail[n_in:], size=min(4, len(avail) - n_in), replace=False)]
-                opt = eoc.netlist_optimize(gates, outs)
+                opt = eoc.netlist_optimize(gates, outs, extension_gates=bool(rng.integers(0, 2)))
                 bits = rng.integers(0, 2, (n_in, S)).astype(np.uint8)
                 wires = np.zeros((n_wires, S, n + 1), np.int32)
                 for w_ in range(n_in):
