@@ -222,7 +222,9 @@ int eoc_gate_batch_device(eoc_engine *e, int op, const uint8_t *ops, const int32
 
 /* netlist evaluation: `instances` independent copies of one circuit.
  * wires: DEVICE array [n_wires][instances][n+1]; gate g reads wires in0,in1,in2 and writes out.
- * Gates must be topologically ordered; the engine levelises them and batches every level. */
+ * Gates must be topologically ordered; the engine levelises them (read-after-write, write-after-read and write-after-write
+ * hazards on wires: a netlist may re-use wires) and batches every level over all instances: one blind rotation for all
+ * bootstrapped gates of a level, preceded by one pre-pass for its free gates -- NOT / COPY / CONSTANT cost no level. */
 typedef struct eoc_gate {
     int32_t op;
     int32_t in0, in1, in2; /* wire ids (unused = -1) */
@@ -255,8 +257,8 @@ enum { EOC_NL_BOOTS_GATES_ONLY = 1 };
 int64_t eoc_netlist_optimize_ex(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
                                 eoc_gate *gates_out, unsigned flags);
 /* levels of a netlist exactly as eoc_circuit_run_device assigns them (RAW, WAR, WAW hazards; 1-based; level_of[n_gates] or
- * NULL); *bootstrap_levels (or NULL) = levels that hold at least one blind rotation -- the sequential depth a small batch
- * pays for.  Returns the number of levels. */
+ * NULL; a free gate carries the level in whose pre-pass it runs); *bootstrap_levels (or NULL) = levels that hold at least
+ * one blind rotation -- the sequential depth a small batch pays for.  Returns the number of levels. */
 int64_t eoc_netlist_levels(const eoc_gate *gates, size_t n_gates, int32_t *level_of, int64_t *bootstrap_levels);
 /* Estimated run time of a netlist over `instances` instances, in units of 0.1 ms on one MI355X (Set A): a level of
  * J = instances x jobs blind rotations runs as J / R full launches (3.0 ms) plus one partly filled launch costing

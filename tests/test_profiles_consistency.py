@@ -82,8 +82,11 @@ def test_bench_lines_carry_the_contract_and_add_up(name, pset):
         assert s["nand16384_wide"]["bootstraps_per_s"] > 1.04 * d["value"]                # the wide kernel's gain
         assert s["adder8"]["bootstraps"] == 163840 and all(s[w]["decrypt_ok"] for w in ("adder8", "streq32", "mixed", "nand16384_wide"))
         # round 6 (VERDICT r5 task 1): the rewritten literal adder against the netlist as written, and the 8-instance latency
-        assert s["adder8_optimized"]["bootstraps"] == 30 * 4096 and s["adder8_optimized"]["decrypt_ok"]
-        assert s["adder8_optimized"]["pairs_per_s_over_adder8"] >= 1.2
+        # ... with the extension gates (XOR3 + MAJ: 16 bootstraps per pair) and inside libtfhe's gate family (MUX carry: 30)
+        assert s["adder8_optimized"]["bootstraps"] == 16 * 4096 and s["adder8_optimized"]["decrypt_ok"]
+        assert s["adder8_optimized"]["pairs_per_s_over_adder8"] >= 2.2
+        assert s["adder8_optimized_boots_gates"]["bootstraps"] == 30 * 4096 and s["adder8_optimized_boots_gates"]["decrypt_ok"]
+        assert s["adder8_optimized_boots_gates"]["pairs_per_s_over_adder8"] >= 1.2
         lat = s["latency_8_instances_ms"]
         assert lat["decrypt_ok"] and lat["prefix_over_ripple"] <= 0.4 and lat["prefix_log_depth"] < lat["ripple_rewritten"] < lat["ripple_as_written"]
         assert s["mixed"]["blind_rotate_spans"] == 1                                       # one pooled blind rotation per mixed call
