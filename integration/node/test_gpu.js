@@ -12,6 +12,8 @@ for (const x of [0, 1]) for (const y of [0, 1]) {
   assert.strictEqual(tfhe.decryptBit(tfhe.nand(e[x], e[y], ''), ''), 1 - (x & y));
   assert.strictEqual(tfhe.decryptBit(tfhe.xor(e[x], e[y], ''), ''), x ^ y);
   assert.strictEqual(tfhe.decryptBit(tfhe.mux(e[x], e[y], e[1 - y], ''), ''), x ? y : 1 - y);
+  assert.strictEqual(tfhe.decryptBit(tfhe.maj(e[x], e[y], e[1 - y], ''), ''), x);          // MAJ(x, y, NOT y) = x
+  assert.strictEqual(tfhe.decryptBit(tfhe.xor3(e[x], e[y], e[1], ''), ''), x ^ y ^ 1);
 }
 assert.strictEqual(tfhe.decryptBit(tfhe.not(e[1], ''), ''), 0);
 assert.strictEqual(tfhe.decryptBit(tfhe.and(tfhe.constantBit(1), e[1], ''), ''), 1);

@@ -65,10 +65,11 @@ def main():
              "lwe_key_sha": sha(o.lwe_key), "tlwe_key_sha": sha(o.tlwe_key), "bk_sha": sha(o.bk),
              "ksk_sha": sha(o.ksk), "bkfft_sha": sha(o.bkfft + 0.0),  # +0.0 canonicalises -0
              "c0_sha": sha(c0), "c1_sha": sha(c1), "gates": {}}
-        for opn in ["NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NOT"]:
-            out = o.gate_batch(ol.OPS[opn], c0, c1 if opn != "NOT" else None, c2 if opn == "MUX" else None)
+        # MAJ and XOR3 (round 6) are this repo's extension gates, not libtfhe functions: same bootstrap, three-input linear stage
+        for opn in ["NAND", "AND", "OR", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NOT", "MAJ", "XOR3"]:
+            out = o.gate_batch(ol.OPS[opn], c0, c1 if opn != "NOT" else None, c2 if opn in ("MUX", "MAJ", "XOR3") else None)
             e["gates"][opn] = {"sha": sha(out), "bits": o.decrypt_bits(out).tolist()}
-            if opn in ("NAND", "MUX"):
+            if opn in ("NAND", "MUX", "MAJ", "XOR3"):
                 arrays[f"{name}_{opn}_out"] = out
         t = o.gate_linear(ol.OPS["NAND"], c0[3], c1[3])
         u = o.blind_rotate_extract(t)

@@ -151,6 +151,11 @@ def test_string_api_and_host_batch_api(eoc):
         assert base64.b64decode(k1)[: 4 * 500] == bytes(4 * 500) and base64.b64decode(k1)[-8:] == bytes(8)
         assert T.decryptBit(T.and_(k1, c1)) == 1 and T.decryptBit(T.or_(k0, c0)) == 0
         assert T.decryptBit(T.mux(c1, c0, c1)) == 0 and T.decryptBit(T.mux(c0, c0, c1)) == 1
+        # the extension gates through the string API: majority and parity of three bits, one bootstrap each
+        for k in range(8):
+            x, y, z = (c1 if (k >> j) & 1 else c0 for j in range(3))
+            assert T.decryptBit(T.maj(x, y, z)) == int(bin(k).count("1") >= 2) and T.decryptBit(T.xor3(x, y, z)) == bin(k).count("1") & 1
+        assert T.maj(c1, "not base64!", c0) is None and T.xor3(c1, c0, "") is None
         assert T.nand("not base64!", c1) is None          # malformed input -> NULL
         # host-buffer batch API on the same global engine
         raw0 = np.frombuffer(base64.b64decode(c0)[: 4 * 501], np.int32)

@@ -56,8 +56,10 @@ def test_gates_equal_committed_bytes(eoc, golden, pset, name):
 
     assert np.array_equal(run("NAND", c[0], c[1], None), z[f"{name}_NAND_out"])
     assert np.array_equal(run("MUX", c[0], c[1], c[2]), z[f"{name}_MUX_out"])
+    assert np.array_equal(run("MAJ", c[0], c[1], c[2]), z[f"{name}_MAJ_out"])     # the extension gates (round 6)
+    assert np.array_equal(run("XOR3", c[0], c[1], c[2]), z[f"{name}_XOR3_out"])
     for opn, e in g[name]["gates"].items():       # every opcode: SHA-256 of the four output samples + decrypted bits
-        got = run(opn, c[0], None if opn == "NOT" else c[1], c[2] if opn == "MUX" else None)
+        got = run(opn, c[0], None if opn == "NOT" else c[1], c[2] if opn in ("MUX", "MAJ", "XOR3") else None)
         assert sha(got) == e["sha"], opn
         assert sk.decrypt_bits(got).tolist() == e["bits"], opn
     # the blind rotation alone: extracted sample of NAND(1, 1), all 1025 words

@@ -199,9 +199,9 @@ def test_gates_match_golden_set_a(golden, orc_a):
     b0, b1, b2 = np.array([0, 0, 1, 1]), np.array([0, 1, 0, 1]), np.array([1, 0, 0, 1])
     tt = dict(NAND=1 - (b0 & b1), AND=b0 & b1, OR=b0 | b1, NOR=1 - (b0 | b1), XOR=b0 ^ b1, XNOR=1 - (b0 ^ b1),
               ANDNY=(1 - b0) & b1, ANDYN=b0 & (1 - b1), ORNY=(1 - b0) | b1, ORYN=b0 | (1 - b1),
-              MUX=np.where(b0 == 1, b1, b2), NOT=1 - b0)
+              MUX=np.where(b0 == 1, b1, b2), NOT=1 - b0, MAJ=(b0 + b1 + b2 >= 2) * 1, XOR3=b0 ^ b1 ^ b2)
     for name, want in tt.items():
-        out = o.gate_batch(ol.OPS[name], c0, None if name == "NOT" else c1, c2 if name == "MUX" else None)
+        out = o.gate_batch(ol.OPS[name], c0, None if name == "NOT" else c1, c2 if name in ("MUX", "MAJ", "XOR3") else None)
         assert sha(out) == g["A"]["gates"][name]["sha"], name
         assert o.decrypt_bits(out).tolist() == want.tolist() == g["A"]["gates"][name]["bits"], name
     assert np.array_equal(o.gate_batch(ol.OPS["NAND"], c0, c1), a["A_NAND_out"])
@@ -219,6 +219,8 @@ def test_gates_match_golden_set_b(golden):
     assert np.array_equal(out, a["B_NAND_out"])
     assert o.decrypt_bits(out).tolist() == [1, 1, 1, 0]
     assert np.array_equal(o.gate_batch(ol.OPS["MUX"], a["B_c0"], a["B_c1"], a["B_c2"]), a["B_MUX_out"])
+    for opn in ("MAJ", "XOR3"):
+        assert np.array_equal(o.gate_batch(ol.OPS[opn], a["B_c0"], a["B_c1"], a["B_c2"]), a[f"B_{opn}_out"]), opn
 
 
 def test_fft_step_close_to_exact_step(orc_a):
