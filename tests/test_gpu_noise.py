@@ -117,3 +117,43 @@ def test_gpu_mux_noise_is_two_rotations_and_one_key_switch(eoc):
     assert abs(err.mean() - mean_pred) < 5 * err.std() / np.sqrt(COUNT), (err.mean(), mean_pred)
     # and it is NOT one rotation's worth: the single-bootstrap prediction is excluded
     assert err.var() / pred["total_var"] > 1.5
+
+
+def test_gpu_extension_gates_see_the_predicted_input_noise(eoc):
+    """round 6: circuits.noise_margin prices the phase an extension gate's blind rotation sees -- XOR3: -2 (a + b + c), variance
+    4 (V_a + V_b + V_c); MAJ: a + b + c, variance V_a + V_b + V_c (+ the mod-switch rounding, which the phase below does not
+    contain).  Measured on the WORST input the gate set allows: three bootsMUX outputs (2 V_BR + V_KS each) from the GPU,
+    Set A, 16 384 samples: the variance of t's phase error is within [0.8, 1.25] of the prediction, every sample stays inside
+    its decision margin (1/4 for XOR3, 1/8 for MAJ) with room to spare, and both gates then decrypt correctly."""
+    torch = torch_cuda()
+    p = eoc.default_params(0)
+    sk = eoc.SecretKey(p, 1)
+    eng = eoc.Engine(p)
+    eng.load_cloud_key(sk)
+    rng = np.random.default_rng(310)
+    pred = noise.predict(p, sk.lwe_key, sk.tlwe_key, sk.ksk)
+    v_mux = 2 * pred["br_var"] + pred["ks_var"]
+    s = sk.lwe_key.astype(np.int64)
+    mux_out, mux_bits = [], []
+    for k in range(3):
+        b = [rng.integers(0, 2, COUNT) for _ in range(3)]
+        d = [to_dev(sk.encrypt_bits(b[j], 4400 + 10 * k + j)) for j in range(3)]
+        out = dev_empty((COUNT, p.n + 1), torch.int32)
+        eng.gate_batch_device(eoc.OPS["MUX"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), out.data_ptr(), COUNT)
+        sync()
+        mux_out.append(out)
+        mux_bits.append(np.where(b[0] == 1, b[1], b[2]))
+    ssum = sum(o.cpu().numpy().astype(np.int64) for o in mux_out)
+    ones = mux_bits[0] + mux_bits[1] + mux_bits[2]
+    for name, scale, var_pred, margin, truth in (("XOR3", -2, 12 * v_mux, 0.25, ones & 1), ("MAJ", 1, 3 * v_mux, 0.125, (ones >= 2) * 1)):
+        t = scale * ssum
+        ph = ((t[:, -1] - t[:, :-1] @ s) + 2**31) % 2**32 - 2**31
+        ideal = scale * (2 * ones - 3) * 2**29                                   # the noiseless phase: scale * sum of +-1/8
+        err = (((ph - ideal) + 2**31) % 2**32 - 2**31) / 2.0**32
+        assert 0.8 < err.var() / var_pred < 1.25, (name, err.var(), var_pred)
+        assert np.abs(err).max() < 0.6 * margin, (name, np.abs(err).max())        # 16 384 samples stay far inside the margin
+        out = dev_empty((COUNT, p.n + 1), torch.int32)
+        eng.gate_batch_device(eoc.OPS[name], mux_out[0].data_ptr(), mux_out[1].data_ptr(), mux_out[2].data_ptr(), out.data_ptr(), COUNT)
+        sync()
+        assert np.array_equal(sk.decrypt_bits(out.cpu().numpy()), truth), name
+    eng.close()
