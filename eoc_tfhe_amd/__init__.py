@@ -953,3 +953,69 @@ class Tfhe:
     def lessThanBits(A, B):
         return Tfhe._strings(Tfhe.lessThanBitsBatch(Tfhe._samples(A), Tfhe._samples(B))[None])[0]
 
+
+class Circuit:
+    """Deferred gates: the reference's call style (one ciphertext operation per call, ao-tfhe/tfhe.lua:4-53) evaluated by ONE
+    backend call.  A gate call on the string API costs a whole blind rotation's n sequential steps (1.8 ms) however little
+    it computes; a Circuit records the same calls on wire handles and run() sends the recorded netlist through
+    eoc_netlist_optimize and one eoc_global_circuit_run, where every LEVEL costs those 1.8 ms.  The twin of Tfhe.newCircuit
+    in tfhe_gates.lua / tfhe.js.
+
+        c = Circuit(); x, y = c.input(ct_x), c.input(ct_y)
+        s, k = c.run([c.xor(x, y), c.and_(x, y)])          # base64 ciphertext strings, one backend call
+    """
+
+    def __init__(self):
+        self.gates, self.n_wires, self.inputs, self.instances = [], 0, {}, None
+
+    def _wire(self):
+        self.n_wires += 1
+        return self.n_wires - 1
+
+    def _gate(self, name, a=-1, b=-1, c=-1):
+        out = self._wire()
+        self.gates.append(Gate(OPS[name], a, b, c, out))
+        return out
+
+    def _add_input(self, planes):
+        if self.instances not in (None, planes.shape[0]):
+            raise EocError("every input of a Circuit has the same instance count")
+        self.instances = planes.shape[0]
+        w = self._wire()
+        self.inputs[w] = planes
+        return w
+
+    def input(self, ct):
+        """one base64 ciphertext string"""
+        return self._add_input(Tfhe._samples([ct])[0])
+
+    def input_samples(self, samples):
+        """raw samples [instances][n+1]"""
+        return self._add_input(np.ascontiguousarray(samples, np.int32))
+
+    def constant(self, bit):
+        return self._gate("CONST1" if bit else "CONST0")
+
+    def nand(self, a, b): return self._gate("NAND", a, b)
+    def and_(self, a, b): return self._gate("AND", a, b)
+    def or_(self, a, b): return self._gate("OR", a, b)
+    def nor(self, a, b): return self._gate("NOR", a, b)
+    def xor(self, a, b): return self._gate("XOR", a, b)
+    def xnor(self, a, b): return self._gate("XNOR", a, b)
+    def not_(self, a): return self._gate("NOT", a)
+    def mux(self, a, b, c): return self._gate("MUX", a, b, c)
+    def maj(self, a, b, c): return self._gate("MAJ", a, b, c)
+    def xor3(self, a, b, c): return self._gate("XOR3", a, b, c)
+
+    def run(self, outs):
+        """outs: handles -> list of base64 strings (one instance) or of sample arrays [instances][n+1]"""
+        instances = self.instances or 1
+        rowlen = next(iter(self.inputs.values())).shape[-1] if self.inputs else global_params().n + 1
+        wires = np.zeros((self.n_wires, instances, rowlen), np.int32)
+        for w, planes in self.inputs.items():
+            wires[w] = planes
+        gates = netlist_optimize(self.gates, list(outs)) if self.gates else []
+        if gates:
+            global_circuit_run(gates, wires, instances)
+        return Tfhe._strings([wires[w] for w in outs]) if instances == 1 else [wires[w] for w in outs]
+

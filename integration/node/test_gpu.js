@@ -30,6 +30,24 @@ for (const [x, y] of [[5, 3], [2, 6], [4, 4]]) {
 const mm = tfhe.minMaxBits(enc(5, 3), enc(3, 3), '');
 assert.strictEqual(val(mm.min), 3);
 assert.strictEqual(val(mm.max), 5);
+// deferred gates: the reference's call style (one operation per call) recorded on handles, ONE backend call per run():
+// a 3-bit adder written gate by gate the textbook way; then a batch of raw samples through maj / xor3 / not / constant
+{
+  const c = tfhe.newCircuit(), xs = enc(5, 3).map(c.input), ys = enc(6, 3).map(c.input), outs = [];
+  let carry = null;
+  for (let i = 0; i < 3; i++) {
+    const p = c.xor(xs[i], ys[i]), g = c.and(xs[i], ys[i]);
+    if (carry === null) { outs.push(p); carry = g; } else { outs.push(c.xor(p, carry)); carry = c.or(g, c.and(p, carry)); }
+  }
+  assert.strictEqual(c.gateCount(), 12);
+  assert.strictEqual(val(c.run([...outs, carry])), 11);
+  const c2 = tfhe.newCircuit(), v = Buffer.from([1, 0, 1, 1, 0]), nv = Buffer.from([0, 1, 0, 0, 1]);
+  const h = [v, nv, v].map(b => c2.inputSamples(tfhe.backend.encryptBits(b)));
+  assert.strictEqual(c2.inputSamples(tfhe.backend.encryptBits(Buffer.from([1, 1]))), null);   // another instance count: refused
+  const [m, q] = c2.run([c2.maj(h[0], h[1], h[2]), c2.xor3(h[0], c2.not(h[1]), c2.constant(1))]);
+  assert.deepStrictEqual([...tfhe.backend.decryptBits(m)], [...v]);
+  assert.deepStrictEqual([...tfhe.backend.decryptBits(q)], [...v].map(b => b ^ b ^ 1));
+}
 // batched: 2048 NANDs and a 16-byte string equality through raw buffers
 const N = 2048, bits0 = Buffer.alloc(N), bits1 = Buffer.alloc(N);
 for (let i = 0; i < N; i++) { bits0[i] = (i * 7 + 3) & 1; bits1[i] = (i >> 3) & 1; }

@@ -395,4 +395,43 @@ Tfhe.equalBits = (X, Y) => {  // X, Y: Buffers of int32 samples [nbits][n+1] (on
 // string helpers of the gate path: a string travels as 8 bit-ciphertexts per byte, LSB first (raw Buffer of samples)
 Tfhe.encryptStringBits = str => B.encryptBits(Buffer.from([...Buffer.from(str)].flatMap(c => [...Array(8).keys()].map(k => (c >> k) & 1))));
 Tfhe.equalStrings = (X, Y) => Tfhe.equalBits(X, Y);   // one ciphertext: 1 iff the two encrypted strings are equal
+// ---- deferred gates: the reference's call style (one ciphertext operation per call, tfhe.lua:4-53), ONE backend call ----
+// A gate call on the string API costs a whole blind rotation's n sequential steps (1.8 ms) however little it computes.  A
+// deferred circuit records the same calls on wire handles and evaluates them together: run() sends the recorded netlist
+// through B.netlistOptimize and ONE B.circuitRun, where every LEVEL costs those 1.8 ms.
+//   const c = Tfhe.newCircuit(), x = c.input(ctX), y = c.input(ctY);
+//   const [s, k] = c.run([c.xor(x, y), c.and(x, y)]);      // base64 ciphertext strings, one backend call
+Tfhe.newCircuit = () => {
+  const nl = new Netlist(), inputs = {}, c = { instances: null };
+  const addInput = (buf, instances) => {
+    if (c.instances !== null && c.instances !== instances) return null;   // every input has the same instance count
+    c.instances = instances;
+    const w = nl.wire(1);
+    inputs[w] = buf;
+    return w;
+  };
+  c.input = ct => addInput(strToSample(ct), 1);                          // one base64 ciphertext string
+  c.inputSamples = buf => addInput(buf, buf.length / (B.sampleInts() * 4)); // raw samples [instances][n+1]
+  c.constant = bit => nl.gate(bit ? OP.CONST1 : OP.CONST0, -1);
+  c.nand = (a, b) => nl.gate(OP.NAND, a, b);
+  c.and = (a, b) => nl.gate(OP.AND, a, b);
+  c.or = (a, b) => nl.gate(OP.OR, a, b);
+  c.nor = (a, b) => nl.gate(OP.NOR, a, b);
+  c.xor = (a, b) => nl.gate(OP.XOR, a, b);
+  c.xnor = (a, b) => nl.gate(OP.XNOR, a, b);
+  c.not = a => nl.gate(OP.NOT, a);
+  c.mux = (a, b, d) => nl.gate(OP.MUX, a, b, d);
+  c.maj = (a, b, d) => nl.gate(OP.MAJ, a, b, d);
+  c.xor3 = (a, b, d) => nl.gate(OP.XOR3, a, b, d);
+  c.gateCount = () => nl.gates.length;
+  c.netlist = () => nl;
+  // outs: array of handles -> array of base64 strings (instances == 1) or of raw sample Buffers [instances][n+1]
+  c.run = outs => {
+    const instances = c.instances === null ? 1 : c.instances;
+    const wires = Tfhe.runNetlist(nl, inputs, instances, outs);
+    if (!wires) return null;
+    return outs.map(w => { const buf = planes(wires, w, 1, instances); return instances === 1 ? sampleToStr(buf) : buf; });
+  };
+  return c;
+};
 module.exports = Tfhe;

@@ -173,6 +173,33 @@ def test_string_api_and_host_batch_api(eoc):
             assert st1["bootstraps"] - st0["bootstraps"] == 48 and st1["batches"] - st0["batches"] == 5   # prefix adder
             assert T.decryptBit(T.lessThanBits(A, B)) == int(av < bv)
             assert eoc.stats()["bootstraps"] - st1["bootstraps"] == 29                                  # tree comparator
+        # deferred gates (round 6): the reference's call style -- one operation per call -- recorded on handles and run by ONE
+        # backend call: a 4-bit adder written gate by gate the textbook way (17 bootstrapped gate calls, 7 dependent levels as
+        # written) costs 8 bootstraps on 4 levels after the rewrite, and equals the gate-by-gate string API's answer
+        av, bv = 11, 6
+        A = [T.encryptBit((av >> i) & 1) for i in range(4)]
+        B = [T.encryptBit((bv >> i) & 1) for i in range(4)]
+        c = eoc.Circuit()
+        xs, ys = [c.input(x) for x in A], [c.input(y) for y in B]
+        carry, outs = None, []
+        for i in range(4):
+            p_, g_ = c.xor(xs[i], ys[i]), c.and_(xs[i], ys[i])
+            if carry is None:
+                outs.append(p_)
+                carry = g_
+            else:
+                outs.append(c.xor(p_, carry))
+                carry = c.or_(g_, c.and_(p_, carry))
+        st0 = eoc.stats()
+        res = c.run(outs + [carry])
+        st1 = eoc.stats()
+        assert sum(T.decryptBit(x) << i for i, x in enumerate(res)) == av + bv
+        assert st1["bootstraps"] - st0["bootstraps"] == 8 and st1["batches"] - st0["batches"] == 4, (st0, st1)
+        c2 = eoc.Circuit()                                     # batches of raw samples through the same builder
+        vals = np.array([1, 0, 1, 1, 0], np.uint8)
+        h = [c2.input_samples(eoc.global_encrypt_bits(v)) for v in (vals, 1 - vals, vals)]
+        m, q = c2.run([c2.maj(*h), c2.xor3(h[0], c2.not_(h[1]), c2.constant(1))])
+        assert np.array_equal(eoc.global_decrypt_bits(m), vals) and np.array_equal(eoc.global_decrypt_bits(q), vals ^ vals ^ 1)
         planes = lambda vals: np.stack([eoc.global_encrypt_bits(((vals >> i) & 1).astype(np.uint8)) for i in range(8)])
         rng = np.random.default_rng(12)
         Av, Bv = rng.integers(0, 256, 1200), rng.integers(0, 256, 1200)

@@ -167,7 +167,7 @@ def value_of(buf, instances):
 def test_facade_defines_its_functions_and_passes_through(facade):
     it, tf, be = facade
     for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
-                 "muxAdderNetlist", "majAdderNetlist", "majSubtractorNetlist", "majLessThanNetlist", "maj", "xor3", "prefixAdderNetlist", "prefixSubtractorNetlist", "wallaceMultiplierNetlist", "multiplierNetlistFor", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
+                 "newCircuit", "muxAdderNetlist", "majAdderNetlist", "majSubtractorNetlist", "majLessThanNetlist", "maj", "xor3", "prefixAdderNetlist", "prefixSubtractorNetlist", "wallaceMultiplierNetlist", "multiplierNetlistFor", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
                  "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
                  "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
         assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
@@ -299,6 +299,57 @@ def test_forms_are_picked_by_instance_count(facade):
     assert be.calls[-1][:2] == ("circuitRun", len(circuits.prefix_adder(8)[0]))
 
 
+def test_deferred_circuit_records_gate_calls_and_runs_them_in_one_backend_call(facade):
+    """Tfhe.newCircuit: the reference's call style (one ciphertext operation per Lua call) recorded on wire handles and
+    evaluated by ONE circuitRun (after netlistOptimize) -- a 3-bit adder written gate by gate the textbook way, over 5
+    instances from raw samples and over one instance from base64 strings"""
+    import base64
+    from eoc_tfhe_amd import circuits
+    it, tf, be = facade
+    S = 5
+    A, B = np.array([3, 7, 0, 5, 6]), np.array([1, 7, 4, 2, 3])
+
+    def build(c, xs, ys):
+        cget = lambda name: c.get(name.encode())
+        carry, outs = None, []
+        for i in range(3):
+            p = it.call(cget("xor"), [xs[i], ys[i]])[0]
+            g = it.call(cget("band"), [xs[i], ys[i]])[0]
+            if carry is None:
+                outs.append(p)
+                carry = g
+            else:
+                outs.append(it.call(cget("xor"), [p, carry])[0])
+                carry = it.call(cget("bor"), [g, it.call(cget("band"), [p, carry])[0]])[0]
+        return outs + [carry]
+
+    c = call(it, tf, "newCircuit")[0]
+    xs = [it.call(c.get(b"inputSamples"), [planes_of(A, 3, S)[i * S * ROW * 4:(i + 1) * S * ROW * 4]])[0] for i in range(3)]
+    ys = [it.call(c.get(b"inputSamples"), [planes_of(B, 3, S)[i * S * ROW * 4:(i + 1) * S * ROW * 4]])[0] for i in range(3)]
+    outs = build(c, xs, ys)
+    assert it.call(c.get(b"gateCount"), []) == [2 + 5 * 2]
+    n_calls = len(be.calls)
+    res = ml.to_python(it.call(c.get(b"run"), [ml.table_from(outs)])[0])
+    new_calls = [x[0] for x in be.calls[n_calls:]]
+    assert new_calls == ["netlistOptimize", "circuitRun"], new_calls                      # ONE evaluation for twelve gate calls
+    assert be.calls[-1][1] == 6                                    # rewritten: XOR + AND, then XOR3 + MAJ per bit
+    assert np.array_equal(value_of(b"".join(res), S), A + B)
+    # a second input with another instance count is refused
+    assert it.call(c.get(b"inputSamples"), [planes_of(A[:2], 1, 2)]) == [None]
+    # one instance, base64 strings in and out
+    c1 = call(it, tf, "newCircuit")[0]
+
+    def ct(bit):
+        return base64.b64encode(np.array([0] * (ROW - 1) + [bit], "<i4").tobytes() + bytes(8))
+
+    x, y, z = (it.call(c1.get(b"input"), [ct(v)])[0] for v in (1, 0, 1))
+    m = it.call(c1.get(b"maj"), [x, y, z])[0]
+    q = it.call(c1.get(b"xor3"), [x, it.call(c1.get(b"bnot"), [y])[0], it.call(c1.get(b"constant"), [1])[0]])[0]
+    r = ml.to_python(it.call(c1.get(b"run"), [ml.table_from([m, q])])[0])
+    bits = [int(np.frombuffer(base64.b64decode(v)[: ROW * 4], "<i4")[-1]) for v in r]
+    assert bits == [1, 1 ^ 1 ^ 1]
+
+
 def test_batch_functions_pack_and_slice_wires(facade):
     it, tf, be = facade
     rng = np.random.default_rng(9)
@@ -396,6 +447,14 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
             wires[o] = orc.gate_batch(int(op), wires[i0], wires[i1], wires[i2] if i2 >= 0 else None)
         want = np.concatenate([wires[w] for w in ml.to_python(s)]).tobytes()
         assert out == want
+        # deferred gates through the real binding: MAJ / XOR3 / NOT / CONSTANT recorded on handles, ONE circuitRun on the GPU
+        c = call(it, tf, "newCircuit")[0]
+        e1, e0 = call(it, tf, "encryptBit", 1)[0], call(it, tf, "encryptBit", 0)[0]
+        h = [it.call(c.get(b"input"), [x])[0] for x in (e1, e0, e1)]
+        m = it.call(c.get(b"maj"), h)[0]
+        q = it.call(c.get(b"xor3"), [h[0], it.call(c.get(b"bnot"), [h[1]])[0], it.call(c.get(b"constant"), [1])[0]])[0]
+        r = ml.to_python(it.call(c.get(b"run"), [ml.table_from([m, q])])[0])
+        assert [call(it, tf, "decryptBit", v)[0] for v in r] == [1, 1 ^ 1 ^ 1]
         # string-level circuits: base64 ciphertext strings in and out (the facade's own base64), one backend call each;
         # lessThanBits goes through the backend's netlistOptimize (NOT folding, MUX fusion, dead gates dropped)
         for av, bv in ((5, 6), (7, 2)):
