@@ -821,34 +821,62 @@ def fuse_carry(gates, outputs, extension_gates=False):
 
 
 def fuse_maj(gates, outputs):
-    """extension gates only: MUX(XOR(x, y), c, x) (or ..., c, y) -- the carry written as one MUX -- is MAJ(x, y, c): where x
-    and y differ the third input decides, where they agree they do.  The XOR wire stays if anyone else reads it."""
-    _check_ssa(gates)
-    src = {g.out: g for g in gates}
-    out = []
-    for g in gates:
-        q = src.get(g.in0) if _NAMES[g.op] == "MUX" else None
-        if q is not None and _NAMES[q.op] == "XOR" and q.in0 != q.in1 and g.in2 in (q.in0, q.in1):
-            out.append(Gate(OPS["MAJ"], q.in0, q.in1, g.in1, g.out))
-        else:
-            out.append(Gate(g.op, g.in0, g.in1, g.in2, g.out))
-    return _drop_dead(out, outputs)
-
-
-def fuse_xor3(gates, outputs):
-    """extension gates only: XOR(XOR(a, b), c) with a single-use inner wire that is no output is XOR3(a, b, c) -- one
-    bootstrap on one level instead of two on two (a full adder's sum once its carry no longer reads a XOR b)"""
+    """extension gates only: a MUX whose selector is XOR(x, y) or XNOR(x, y) and one of whose branches is x or y is a
+    MAJORITY.  With d the branch taken where x and y differ and o the other one:  o in {x, y}: MAJ(x, y, d) (the carry written
+    as one MUX);  d in {x, y}: MAJ(NOT other, d, o) (a borrow / comparator step, MUX(XNOR(a, b), lt, b) = MAJ(NOT a, b, lt)) --
+    the NOT takes the selector's own wire when this MUX is its only reader and it is no output."""
     _check_ssa(gates)
     src = {g.out: g for g in gates}
     uses = _uses(gates)
     keep = set(outputs)
+    out, pos = [], {}
+    for g in gates:
+        m = None
+        q = src.get(g.in0) if _NAMES[g.op] == "MUX" else None
+        if q is not None and _NAMES[q.op] in ("XOR", "XNOR") and q.in0 != q.in1:
+            x, y = q.in0, q.in1
+            d, o = (g.in1, g.in2) if _NAMES[q.op] == "XOR" else (g.in2, g.in1)
+            if o in (x, y):
+                m = Gate(OPS["MAJ"], x, y, d, g.out)
+            elif d in (x, y) and uses.get(q.out, 0) == 1 and q.out not in keep and q.out in pos:
+                out[pos[q.out]] = Gate(OPS["NOT"], y if d == x else x, -1, -1, q.out)
+                m = Gate(OPS["MAJ"], q.out, d, o, g.out)
+        out.append(m if m is not None else Gate(g.op, g.in0, g.in1, g.in2, g.out))
+        pos[g.out] = len(out) - 1
+    return _drop_dead(out, outputs)
+
+
+def fuse_xor3(gates, outputs):
+    """extension gates only: XOR(XOR(a, b), c) is XOR3(a, b, c) when that lets the inner wire die -- it is no output and its
+    only other reader, if any, is a MUX that fuse_maj turns into MAJ(NOT ., ., .) on the inner wire itself (a subtractor's
+    difference bit next to its borrow).  One bootstrap on one level instead of two on two."""
+    _check_ssa(gates)
+    src = {g.out: g for g in gates}
+    uses = _uses(gates)
+    keep = set(outputs)
+    sel_of, sel_count = {}, {}
+    for g in gates:
+        if _NAMES[g.op] == "MUX":
+            sel_of[g.in0] = g
+            sel_count[g.in0] = sel_count.get(g.in0, 0) + 1
+
+    def inner_dies(q):
+        if q.out in keep:
+            return False
+        if uses.get(q.out, 0) == 1:
+            return True
+        if uses.get(q.out, 0) != 2 or sel_count.get(q.out, 0) != 1:
+            return False
+        m = sel_of[q.out]                               # q = XOR(x, y): the branch taken where x and y differ is in1
+        return m.in1 != q.out and m.in2 != q.out and m.in1 in (q.in0, q.in1) and m.in2 not in (q.in0, q.in1)
+
     out = []
     for g in gates:
         m = None
         if _NAMES[g.op] == "XOR" and g.in0 != g.in1:
             for p, c in ((g.in0, g.in1), (g.in1, g.in0)):
                 q = src.get(p)
-                if m is None and q is not None and _NAMES[q.op] == "XOR" and uses.get(p, 0) == 1 and p not in keep:
+                if m is None and q is not None and _NAMES[q.op] == "XOR" and q.in0 != q.in1 and inner_dies(q):
                     m = Gate(OPS["XOR3"], q.in0, q.in1, c, g.out)
         out.append(m if m is not None else Gate(g.op, g.in0, g.in1, g.in2, g.out))
     return _drop_dead(out, outputs)

@@ -1031,8 +1031,12 @@ Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_
     return res;
 }
 
-// extension gates only.  MUX(XOR(x, y), c, x) (or ..., c, y) -- the carry written as one MUX -- is MAJ(x, y, c): where x and y
-// differ the third input decides, where they agree they do.  The XOR wire stays if anyone else reads it.
+// extension gates only.  A MUX whose selector is XOR(x, y) or XNOR(x, y) and one of whose branches is x or y is a MAJORITY.
+// Let d be the branch taken where x and y differ, o the other one.
+//   o in {x, y}:  MAJ(x, y, d) -- the carry written as one MUX, MUX(XOR(x, y), c, x): where the inputs agree they are the result
+//   d in {x, y}:  MAJ(NOT other, d, o) -- a borrow / comparator step, MUX(XNOR(a, b), lt, b) = MAJ(NOT a, b, lt).  The NOT needs
+//                 a wire: the selector's own, when this MUX is its only reader and it is no output (its gate becomes the NOT:
+//                 same wire numbering, one bootstrap less on top of the MUX's)
 Netlist pass_fuse_maj(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
 {
     std::vector<int64_t> src;
@@ -1040,26 +1044,53 @@ Netlist pass_fuse_maj(const Netlist &cur, const std::vector<char> &keep, size_t 
     index_netlist(cur, n_wires, src, uses);
     Netlist res;
     res.reserve(cur.size());
+    std::vector<int64_t> pos(n_wires, -1); // wire -> index of its gate in res
     for (const eoc_gate &g : cur) {
+        bool done = false;
         if (g.op == EOC_MUX && src[g.in0] >= 0) {
             const eoc_gate &q = cur[src[g.in0]];
-            if (q.op == EOC_XOR && q.in0 != q.in1 && (g.in2 == q.in0 || g.in2 == q.in1)) {
-                res.push_back(mk(EOC_MAJ, q.in0, q.in1, g.in1, g.out));
-                continue;
+            if ((q.op == EOC_XOR || q.op == EOC_XNOR) && q.in0 != q.in1) {
+                const int32_t x = q.in0, y = q.in1;
+                const int32_t d = q.op == EOC_XOR ? g.in1 : g.in2, o = q.op == EOC_XOR ? g.in2 : g.in1;
+                if (o == x || o == y) {
+                    res.push_back(mk(EOC_MAJ, x, y, d, g.out));
+                    done = true;
+                } else if ((d == x || d == y) && uses[q.out] == 1 && !keep[q.out] && pos[q.out] >= 0) {
+                    res[pos[q.out]] = mk(EOC_NOT, d == x ? y : x, -1, -1, q.out);
+                    res.push_back(mk(EOC_MAJ, q.out, d, o, g.out));
+                    done = true;
+                }
             }
         }
-        res.push_back(g);
+        if (!done) res.push_back(g);
+        pos[g.out] = (int64_t)res.size() - 1;
     }
     drop_dead(res, keep, n_wires);
     return res;
 }
-// extension gates only.  XOR(XOR(a, b), c) with a single-use inner wire that is no output is XOR3(a, b, c): one bootstrap
-// on one level instead of two on two (a full adder's sum once its carry no longer reads a XOR b)
+// extension gates only.  XOR(XOR(a, b), c) is XOR3(a, b, c) when that lets the inner wire die: it is no output and its only
+// other reader, if any, is a MUX that pass_fuse_maj turns into MAJ(NOT ., ., .) on the inner wire itself (a subtractor's
+// difference bit next to its borrow).  One bootstrap on one level instead of two on two.
 Netlist pass_fuse_xor3(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
 {
     std::vector<int64_t> src;
     std::vector<int> uses;
     index_netlist(cur, n_wires, src, uses);
+    // the MUX (if exactly one) whose selector each wire is
+    std::vector<int64_t> sel_of(n_wires, -1);
+    std::vector<int> sel_count(n_wires, 0);
+    for (size_t k = 0; k < cur.size(); k++)
+        if (cur[k].op == EOC_MUX) {
+            sel_of[cur[k].in0] = (int64_t)k;
+            sel_count[cur[k].in0]++;
+        }
+    auto inner_dies = [&](const eoc_gate &q) {
+        if (keep[q.out]) return false;
+        if (uses[q.out] == 1) return true;
+        if (uses[q.out] != 2 || sel_count[q.out] != 1) return false;
+        const eoc_gate &m = cur[sel_of[q.out]]; // q = XOR(x, y): the branch taken where x and y differ is in1
+        return m.in1 != q.out && m.in2 != q.out && (m.in1 == q.in0 || m.in1 == q.in1) && m.in2 != q.in0 && m.in2 != q.in1;
+    };
     Netlist res;
     res.reserve(cur.size());
     for (const eoc_gate &g : cur) {
@@ -1069,7 +1100,7 @@ Netlist pass_fuse_xor3(const Netlist &cur, const std::vector<char> &keep, size_t
                 const int32_t p = side ? g.in1 : g.in0, c = side ? g.in0 : g.in1;
                 if (src[p] < 0) continue;
                 const eoc_gate &q = cur[src[p]];
-                if (q.op == EOC_XOR && uses[p] == 1 && !keep[p]) {
+                if (q.op == EOC_XOR && q.in0 != q.in1 && inner_dies(q)) {
                     res.push_back(mk(EOC_XOR3, q.in0, q.in1, c, g.out));
                     done = true;
                 }

@@ -249,10 +249,12 @@ size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
 int64_t eoc_netlist_optimize(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
                              eoc_gate *gates_out);
 /* ... with flags.  By default (flags 0, = eoc_netlist_optimize) the rewriting may use the EXTENSION gates: the full adder's
- * carry becomes EOC_MAJ(a, b, c) (one bootstrap, not MUX's two), MUX(XOR(x, y), c, x) becomes EOC_MAJ(x, y, c), and
- * XOR(XOR(a, b), c) with a single-use inner wire becomes EOC_XOR3(a, b, c): the literal 8-bit ripple-carry adder goes from 40
- * bootstraps on 17 levels to 16 on 8.  EOC_NL_BOOTS_GATES_ONLY keeps the result inside libtfhe's boots* family (the carry
- * as MUX: 30 bootstraps on 8 levels). */
+ * carry becomes EOC_MAJ(a, b, c) (one bootstrap, not MUX's two); a MUX whose selector is XOR / XNOR(x, y) and one of whose
+ * branches is x or y becomes a majority -- MUX(XOR(x, y), c, x) = EOC_MAJ(x, y, c), the borrow / comparator step
+ * MUX(XNOR(a, b), lt, b) = EOC_MAJ(NOT a, b, lt) with the NOT on the selector's wire once that has no other reader -- and
+ * XOR(XOR(a, b), c) whose inner wire then dies becomes EOC_XOR3(a, b, c): the literal 8-bit ripple-carry adder goes from 40
+ * bootstraps on 17 levels to 16 on 8, the textbook subtractor from 30 to 16, the comparator chain from 22 to 8.
+ * EOC_NL_BOOTS_GATES_ONLY keeps the result inside libtfhe's boots* family (the carry as MUX: 30 bootstraps on 8 levels). */
 enum { EOC_NL_BOOTS_GATES_ONLY = 1 };
 int64_t eoc_netlist_optimize_ex(const eoc_gate *gates, size_t n_gates, const int32_t *outputs, size_t n_outputs,
                                 eoc_gate *gates_out, unsigned flags);

@@ -413,6 +413,64 @@ def test_carry_rewrite_on_the_literal_adder():
     assert [c._NAMES[g.op] for g in c.fuse_carry(shared, [6, 7])] == ["XOR", "AND", "AND", "OR", "XOR"]
 
 
+def _flat(parts):
+    out = []
+    for x in parts:
+        out += x if isinstance(x, list) else [x]
+    return out
+
+
+def test_borrow_and_comparison_chains_become_majorities():
+    """MUX(XOR(x, y), d, o) with o in {x, y} is MAJ(x, y, d); with d in {x, y} it is MAJ(NOT other, d, o) and the NOT reuses
+    the selector's wire when the selector has no other reader left (XNOR selectors: the branches swap).  A difference bit
+    XOR(XOR(a, b), br) next to such a borrow is XOR3(a, b, br).  So the textbook subtractor, comparator and min/max reach
+    the forms maj_subtractor / maj_less_than build by hand: one bootstrap per borrow, all inputs checked at 4 bits."""
+    for build, want, hand in ((c.subtractor, (16, 8), c.maj_subtractor), (c.less_than, (8, 8), c.maj_less_than)):
+        r = build(8)
+        outs = _flat(r[4:])
+        o = c.optimize(r[0], outs)
+        assert (circuit_bootstraps(o), c.bootstrap_depth(o)) == want
+        h = hand(8)[0]
+        assert sorted(c._NAMES[g.op] for g in o if c._boots(g)) == sorted(c._NAMES[g.op] for g in h if c._boots(g))
+        assert (circuit_bootstraps(c.optimize(r[0], outs, extension_gates=False)), c.bootstrap_depth(r[0])) == \
+               (circuit_bootstraps(r[0]), want[1])                                  # inside libtfhe's family: as written
+    gates, nw, a, b, mn, mx = c.min_max(8)
+    o = c.optimize(gates, mn + mx)
+    assert (circuit_bootstraps(gates), circuit_bootstraps(o), c.bootstrap_depth(o)) == (54, 40, 9)
+    for build in (c.prefix_adder, c.less_than_tree):
+        r = build(8)
+        outs = _flat(r[4:])
+        o = c.optimize(r[0], outs)
+        assert (circuit_bootstraps(o), c.bootstrap_depth(o)) == {c.prefix_adder: (40, 5), c.less_than_tree: (27, 4)}[build]
+    A, B, S = _words(4)
+    for build, value in ((c.subtractor, lambda A, B: (A - B) & 15), (c.less_than, lambda A, B: (A < B) * 1)):
+        r = build(4)
+        outs = _flat(r[4:])
+        for ext in (True, False):
+            o = c.optimize(r[0], outs, extension_gates=ext)
+            w = np.zeros((r[1], S), np.uint8)
+            _load(w, r[2], A)
+            _load(w, r[3], B)
+            got = c.evaluate_plain(o, w)
+            assert np.array_equal(_value(got, r[4]) if isinstance(r[4], list) else got[r[4]], value(A, B))
+    # every shape of the pattern on three inputs, selector single-use or shared, XOR or XNOR
+    w = np.zeros((8, 8), np.uint8)
+    for k in range(8):
+        w[0, k], w[1, k], w[2, k] = k & 1, (k >> 1) & 1, (k >> 2) & 1
+    for sel in ("XOR", "XNOR"):
+        for d, o_ in ((2, 0), (2, 1), (0, 2), (1, 2), (0, 1), (1, 0)):
+            for shared in (False, True):
+                nl = [Gate(OPS[sel], 0, 1, -1, 3), Gate(OPS["MUX"], 3, d, o_, 4)]
+                outs = [4, 3] if shared else [4]
+                opt = c.optimize(nl, outs)
+                got, ref = c.evaluate_plain(opt, w), c.evaluate_plain(nl, w)
+                assert all(np.array_equal(got[x], ref[x]) for x in outs), (sel, d, o_, shared)
+                assert circuit_bootstraps(opt) <= circuit_bootstraps(nl)
+                differ, same = (d, o_) if sel == "XOR" else (o_, d)              # the branch taken where x != y / x == y
+                fused = same in (0, 1) or (differ in (0, 1) and same == 2 and not shared)
+                assert ("MAJ" in [c._NAMES[g.op] for g in opt]) == fused, (sel, d, o_, shared, opt)
+
+
 def test_constant_folding_every_gate_and_position():
     two = list(c._SEM2)
     for name in two:
