@@ -486,17 +486,21 @@ MULTIPLIER_FORMS = {"rows": lambda n: _optimized(multiplier(n)), "wallace": lamb
 
 
 def _optimized(built):
-    """the builder's result with its netlist run through optimize (outputs = the last element)"""
-    outs = built[-1] if isinstance(built[-1], list) else [built[-1]]
+    """the builder's result with its netlist run through optimize (outputs = every wire group behind the operands)"""
+    outs = []
+    for part in built[4:]:
+        outs += list(part) if isinstance(part, (list, tuple)) else [part]
     return (optimize(built[0], outs),) + tuple(built[1:])
 
 
-def pick_form(forms, nbits, instances, resident_jobs=1024):
+def pick_form(forms, nbits, instances, resident_jobs=1024, optimized=False):
     """the form of lowest netlist_cost for this many instances (ties: fewest bootstraps): depth decides below a quarter
-    of the resident set, bootstraps decide above it.  Returns (name, builder result)."""
+    of the resident set, bootstraps decide above it.  optimized: every candidate goes through optimize first and is
+    priced -- and returned -- as rewritten (the prefix adder 48 -> 40 bootstraps, the tree comparator 29 -> 27).
+    Returns (name, builder result)."""
     best = None
     for name, build in forms.items():
-        r = build(nbits)
+        r = _optimized(build(nbits)) if optimized else build(nbits)
         boots = sum(_boots(g) for g in r[0])
         key = (netlist_cost(r[0], instances, resident_jobs), boots)
         if best is None or key < best[0]:
@@ -505,15 +509,15 @@ def pick_form(forms, nbits, instances, resident_jobs=1024):
 
 
 def adder(nbits=8, instances=1, resident_jobs=1024):
-    """the adder form to run for `instances` input pairs: maj_adder (fewest bootstraps) for wide batches, prefix_adder
-    (fewest levels) for small ones.  ripple_carry_adder is never chosen (it is the textbook form BASELINE configs[2] is
-    timed on, kept as written), nor mux_carry_adder (the best form inside libtfhe's gate family: maj_adder beats it)"""
+    """the adder form to run for `instances` input pairs, through optimize: maj_adder (fewest bootstraps) for wide batches,
+    prefix_adder (fewest levels) for small ones.  ripple_carry_adder is never chosen (it is the textbook form BASELINE
+    configs[2] is timed on, kept as written), nor mux_carry_adder (the optimizer turns both into maj_adder's netlist)"""
     forms = {k: v for k, v in ADDER_FORMS.items() if k in ("maj", "prefix")}
-    return pick_form(forms, nbits, instances, resident_jobs)[1]
+    return pick_form(forms, nbits, instances, resident_jobs, True)[1]
 
 
 def less_than_for(nbits=8, instances=1, resident_jobs=1024):
-    return pick_form(LESS_THAN_FORMS, nbits, instances, resident_jobs)[1]
+    return pick_form(LESS_THAN_FORMS, nbits, instances, resident_jobs, True)[1]
 
 
 def multiplier_for(nbits=8, instances=1, resident_jobs=1024):
@@ -523,7 +527,7 @@ def multiplier_for(nbits=8, instances=1, resident_jobs=1024):
 
 
 def subtractor_for(nbits=8, instances=1, resident_jobs=1024):
-    return pick_form(SUBTRACTOR_FORMS, nbits, instances, resident_jobs)[1]
+    return pick_form(SUBTRACTOR_FORMS, nbits, instances, resident_jobs, True)[1]
 
 
 def min_max_for(nbits=8, instances=1, resident_jobs=1024):

@@ -245,34 +245,37 @@ function Tfhe.lessThanTreeNetlist(nbits)
 end
 -- the form of lowest estimated cost for this many instances (backend.netlistCost: below a quarter of the resident set a
 -- level costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
--- outPos (optional): position of the builder's output-wire list in what it returns -- the candidates are then priced AFTER
--- backend.netlistOptimize (the multiplier: the row-by-row form shrinks from 320 to 176 bootstraps, the column form to 230)
+-- outPos: positions of the builder's output wires (lists or single wires) in what it returns -- the candidates are priced
+-- AFTER backend.netlistOptimize, the way runNetlist runs them (the row-by-row multiplier shrinks from 320 to 176 bootstraps,
+-- the column form to 230, the prefix adder from 48 to 40, the tree comparator from 29 to 27)
 local function cheapest(builders, nbits, instances, outPos)
   local best, bestCost
   for i = 1, #builders do
     local r = { builders[i](nbits) }
-    local gates = r[1].packed()
-    if outPos then
-      local o = {}
-      for k = 1, #r[outPos] do o[k] = string.pack("<i4", r[outPos][k]) end
-      gates = Tfhe.backend.netlistOptimize(gates, table.concat(o)) or gates
+    local gates, o = r[1].packed(), {}
+    for _, pos in ipairs(outPos) do
+      local part = r[pos]
+      if type(part) == "table" then
+        for k = 1, #part do o[#o + 1] = string.pack("<i4", part[k]) end
+      else o[#o + 1] = string.pack("<i4", part) end
     end
+    gates = Tfhe.backend.netlistOptimize(gates, table.concat(o)) or gates
     local cost = Tfhe.backend.netlistCost(gates, instances)
     if not best or (cost >= 0 and cost < bestCost) then best, bestCost = r, cost end
   end
   return table.unpack(best)
 end
 function Tfhe.adderNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.majAdderNetlist, Tfhe.prefixAdderNetlist }, nbits, instances)
+  return cheapest({ Tfhe.majAdderNetlist, Tfhe.prefixAdderNetlist }, nbits, instances, { 4 })
 end
 function Tfhe.lessThanNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances)
+  return cheapest({ Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist }, nbits, instances, { 4 })
 end
 function Tfhe.multiplierNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist }, nbits, instances, 4)
+  return cheapest({ Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist }, nbits, instances, { 4 })
 end
 function Tfhe.subtractorNetlistFor(nbits, instances)
-  return cheapest({ Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances)
+  return cheapest({ Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances, { 4, 5 })
 end
 -- min / max on the comparator picked for this many instances: one MUX per output bit behind it
 function Tfhe.minMaxNetlistFor(nbits, instances)
@@ -474,6 +477,13 @@ local function stack(arr)
   for i = 1, #arr do parts[i] = strToSample(arr[i]) end
   return table.concat(parts)
 end
+local function joined(...)                                -- wire lists end to end
+  local out = {}
+  for _, part in ipairs({ ... }) do
+    for i = 1, #part do out[#out + 1] = part[i] end
+  end
+  return out
+end
 local function pick(wires, ws)                            -- wires of ONE instance -> array of base64 ciphertext strings
   local out = {}
   for i = 1, #ws do out[i] = sampleToStr(planes(wires, ws[i], 1, 1)) end
@@ -482,7 +492,7 @@ end
 -- string-API circuits: arrays of base64 bit ciphertexts (LSB first) in, arrays out -- ONE backend call per circuit
 function Tfhe.addBits(A, B)                               -- -> #A + 1 ciphertexts (one instance: the log-depth form)
   local nl, a, b, sum = Tfhe.adderNetlistFor(#A, 1)
-  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1)
+  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1, sum)
   return wires and pick(wires, sum)
 end
 function Tfhe.lessThanBits(A, B)                          -- -> one ciphertext: 1 iff A < B (unsigned; the log-depth form)
@@ -492,14 +502,14 @@ function Tfhe.lessThanBits(A, B)                          -- -> one ciphertext: 
 end
 function Tfhe.minMaxBits(A, B)                            -- -> min, max (arrays of #A ciphertexts)
   local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlistFor(#A, 1)
-  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1)
+  local wires = Tfhe.runNetlist(nl, { [a] = stack(A), [b] = stack(B) }, 1, joined(mn, mx))
   if not wires then return nil end
   return pick(wires, mn), pick(wires, mx)
 end
 -- raw-buffer circuits over many instances: operands are samples [nbits][instances][n+1]
 function Tfhe.addBitsBatch(A, B, nbits, instances)      -- the form is picked by the instance count (adderNetlistFor)
   local nl, a, b, sum = Tfhe.adderNetlistFor(nbits, instances)
-  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances, sum)
   if not wires then return nil end
   local out = {}
   for i = 1, #sum do out[i] = planes(wires, sum[i], 1, instances) end
@@ -507,7 +517,7 @@ function Tfhe.addBitsBatch(A, B, nbits, instances)      -- the form is picked by
 end
 function Tfhe.subtractBitsBatch(A, B, nbits, instances)  -- -> [nbits + 1][instances][n+1]: difference bits, then the borrow
   local nl, a, b, diff, borrow = Tfhe.subtractorNetlistFor(nbits, instances)
-  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances, joined(diff, { borrow }))
   if not wires then return nil end
   local out = {}
   for i = 1, #diff do out[i] = planes(wires, diff[i], 1, instances) end
@@ -540,7 +550,7 @@ end
 function Tfhe.equalStrings(X, Y) return Tfhe.equalBits(X, Y) end
 function Tfhe.minMaxBitsBatch(A, B, nbits, instances)
   local nl, a, b, lt, mn, mx = Tfhe.minMaxNetlistFor(nbits, instances)
-  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances, joined(mn, mx, { lt }))
   if not wires then return nil end
   local lo, hi = {}, {}
   for i = 1, nbits do lo[i] = planes(wires, mn[i], 1, instances); hi[i] = planes(wires, mx[i], 1, instances) end

@@ -245,23 +245,25 @@ Tfhe.lessThanTreeNetlist = nbits => {
 };
 // the form of lowest estimated cost for this many instances (B.netlistCost: below a quarter of the resident set a level
 // costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
-// outKey (optional): the builder's output-wire list -- the candidates are then priced AFTER B.netlistOptimize (the multiplier:
-// the row-by-row form shrinks from 320 to 176 bootstraps, the column form to 230)
-const cheapest = (builders, nbits, instances, outKey) => {
+// outKeys: the builder's output wires (lists or single wires) -- the candidates are priced AFTER B.netlistOptimize, the way
+// runNetlist runs them (the row-by-row multiplier shrinks from 320 to 176 bootstraps, the column form to 230, the prefix
+// adder from 48 to 40, the tree comparator from 29 to 27)
+const outputsOf = (r, outKeys) => outKeys.flatMap(k => r[k]);
+const cheapest = (builders, nbits, instances, outKeys) => {
   let best = null, bestCost = 0;
   for (const build of builders) {
     const r = build(nbits);
     let gates = r.nl.packed();
-    if (outKey) gates = B.netlistOptimize(gates, Int32Array.from(r[outKey])) || gates;
+    gates = B.netlistOptimize(gates, Int32Array.from(outputsOf(r, outKeys))) || gates;
     const cost = B.netlistCost(gates, instances);
     if (best === null || (cost >= 0 && cost < bestCost)) { best = r; bestCost = cost; }
   }
   return best;
 };
-Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.majAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances);
-Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances);
-Tfhe.multiplierNetlistFor = (nbits, instances) => cheapest([Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist], nbits, instances, 'prod');
-Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances);
+Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.majAdderNetlist, Tfhe.prefixAdderNetlist], nbits, instances, ['sum']);
+Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances, ['lt']);
+Tfhe.multiplierNetlistFor = (nbits, instances) => cheapest([Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist], nbits, instances, ['prod']);
+Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances, ['diff', 'borrow']);
 // min / max on the comparator picked for this many instances: one MUX per output bit behind it
 Tfhe.minMaxNetlistFor = (nbits, instances) => {
   const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances), min = [], max = [];
@@ -350,7 +352,7 @@ const unstack = (buf, k) => { const w = B.sampleInts() * 4; return [...Array(k).
 // string-API circuits: arrays of base64 bit ciphertexts in, arrays out -- ONE backend call per circuit
 Tfhe.addBits = (A, Bs) => {   // one instance: the log-depth form
   const { nl, a, b, sum } = Tfhe.adderNetlistFor(A.length, 1);
-  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1);
+  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1, sum);
   return wires && sum.map(wi => unstack(planes(wires, wi, 1, 1), 1)[0]);
 };
 Tfhe.lessThanBits = (A, Bs) => {   // one instance: the log-depth form
@@ -360,19 +362,19 @@ Tfhe.lessThanBits = (A, Bs) => {   // one instance: the log-depth form
 };
 Tfhe.minMaxBits = (A, Bs) => {
   const { nl, a, b, min, max } = Tfhe.minMaxNetlistFor(A.length, 1);
-  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1);
+  const wires = Tfhe.runNetlist(nl, { [a]: stack(A), [b]: stack(Bs) }, 1, [...min, ...max]);
   const pick = ws => ws.map(wi => unstack(planes(wires, wi, 1, 1), 1)[0]);
   return wires && { min: pick(min), max: pick(max) };
 };
 // raw-buffer circuits over many instances: operands are Buffers [nbits][instances][n+1]
 Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // the form is picked by the instance count
   const { nl, a, b, sum } = Tfhe.adderNetlistFor(nbits, instances);
-  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, sum);
   return wires && Buffer.concat(sum.map(wi => planes(wires, wi, 1, instances)));   // [nbits + 1][instances][n+1]
 };
 Tfhe.subtractBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [nbits + 1][instances][n+1]: difference bits, then the borrow
   const { nl, a, b, diff, borrow } = Tfhe.subtractorNetlistFor(nbits, instances);
-  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, [...diff, borrow]);
   return wires && Buffer.concat([...diff, borrow].map(wi => planes(wires, wi, 1, instances)));
 };
 Tfhe.multiplyBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [2 nbits][instances][n+1]
@@ -382,7 +384,7 @@ Tfhe.multiplyBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [2 nbits][i
 };
 Tfhe.minMaxBitsBatch = (Abuf, Bbuf, nbits, instances) => {     // -> { min, max: [nbits][instances][n+1], lt: [instances][n+1] }
   const { nl, a, b, lt, min, max } = Tfhe.minMaxNetlistFor(nbits, instances);
-  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, [...min, ...max, lt]);
   const pick = ws => Buffer.concat(ws.map(wi => planes(wires, wi, 1, instances)));
   return wires && { min: pick(min), max: pick(max), lt: planes(wires, lt, 1, instances) };
 };

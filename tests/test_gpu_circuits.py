@@ -353,7 +353,8 @@ def test_min_max_4bit_bit_exact_and_optimised_select(eoc):
                       eoc.Gate(eoc.OPS["OR"], t0, t1, -1, o)]
         outs.append(o)
     opt = circuits.optimize(long_form, outs)
-    assert eoc.circuit_bootstraps(opt) == eoc.circuit_bootstraps(lt_gates) + 2 * nb
+    assert eoc.circuit_bootstraps(opt) == nb + 2 * nb      # the comparator chain as MAJ(NOT a, b, lt) per bit, one MUX per selected bit
+    assert eoc.circuit_bootstraps(circuits.optimize(long_form, outs, extension_gates=False)) == eoc.circuit_bootstraps(lt_gates) + 2 * nb
     assert eoc.circuit_bootstraps(long_form) == eoc.circuit_bootstraps(lt_gates) + 3 * nb
     wires2 = np.zeros((nxt, S, p.n + 1), np.int32)
     wires2[: 2 * nb] = wires[: 2 * nb]

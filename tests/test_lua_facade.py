@@ -277,9 +277,11 @@ def test_forms_are_picked_by_instance_count(facade):
     from eoc_tfhe_amd import Gate, circuits
     it, tf, be = facade
 
-    def shape(nl):
-        g = [Gate(*map(int, row)) for row in np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)]
+    def shape_of(g):
         return sum(2 if x.op == 10 else 0 if 11 <= x.op <= 14 else 1 for x in g), circuits.bootstrap_depth(g)
+
+    def shape(nl):
+        return shape_of([Gate(*map(int, row)) for row in np.frombuffer(it.call(nl.get(b"packed"), [])[0], "<i4").reshape(-1, 5)])
 
     for inst, add_want, lt_want in ((1, (48, 5), (29, 4)), (8, (48, 5), (29, 4)), (4096, (16, 8), (8, 8))):
         assert shape(call(it, tf, "adderNetlistFor", 8, inst)[0]) == add_want, inst
@@ -296,7 +298,9 @@ def test_forms_are_picked_by_instance_count(facade):
     assert np.array_equal(value_of(lt, 3), (A < B).astype(np.int64))
     out = call(it, tf, "addBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)[0]
     assert np.array_equal(value_of(out, 3), A + B)
-    assert be.calls[-1][:2] == ("circuitRun", len(circuits.prefix_adder(8)[0]))
+    # what runs is the picked form AFTER netlistOptimize (the prefix adder: 48 -> 40 bootstraps on the same 5 levels)
+    ran = circuits.adder(8, 3)[0]
+    assert be.calls[-1][:2] == ("circuitRun", len(ran)) and shape_of(ran) == (40, 5)
 
 
 def test_deferred_circuit_records_gate_calls_and_runs_them_in_one_backend_call(facade):

@@ -21,18 +21,22 @@ R = eng.resident_jobs() // 2                      # the pair kernel's resident s
 COUNTS = [int(x) for x in os.environ.get("COUNTS", "1,8,64,256,512,1024,2048,4096").split(",")]
 rng = np.random.default_rng(9)
 
+opt = c._optimized                                # what the facades run: the picked form through eoc_netlist_optimize
 OPS = [
     ("add8", {"ripple as written": lambda: c.ripple_carry_adder(8, carry_in_zero=True), "mux-carry": lambda: c.mux_carry_adder(8),
-              "xor3/maj": lambda: c.maj_adder(8), "prefix": lambda: c.prefix_adder(8)}, lambda A, B: A + B, 8),
-    ("sub8", {"ripple": lambda: c.subtractor(8)[:5], "xor3/maj": lambda: c.maj_subtractor(8)[:5],
-              "prefix": lambda: c.prefix_subtractor(8)[:5]}, lambda A, B: (A - B) % 256, 8),
-    ("lt8", {"ripple": lambda: c.less_than(8), "maj": lambda: c.maj_less_than(8), "tree": lambda: c.less_than_tree(8)},
+              "xor3/maj": lambda: c.maj_adder(8), "prefix": lambda: c.prefix_adder(8),
+              "prefix (optimized)": lambda: opt(c.prefix_adder(8))}, lambda A, B: A + B, 8),
+    ("sub8", {"ripple": lambda: c.subtractor(8)[:5], "ripple (optimized)": lambda: opt(c.subtractor(8))[:5],
+              "xor3/maj": lambda: c.maj_subtractor(8)[:5], "prefix": lambda: c.prefix_subtractor(8)[:5]},
+     lambda A, B: (A - B) % 256, 8),
+    ("lt8", {"ripple": lambda: c.less_than(8), "ripple (optimized)": lambda: opt(c.less_than(8)), "maj": lambda: c.maj_less_than(8),
+             "tree": lambda: c.less_than_tree(8), "tree (optimized)": lambda: opt(c.less_than_tree(8))},
      lambda A, B: (A < B).astype(np.int64), 8),
     ("mul8", {"rows as written": lambda: c.multiplier(8), "rows (optimized)": lambda: c.MULTIPLIER_FORMS["rows"](8),
               "columns (optimized)": lambda: c.MULTIPLIER_FORMS["wallace"](8)}, lambda A, B: A * B, 8),
 ]
 # the forms the facades choose between (the others are shown for comparison)
-CANDIDATES = {"add8": ("xor3/maj", "prefix"), "sub8": ("xor3/maj", "prefix"), "lt8": ("maj", "tree"),
+CANDIDATES = {"add8": ("xor3/maj", "prefix (optimized)"), "sub8": ("xor3/maj", "prefix"), "lt8": ("maj", "tree (optimized)"),
               "mul8": ("rows (optimized)", "columns (optimized)")}
 worst = 0.0
 agree = total = 0

@@ -95,6 +95,19 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
                                   eoc.Gate(eoc.OPS["AND"], out, z, -1, out + 2), eoc.Gate(eoc.OPS["OR"], out + 1, out + 2, -1, out + 3)]
                         avail += [out, out + 3]
                         continue
+                    if r == 1 and n_gates - len(gates) >= 3:       # a borrow / comparator step, sometimes with its difference bit
+                        x, y, z = pick(), pick(), pick()
+                        sel = "XOR" if rng.integers(0, 2) else "XNOR"
+                        differ, same = (x if rng.integers(0, 2) else y, z) if rng.integers(0, 2) else (z, x if rng.integers(0, 2) else y)
+                        br = (differ, same) if sel == "XOR" else (same, differ)
+                        gates += [eoc.Gate(eoc.OPS[sel], x, y, -1, out), eoc.Gate(eoc.OPS["MUX"], out, br[0], br[1], out + 1)]
+                        avail.append(out + 1)
+                        if rng.integers(0, 2):
+                            gates.append(eoc.Gate(eoc.OPS["XOR"], out, z, -1, out + 2))
+                            avail.append(out + 2)
+                        if rng.integers(0, 4) == 0:
+                            avail.append(out)                      # the selector stays visible: the NOT cannot take its wire
+                        continue
                     op = int(rng.choice(BOOT + FREE + [eoc.OPS["NOT"], eoc.OPS["MUX"]]))
                     ni = (0 if op in (eoc.OPS["CONST0"], eoc.OPS["CONST1"]) else 1 if op in (eoc.OPS["NOT"], eoc.OPS["COPY"])
                           else 3 if op in THREE else 2)
