@@ -194,11 +194,97 @@ def pipe_busy(pset, shape, launch_ms, steps_per_launch, sclk_mhz):
                     "fraction is quoted against"}
 
 
+LIVE_PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"),
+                   ("SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU_FMA_F64",
+                    "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
+
+
+def live_traffic(gates, n_steps, timeout_s=110):
+    """HBM / fabric bytes per k_blind_rotate launch -- and the kernel's L2 and LDS counters -- MEASURED IN THIS RUN: child
+    runs of this script's resident steps under `rocprofv3 --pmc`, one pass per counter group (FETCH_SIZE; WRITE_SIZE + the
+    L2 hit / miss counts; the SQ counters), counters only, no trace domain, the program itself behind `--`
+    (MI355X_MICROARCH.md, HBM / rocprofv3 section), averaged over the pair kernel's dispatches and corrected as that
+    section prescribes: KiB units, FETCH_SIZE doubled on gfx950.  Returns {"bytes_per_launch": ..., "cobounds": ...} or
+    {"error": ...} (no rocprofv3, a byte-count pass failed or timed out: the stored profile figure is reported instead,
+    labelled; a failed SQ pass only drops `cobounds`)."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="eoc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", EOC_BENCH_NO_LIVE_PMC="1", EOC_BENCH_NO_INLIB="1")
+    means, count, errors, t0 = {}, 0, [], time.time()
+    try:
+        for k, counters in enumerate(LIVE_PMC_PASSES):
+            cmd = [prof, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, f"pass{k}"), "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                   "--gates", str(gates), "--no-cpu-baseline", "--no-secondary", "--no-host-legs"]
+            proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)       # the group this call started, nothing else
+                proc.communicate()
+                errors.append(f"pass {counters[0]} timed out after {timeout_s} s")
+                break                                     # a pass that hung: start no further GPU step
+            if proc.returncode != 0:
+                errors.append(f"pass {counters[0]} rc={proc.returncode}: {(err or '')[-300:]}")
+                continue
+            acc = {}
+            for f in glob.glob(os.path.join(tmp, f"pass{k}", "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "k_blind_rotate<" in row.get("Kernel_Name", ""):
+                            acc.setdefault(row.get("Counter_Name"), []).append(float(row["Counter_Value"]))
+            for c in counters:
+                if acc.get(c):
+                    means[c] = sum(acc[c]) / len(acc[c])
+                    count = len(acc[c])
+                else:
+                    errors.append(f"no k_blind_rotate rows for {c}")
+    except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal
+        errors.append(repr(e)[:300])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if "FETCH_SIZE" not in means or "WRITE_SIZE" not in means:
+        return {"error": "; ".join(errors) or "no byte counters"}
+    fetch, write = means["FETCH_SIZE"], means["WRITE_SIZE"]
+    res = {"bytes_per_launch": int((2 * fetch + write) * 1024), "FETCH_SIZE_KiB": round(fetch, 1), "WRITE_SIZE_KiB": round(write, 1),
+           "dispatches_averaged": count, "seconds": round(time.time() - t0, 1),
+           "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024: KiB units, FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)",
+           "how": "child runs of this script (2 timed steps, resident operands) under rocprofv3 --pmc, one pass per counter group"}
+    cb = {}
+    if means.get("TCC_HIT_sum") is not None and means.get("TCC_MISS_sum") is not None:
+        cb["tcc_hit_bytes_per_launch"] = int(means["TCC_HIT_sum"] * 128)
+        cb["tcc_hit_rate"] = round(means["TCC_HIT_sum"] / (means["TCC_HIT_sum"] + means["TCC_MISS_sum"]), 4)
+    if means.get("SQ_WAVE_CYCLES"):
+        wave_steps = 2.0 * gates * n_steps                  # the pair kernel: two waves per job, n steps each
+        cb.update({"lds_wait_frac": round(means["SQ_WAIT_INST_LDS"] / means["SQ_WAVE_CYCLES"], 4),
+                   "SQ_WAIT_INST_LDS": round(means["SQ_WAIT_INST_LDS"]), "SQ_WAVE_CYCLES": round(means["SQ_WAVE_CYCLES"]),
+                   "lds_bank_conflict_cycles": means.get("SQ_LDS_BANK_CONFLICT"),
+                   "lds_insts_per_wave_step": round(means.get("SQ_INSTS_LDS", 0.0) / wave_steps, 1),
+                   "valu_insts_per_wave_step": round(means.get("SQ_INSTS_VALU", 0.0) / wave_steps, 1),
+                   # + the 16 truncations of the conversion, which the F64 counters do not tally
+                   "fp64_insts_per_wave_step": round((means.get("SQ_INSTS_VALU_FMA_F64", 0.0) + means.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                                                      + means.get("SQ_INSTS_VALU_MUL_F64", 0.0)) / wave_steps + 16, 1)})
+    if cb:
+        res["cobounds"] = cb
+    if errors:
+        res["pass_errors"] = errors
+    return res
+
+
 def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_launch_ms=None, sclk_mhz=None,
-                   shape="pair", steps_per_launch=None):
-    """FP64-issue roofline of k_blind_rotate from this run's HIP-event launch duration (+ the stored PMC byte count).
+                   shape="pair", steps_per_launch=None, live=None):
+    """FP64-issue roofline of k_blind_rotate from this run's HIP-event launch duration; `traffic` = the PMC byte count
+    measured in this run (live = live_traffic()'s result) or, failing that, the stored profile figure, labelled.
     br_ms = blind-rotate time of `jobs_per_launch` whole blind rotations; traffic_launch_ms = duration of ONE kernel
-    launch when a blind rotation runs as several (Set B: two parts), since the stored byte count is per launch."""
+    launch when a blind rotation runs as several (Set B: two parts), since the byte count is per launch."""
     bk_b, _, _ = algorithmic_bytes(p)
     flop_job = algorithmic_flops(p)
     tf = flop_job * jobs_per_launch / (br_ms * 1e-3) / 1e12 if br_ms > 0 else 0.0
@@ -213,9 +299,14 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
             tsrc = f"profiles/traffic.json ({tj.get('collected', 'stored rocprofv3 PMC figure')}; not measured in this run)"
         except Exception:
             traffic = None
+    stored, unit = traffic, "HBM/fabric bytes per launch (rocprofv3 PMC, stored profile figure)"
+    if live and live.get("bytes_per_launch"):
+        traffic = live["bytes_per_launch"]
+        tsrc = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (bench.py live_traffic)"
+        unit = "HBM/fabric bytes per launch (rocprofv3 PMC, this run)"
     blk = {"bound": "fp64_valu", "kernel": "k_blind_rotate_wide" if shape == "wide" else "k_blind_rotate", "achieved": round(tf, 2),
            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
-           "traffic": traffic, "traffic_unit": "HBM/fabric bytes per launch (rocprofv3 PMC, stored profile figure)",
+           "traffic": traffic, "traffic_unit": unit,
            "traffic_source": tsrc,
            "flop_per_job": flop_job, "jobs_per_launch": round(jobs_per_launch, 1),
            "avg_launch_ms": round(br_ms, 4),
@@ -244,9 +335,12 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
             cb = json.load(open(tpath)).get(f"cobounds_{pset}_wide" if shape == "wide" else f"cobounds_{pset}")
         except Exception:
             cb = None
+    lds_source = "profiles/traffic.json (stored rocprofv3 PMC passes of this launch shape; not measured in this run)"
+    if live and live.get("cobounds") and "lds_wait_frac" in live["cobounds"]:
+        cb = dict(cb or {}, **live["cobounds"])          # the measured counters replace the stored ones, key by key
+        lds_source = "measured in this run: rocprofv3 --pmc child passes (bench.py live_traffic); ds_write_b128 count from the ISA"
     if cb:
-        blk["lds"] = dict(cb, source="profiles/traffic.json (stored rocprofv3 PMC passes of this launch shape; not "
-                                      "measured in this run)",
+        blk["lds"] = dict(cb, source=lds_source,
                           note="lds_wait_frac = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES: share of wave cycles in which an LDS "
                                "instruction is ready but the CU's LDS pipe is taken; the store path moves ~79 B/clk/CU "
                                f"(ds_write_b128 = 13.6 cycles), {cb.get('ds_write_b128_per_wave_step')} such stores per "
@@ -255,11 +349,17 @@ def roofline_block(p, pset, G, jobs_per_launch, br_ms, with_traffic, traffic_lau
     if pb_:
         blk["pipes"] = pb_
         blk["bound_primary"] = pb_["bound_primary"]
+    if live is not None:
+        blk["traffic_live"] = live
+        blk["traffic_stored"] = stored
     if traffic and br_ms > 0:
         gbps = traffic / ((traffic_launch_ms or br_ms) * 1e-3) / 1e9
+        is_live = bool(live and live.get("bytes_per_launch"))
         blk["hbm_measured"] = {"GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM_PEAK_GBPS, 4),
-                               "bytes_per_launch": traffic, "source": "profiles/traffic.json",
-                               "note": "counter bytes of the stored profile / this run's launch duration: every XCD "
+                               "bytes_per_launch": traffic,
+                               "source": "this run's PMC passes" if is_live else "profiles/traffic.json",
+                               "note": ("counter bytes of this run's PMC passes" if is_live else "counter bytes of the stored profile")
+                                       + " / this run's launch duration: every XCD "
                                        "fetches each key row once, the other uses hit L2 -- HBM is not the bound"}
     return blk
 
@@ -824,6 +924,13 @@ def main():
         except Exception as e:  # noqa: BLE001 -- time-out, missing interpreter, bad JSON: reported, never fatal
             in_library = {"error": repr(e)[:600]}
 
+    # roofline.traffic measured in THIS run (N = 1, the headline workload on the pair kernel): two PMC child passes after
+    # every timed leg is over; a failure falls back to the stored figure and says so
+    live = None
+    if (single_nand and not args.no_secondary and world == 1 and rank == 0 and args.pset == "A" and not wide_headline
+            and os.environ.get("EOC_BENCH_NO_LIVE_PMC") != "1"):
+        live = live_traffic(G, p.n)
+
     if rank == 0:
         total_gates = boots_per_step * world * args.steps
         value = total_gates / elapsed
@@ -862,7 +969,7 @@ def main():
             # a level wider than the resident set is timed as ONE span of several kernel launches (slices): the pipe
             # figures need the steps that span covers
             "roofline": roofline_block(p, args.pset, G, jobs_per_launch, br_ms, args.workload == "nand",
-                                       sclk_mhz=clk.summary()[0], shape="wide" if wide_headline else "pair",
+                                       sclk_mhz=clk.summary()[0], shape="wide" if wide_headline else "pair", live=live,
                                        steps_per_launch=p.n * max(1, -(-int(round(jobs_per_launch)) // (
                                            (8 if wide_headline else 4) * torch.cuda.get_device_properties(dev).multi_processor_count)))),
             "clock": {"sclk_mhz_under_load": clk.summary()[0], "sclk_mhz_max_seen": clk.summary()[1],
