@@ -199,7 +199,7 @@ LIVE_PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"
                     "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"))
 
 
-def live_traffic(gates, n_steps, timeout_s=110):
+def live_traffic(gates, n_steps, pset="A", timeout_s=110):
     """HBM / fabric bytes per k_blind_rotate launch -- and the kernel's L2 and LDS counters -- MEASURED IN THIS RUN: child
     runs of this script's resident steps under `rocprofv3 --pmc`, one pass per counter group (FETCH_SIZE; WRITE_SIZE + the
     L2 hit / miss counts; the SQ counters), counters only, no trace domain, the program itself behind `--`
@@ -222,7 +222,7 @@ def live_traffic(gates, n_steps, timeout_s=110):
         for k, counters in enumerate(LIVE_PMC_PASSES):
             cmd = [prof, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, f"pass{k}"), "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                   "--gates", str(gates), "--no-cpu-baseline", "--no-secondary", "--no-host-legs"]
+                   "--gates", str(gates), "--pset", pset, "--no-cpu-baseline", "--no-secondary", "--no-host-legs"]
             proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
                                     start_new_session=True)
             try:
@@ -263,7 +263,7 @@ def live_traffic(gates, n_steps, timeout_s=110):
         cb["tcc_hit_bytes_per_launch"] = int(means["TCC_HIT_sum"] * 128)
         cb["tcc_hit_rate"] = round(means["TCC_HIT_sum"] / (means["TCC_HIT_sum"] + means["TCC_MISS_sum"]), 4)
     if means.get("SQ_WAVE_CYCLES"):
-        wave_steps = 2.0 * gates * n_steps                  # the pair kernel: two waves per job, n steps each
+        wave_steps = 2.0 * gates * n_steps                  # the pair kernel: two waves per job, n_steps per launch
         cb.update({"lds_wait_frac": round(means["SQ_WAIT_INST_LDS"] / means["SQ_WAVE_CYCLES"], 4),
                    "SQ_WAIT_INST_LDS": round(means["SQ_WAIT_INST_LDS"]), "SQ_WAVE_CYCLES": round(means["SQ_WAVE_CYCLES"]),
                    "lds_bank_conflict_cycles": means.get("SQ_LDS_BANK_CONFLICT"),
@@ -497,10 +497,10 @@ def main():
                             f"(as written: 40 on 17); the work counted is the work DONE ({eoc.circuit_bootstraps(gates) * S} "
                             f"bootstraps) -- compare pairs_per_s with adder8's")
                 elif name == "adder8_prefix":
-                    gates, n_wires, aw, bw, sw = circuits.prefix_adder(8)
-                    desc = (f"8-bit parallel-prefix (Sklansky, MUX cells) adder, {S} pairs: {eoc.circuit_bootstraps(gates)} "
-                            f"bootstraps per pair on {eoc.netlist_levels(gates)[2]} levels -- the form picked below a quarter of "
-                            f"the resident set")
+                    gates, n_wires, aw, bw, sw = circuits.adder(8, S)      # what Tfhe.addBitsBatch runs for S pairs
+                    desc = (f"8-bit parallel-prefix (Sklansky, MUX cells) adder through eoc_netlist_optimize, {S} pairs: "
+                            f"{eoc.circuit_bootstraps(gates)} bootstraps per pair on {eoc.netlist_levels(gates)[2]} levels -- the "
+                            f"form the facades pick below a quarter of the resident set")
                 bits_in = {aw[0]: ((A[:, None] >> np.arange(8)) & 1), bw[0]: ((B[:, None] >> np.arange(8)) & 1)}
             else:
                 S = instances or 1024 // max(1, world) or 1
@@ -926,10 +926,12 @@ def main():
 
     # roofline.traffic measured in THIS run (N = 1, the headline workload on the pair kernel): two PMC child passes after
     # every timed leg is over; a failure falls back to the stored figure and says so
-    live = None
+    live = live_b = None
     if (single_nand and not args.no_secondary and world == 1 and rank == 0 and args.pset == "A" and not wide_headline
             and os.environ.get("EOC_BENCH_NO_LIVE_PMC") != "1"):
         live = live_traffic(G, p.n)
+        if setb_res:                                      # Set B's blind rotation runs as nlaunch_b / steps launches
+            live_b = live_traffic(G, setb["p"].n * args.steps // max(1, setb_res[2]), "B")
 
     if rank == 0:
         total_gates = boots_per_step * world * args.steps
@@ -993,7 +995,7 @@ def main():
                 "prefix_over_ripple": round(lat["adder8_prefix"] / lat["adder8"], 4),
                 "decrypt_ok": all(chk() for _, _, _, _, chk in latency_runs),
                 "note": "one 8-bit addition over 8 input pairs, wires resident, median of 7 calls: 17 / 8 / 5 dependent levels "
-                        "(40 / 16 / 48 bootstraps per pair); Tfhe.addBits / addBitsBatch pick the form by instance count "
+                        "(40 / 16 / 40 bootstraps per pair); Tfhe.addBits / addBitsBatch pick the form by instance count "
                         "(eoc_netlist_cost)"}
         if setb_res:
             tb, ktb, nlaunch_b = setb_res
@@ -1004,7 +1006,7 @@ def main():
             bb0, bb1 = setb["bits"]
             okb = bool(np.array_equal(setb["sk"].decrypt_bits(setb["d"][2].cpu().numpy()), 1 - (bb0 & bb1)))
             rb = roofline_block(pb, "B", G, G, per_batch_ms, True, traffic_launch_ms=brb_ms, sclk_mhz=setb_clk,
-                                steps_per_launch=pb.n * args.steps / max(1, nlaunch_b))
+                                steps_per_launch=pb.n * args.steps / max(1, nlaunch_b), live=live_b)
             rb["launches_per_blind_rotation"] = round(nlaunch_b / args.steps, 2)
             rb["avg_single_launch_ms"] = round(brb_ms, 4)
             sec["nand1024_setB"] = {
