@@ -215,6 +215,8 @@ def live_traffic(gates, n_steps, pset="A", timeout_s=110):
     prof = shutil.which("rocprofv3")
     if prof is None:
         return {"error": "rocprofv3 not on PATH"}
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "this process is itself being profiled: no nested rocprofv3 passes"}
     tmp = tempfile.mkdtemp(prefix="eoc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", EOC_BENCH_NO_LIVE_PMC="1", EOC_BENCH_NO_INLIB="1")
     means, count, errors, t0 = {}, 0, [], time.time()
