@@ -638,6 +638,70 @@ def _drop_dead(gates, keep):
         gates = live
 
 
+_MIRROR = {"ANDYN": "ANDNY", "ORYN": "ORNY"}            # ANDYN(a, b) = ANDNY(b, a), ORYN(a, b) = ORNY(b, a)
+_SYMMETRIC = ("NAND", "AND", "OR", "NOR", "XOR", "XNOR")
+
+
+def merge_duplicates(gates, outputs):
+    """a gate that repeats an earlier one -- same opcode on the same wires, operand order aside where the gate is symmetric --
+    becomes a COPY of it (a naive builder computes a XOR b once for the sum and once for the carry), and a gate that reads
+    one wire twice is no gate: AND(x, x) = x, XOR(x, x) = 0, NAND(x, x) = NOT x, MUX(s, b, b) = b, MUX(s, s, c) = OR(s, c),
+    MUX(s, b, s) = AND(s, b), MAJ(x, x, y) = x, XOR3(x, x, y) = y.  The COPYs are free and the later passes look through
+    them.  Single-assignment netlists only."""
+    _check_ssa(gates)
+    rep, seen, out = {}, {}, []
+
+    def unary(kind, wire, o):
+        return Gate(OPS[kind], wire, -1, -1, o)
+
+    for g in gates:
+        name = _NAMES[g.op]
+        i0, i1, i2 = (rep.get(w, w) if w >= 0 else w for w in (g.in0, g.in1, g.in2))
+        new = None
+        if name in _SEM2:
+            if i0 == i1:
+                f0, f1 = _SEM2[name](0, 0), _SEM2[name](1, 1)
+                new = (unary("COPY", i0, g.out) if (f0, f1) == (0, 1) else unary("NOT", i0, g.out) if (f0, f1) == (1, 0)
+                       else Gate(OPS["CONST1" if f0 else "CONST0"], -1, -1, -1, g.out))
+            else:
+                if name in _MIRROR:
+                    name, i0, i1 = _MIRROR[name], i1, i0
+                elif name in _SYMMETRIC and i1 < i0:
+                    i0, i1 = i1, i0
+                key = (name, i0, i1)
+        elif name == "MUX":
+            if i1 == i2:
+                new = unary("COPY", i1, g.out)
+            elif i0 == i1:
+                name, i0, i1, i2 = "OR", min(i0, i2), max(i0, i2), -1
+                key = (name, i0, i1)
+            elif i0 == i2:
+                name, i0, i1, i2 = "AND", min(i0, i1), max(i0, i1), -1
+                key = (name, i0, i1)
+            else:
+                key = (name, i0, i1, i2)
+        elif name in _SEM3:
+            a, b, c = sorted((i0, i1, i2))
+            if a == b or b == c:
+                new = unary("COPY", b if name == "MAJ" else (c if a == b else a), g.out)
+            else:
+                i0, i1, i2 = a, b, c
+                key = (name, a, b, c)
+        else:                                           # NOT / COPY / CONSTANT: free, left to fold_nots / fold_constants
+            new = Gate(g.op, i0 if name in ("NOT", "COPY") else -1, -1, -1, g.out)
+        if new is None:
+            if key in seen:
+                new = unary("COPY", seen[key], g.out)
+                rep[g.out] = seen[key]
+            else:
+                seen[key] = g.out
+                new = Gate(OPS[name], i0, i1, i2 if name in ("MUX", "MAJ", "XOR3") else -1, g.out)
+        elif _NAMES[new.op] == "COPY":
+            rep[g.out] = new.in0
+        out.append(new)
+    return _drop_dead(out, outputs)
+
+
 def fold_constants(gates, outputs):
     """Constant propagation: bootsCONSTANT wires (and what follows from them) are folded into their readers -- a
     two-input gate with one known input is that constant, a COPY or a NOT of the other input (free); MUX with a known
@@ -900,14 +964,15 @@ def _normalized(gates):
 
 
 def optimize(gates, outputs, extension_gates=True):
-    """fold_constants, fold_nots, fuse_mux, fuse_carry (and, with the extension gates, fuse_maj and fuse_xor3), repeated
+    """merge_duplicates, fold_constants, fold_nots, fuse_mux, fuse_carry (and, with the extension gates, fuse_maj and fuse_xor3), repeated
     until nothing changes; returns the rewritten netlist (same wire numbering, never more bootstraps, never more levels).
     With the extension gates (default) a textbook full adder becomes XOR3 + MAJ -- the literal 8-bit ripple-carry adder 40
     bootstraps / 17 levels -> 16 / 8; extension_gates=False stays inside libtfhe's boots* family (carry as MUX: 30 / 8).
     eoc_netlist_optimize(_ex) (csrc/host.cpp) is the native twin: same passes, same order, same result."""
     cur = _normalized(gates)
     for _ in range(8):
-        nxt = fuse_carry(fuse_mux(fold_nots(fold_constants(cur, outputs), outputs), outputs), outputs, extension_gates)
+        nxt = fold_nots(fold_constants(merge_duplicates(cur, outputs), outputs), outputs)
+        nxt = fuse_carry(fuse_mux(nxt, outputs), outputs, extension_gates)
         if extension_gates:
             nxt = fuse_xor3(fuse_maj(nxt, outputs), outputs)
         if _as_tuples(nxt) == _as_tuples(cur):

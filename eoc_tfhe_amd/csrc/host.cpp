@@ -10,10 +10,12 @@
 #include "../../include/eoc_tfhe_gpu.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -774,7 +776,8 @@ extern "C" int eoc_global_circuit_run(const eoc_gate *gates, size_t n_gates, int
 }
 
 // ---- netlist rewriting (host side, no GPU): the native twin of eoc_tfhe_amd/circuits.py -------------------
-// Four passes, repeated until nothing changes (same passes, same order, same result as circuits.optimize):
+// The passes, repeated until nothing changes (same passes, same order, same result as circuits.optimize):
+//   merge_duplicates a gate that repeats an earlier one becomes a COPY of it; a gate that reads one wire twice is no gate
 //   fold_constants  bootsCONSTANT wires are folded into their readers (a two-input gate with one known input is a constant,
 //                   a COPY or a NOT; MUX with a known branch is a two-input gate: one bootstrap instead of two)
 //   fold_nots       NOT / COPY are free, but in front of a bootstrapped gate unnecessary altogether: the ten two-input boots*
@@ -858,6 +861,90 @@ inline eoc_gate mk(int op, int32_t i0, int32_t i1, int32_t i2, int32_t out)
     g.in2 = i2;
     g.out = out;
     return g;
+}
+
+// a gate that repeats an earlier one (same opcode on the same wires, operand order aside where the gate is symmetric) becomes
+// a COPY of it, and a gate that reads one wire twice is no gate: AND(x, x) = x, XOR(x, x) = 0, NAND(x, x) = NOT x,
+// MUX(s, b, b) = b, MUX(s, s, c) = OR(s, c), MUX(s, b, s) = AND(s, b), MAJ(x, x, y) = x, XOR3(x, x, y) = y.  The COPYs are
+// free and the later passes look through them.
+Netlist pass_merge_duplicates(const Netlist &in, const std::vector<char> &keep, size_t n_wires)
+{
+    std::vector<int32_t> rep(n_wires);
+    for (size_t w = 0; w < n_wires; w++) rep[w] = (int32_t)w;
+    std::map<std::array<int32_t, 4>, int32_t> seen;
+    Netlist res;
+    res.reserve(in.size());
+    for (const eoc_gate &g : in) {
+        int op = g.op;
+        const int nin = nl_inputs(op);
+        int32_t i0 = nin >= 1 ? rep[g.in0] : -1, i1 = nin >= 2 ? rep[g.in1] : -1, i2 = nin >= 3 ? rep[g.in2] : -1;
+        bool keyed = false, done = false;
+        eoc_gate out = mk(op, i0, i1, i2, g.out);
+        if (op >= EOC_NAND && op <= EOC_ORYN) {
+            if (i0 == i1) {
+                const int f0 = sem2(op, 0, 0), f1 = sem2(op, 1, 1);
+                out = f0 == f1 ? mk(f0 ? EOC_CONST1 : EOC_CONST0, -1, -1, -1, g.out) : mk(f0 ? EOC_NOT : EOC_COPY, i0, -1, -1, g.out);
+                done = true;
+            } else {
+                if (op == EOC_ANDYN || op == EOC_ORYN) { // ANDYN(a, b) = ANDNY(b, a), ORYN(a, b) = ORNY(b, a)
+                    op = op == EOC_ANDYN ? EOC_ANDNY : EOC_ORNY;
+                    std::swap(i0, i1);
+                } else if (op != EOC_ANDNY && op != EOC_ORNY && i1 < i0) {
+                    std::swap(i0, i1);
+                }
+                keyed = true;
+            }
+        } else if (op == EOC_MUX) {
+            if (i1 == i2) {
+                out = mk(EOC_COPY, i1, -1, -1, g.out);
+                done = true;
+            } else {
+                if (i0 == i1) {
+                    op = EOC_OR;
+                    i1 = std::max(i0, i2);
+                    i0 = std::min(i0, i2);
+                    i2 = -1;
+                } else if (i0 == i2) {
+                    op = EOC_AND;
+                    const int32_t lo = std::min(i0, i1), hi = std::max(i0, i1);
+                    i0 = lo;
+                    i1 = hi;
+                    i2 = -1;
+                }
+                keyed = true;
+            }
+        } else if (nl_lin3(op)) {
+            int32_t v[3] = {i0, i1, i2};
+            std::sort(v, v + 3);
+            if (v[0] == v[1] || v[1] == v[2]) {
+                out = mk(EOC_COPY, op == EOC_MAJ ? v[1] : (v[0] == v[1] ? v[2] : v[0]), -1, -1, g.out);
+                done = true;
+            } else {
+                i0 = v[0];
+                i1 = v[1];
+                i2 = v[2];
+                keyed = true;
+            }
+        } else {
+            done = true; // NOT / COPY / CONSTANT: free, left to the other passes
+        }
+        if (keyed) {
+            const std::array<int32_t, 4> key = {op, i0, i1, i2};
+            auto it = seen.find(key);
+            if (it != seen.end()) {
+                out = mk(EOC_COPY, it->second, -1, -1, g.out);
+                rep[g.out] = it->second;
+            } else {
+                seen.emplace(key, g.out);
+                out = mk(op, i0, i1, i2, g.out);
+            }
+        } else if (done && out.op == EOC_COPY) {
+            rep[g.out] = out.in0;
+        }
+        res.push_back(out);
+    }
+    drop_dead(res, keep, n_wires);
+    return res;
 }
 
 Netlist pass_fold_constants(const Netlist &in, const std::vector<char> &keep, size_t n_wires)
@@ -1196,8 +1283,8 @@ static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, cons
     for (size_t k = 0; k < n_outputs; k++) keep[outputs[k]] = 1;
 
     for (int round = 0; round < 8; round++) {
-        Netlist nxt = pass_fuse_carry(
-            pass_fuse_mux(pass_fold_nots(pass_fold_constants(cur, keep, n_wires), keep, n_wires), keep, n_wires), keep, n_wires, ext);
+        Netlist nxt = pass_fold_nots(pass_fold_constants(pass_merge_duplicates(cur, keep, n_wires), keep, n_wires), keep, n_wires);
+        nxt = pass_fuse_carry(pass_fuse_mux(nxt, keep, n_wires), keep, n_wires, ext);
         if (ext) nxt = pass_fuse_xor3(pass_fuse_maj(nxt, keep, n_wires), keep, n_wires);
         const bool same = same_netlist(nxt, cur);
         cur.swap(nxt);

@@ -235,6 +235,9 @@ int eoc_circuit_run_device(eoc_engine *e, const eoc_gate *gates, size_t n_gates,
 /* number of bootstraps (blind rotations) a netlist costs per instance: MUX = 2, NOT / COPY / CONSTANT = 0, everything else 1 */
 size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
 /* Netlist rewriting on the host (no GPU), four passes repeated until nothing changes:
+ *   duplicates  a gate that repeats an earlier one (same opcode, same wires, operand order aside where the gate is symmetric)
+ *               becomes a COPY of it; a gate that reads one wire twice is no gate (AND(x, x) = x, XOR(x, x) = 0, MUX(s, b, b) = b,
+ *               MUX(s, s, c) = OR(s, c), MAJ(x, x, y) = x, ...)
  *   constants   bootsCONSTANT wires are folded into their readers (AND(x, 0) = 0, XOR(x, 1) = NOT x, MUX(s, 0, c) = ANDNY(s, c),
  *               MUX(s, b, 1) = ORNY(s, b), ...: a MUX with a known branch costs one bootstrap instead of two)
  *   NOT / COPY  folded into their readers (the ten two-input gates are closed under input negation; a negated MUX selector

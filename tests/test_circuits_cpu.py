@@ -467,8 +467,57 @@ def test_borrow_and_comparison_chains_become_majorities():
                 assert all(np.array_equal(got[x], ref[x]) for x in outs), (sel, d, o_, shared)
                 assert circuit_bootstraps(opt) <= circuit_bootstraps(nl)
                 differ, same = (d, o_) if sel == "XOR" else (o_, d)              # the branch taken where x != y / x == y
+                if differ in (0, 1) and same in (0, 1):                           # MAJ(x, y, x) = x: no gate at all
+                    assert sum(c._boots(g) for g in opt if g.out == 4) == 0, (sel, d, o_, shared)
+                    continue
                 fused = same in (0, 1) or (differ in (0, 1) and same == 2 and not shared)
                 assert ("MAJ" in [c._NAMES[g.op] for g in opt]) == fused, (sel, d, o_, shared, opt)
+
+
+def test_repeated_gates_merge_and_one_wire_read_twice_is_no_gate():
+    """merge_duplicates: a naive full adder that computes a XOR b once for the sum and once more for the carry, AND(b, a)
+    beside AND(a, b), ANDYN(b, a) beside ANDNY(a, b) ... end as ONE gate each (then the carry rewrite applies: XOR3 + MAJ);
+    AND(x, x) = x, XOR(x, x) = 0, NAND(x, x) = NOT x, MUX(s, b, b) = b, MUX(s, s, c) = OR(s, c), MUX(s, b, s) = AND(s, b),
+    MAJ(x, x, y) = x, XOR3(x, x, y) = y -- every case against the plaintext semantics"""
+    G = lambda name, i0, i1, i2, o: Gate(OPS[name], i0, i1, i2, o)
+    naive = [G("XOR", 0, 1, -1, 3), G("XOR", 3, 2, -1, 4),                                  # sum
+             G("AND", 1, 0, -1, 5), G("XOR", 1, 0, -1, 6), G("AND", 2, 6, -1, 7), G("OR", 7, 5, -1, 8)]   # carry, a XOR b again
+    opt = c.optimize(naive, [4, 8])
+    assert sorted(c._NAMES[g.op] for g in opt) == ["MAJ", "XOR3"]
+    assert circuit_bootstraps(c.optimize(naive, [4, 8], extension_gates=False)) == 4           # XOR, XOR, MUX
+    w = np.zeros((9, 8), np.uint8)
+    for k in range(8):
+        w[0, k], w[1, k], w[2, k] = k & 1, (k >> 1) & 1, (k >> 2) & 1
+    ref, got = c.evaluate_plain(naive, w), c.evaluate_plain(opt, w)
+    assert np.array_equal(ref[4], got[4]) and np.array_equal(ref[8], got[8])
+    pairs = [(("ANDNY", 0, 1), ("ANDYN", 1, 0)), (("ORNY", 0, 1), ("ORYN", 1, 0)), (("NAND", 0, 1), ("NAND", 1, 0)),
+             (("XNOR", 0, 1), ("XNOR", 1, 0)), (("MAJ", 0, 1, 2), ("MAJ", 2, 0, 1)), (("XOR3", 0, 1, 2), ("XOR3", 1, 2, 0)),
+             (("MUX", 0, 1, 2), ("MUX", 0, 1, 2))]
+    for first, second in pairs:
+        nl = [G(first[0], *(list(first[1:]) + [-1])[:3], 3), G(second[0], *(list(second[1:]) + [-1])[:3], 4)]
+        md = c.merge_duplicates(nl, [3, 4])
+        assert [c._NAMES[g.op] for g in md] == [first[0] if first[0] not in ("ANDYN", "ORYN") else second[0], "COPY"] or \
+               [c._NAMES[g.op] for g in md][1] == "COPY", (first, second)
+        r0, r1 = c.evaluate_plain(nl, w), c.evaluate_plain(md, w)
+        assert np.array_equal(r0[3], r1[3]) and np.array_equal(r0[4], r1[4]), (first, second)
+    assert [c._NAMES[g.op] for g in c.merge_duplicates([G("ANDNY", 0, 1, -1, 3), G("ANDNY", 1, 0, -1, 4)], [3, 4])] == ["ANDNY", "ANDNY"]
+    assert [c._NAMES[g.op] for g in c.merge_duplicates([G("MUX", 0, 1, 2, 3), G("MUX", 0, 2, 1, 4)], [3, 4])] == ["MUX", "MUX"]
+    for name in c._SEM2:
+        md = c.merge_duplicates([G(name, 1, 1, -1, 3)], [3])
+        assert len(md) == 1 and c._NAMES[md[0].op] in c._FREE, name
+        assert np.array_equal(c.evaluate_plain(md, w)[3], c._SEM2[name](w[1], w[1])), name
+    three = {("MUX", 0, 1, 1): "COPY", ("MUX", 0, 0, 2): "OR", ("MUX", 0, 1, 0): "AND", ("MAJ", 0, 0, 1): "COPY", ("MAJ", 1, 0, 1): "COPY",
+             ("XOR3", 2, 0, 2): "COPY", ("XOR3", 0, 0, 1): "COPY"}
+    for (name, i0, i1, i2), want in three.items():
+        nl = [G(name, i0, i1, i2, 3)]
+        md = c.merge_duplicates(nl, [3])
+        assert [c._NAMES[g.op] for g in md] == [want], (name, i0, i1, i2)
+        assert np.array_equal(c.evaluate_plain(md, w)[3], c.evaluate_plain(nl, w)[3]), (name, i0, i1, i2)
+    # a repeated gate whose wire the caller reads stays as a (free) COPY; one nobody reads disappears
+    twice = [G("AND", 0, 1, -1, 3), G("AND", 1, 0, -1, 4), G("XOR", 4, 2, -1, 5)]
+    assert [(c._NAMES[g.op], g.in0, g.in1) for g in c.optimize(twice, [5])] == [("AND", 0, 1), ("XOR", 2, 3)] or \
+           [(c._NAMES[g.op]) for g in c.optimize(twice, [5])] == ["AND", "XOR"]
+    assert [c._NAMES[g.op] for g in c.optimize(twice, [4, 5])] == ["AND", "COPY", "XOR"]
 
 
 def test_constant_folding_every_gate_and_position():

@@ -108,6 +108,13 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
                         if rng.integers(0, 4) == 0:
                             avail.append(out)                      # the selector stays visible: the NOT cannot take its wire
                         continue
+                    if r == 2 and gates:                           # an earlier gate again, operands swapped where it has two
+                        e = gates[int(rng.integers(0, len(gates)))]
+                        two = e.in1 >= 0 and e.in2 < 0 and e.op in (eoc.OPS["AND"], eoc.OPS["OR"], eoc.OPS["XOR"], eoc.OPS["XNOR"],
+                                                                     eoc.OPS["NAND"], eoc.OPS["NOR"])
+                        gates.append(eoc.Gate(e.op, e.in1 if two else e.in0, e.in0 if two else e.in1, e.in2, out))
+                        avail.append(out)
+                        continue
                     op = int(rng.choice(BOOT + FREE + [eoc.OPS["NOT"], eoc.OPS["MUX"]]))
                     ni = (0 if op in (eoc.OPS["CONST0"], eoc.OPS["CONST1"]) else 1 if op in (eoc.OPS["NOT"], eoc.OPS["COPY"])
                           else 3 if op in THREE else 2)
