@@ -530,17 +530,33 @@ def subtractor_for(nbits=8, instances=1, resident_jobs=1024):
     return pick_form(SUBTRACTOR_FORMS, nbits, instances, resident_jobs, True)[1]
 
 
-def min_max_for(nbits=8, instances=1, resident_jobs=1024):
-    """(min, max) on the comparator picked for this many instances, one MUX per output bit behind it.
+def min_max_on(built_less_than, xor3_select=False):
+    """(min, max) behind a comparator: min_i = MUX(lt, a_i, b_i) and max_i = MUX(lt, b_i, a_i) -- or, xor3_select,
+    max_i = XOR3(a_i, b_i, min_i) (min_i XOR max_i = a_i XOR b_i): ONE bootstrap instead of the MUX's two, one level later.
     Returns (gates, n_wires, a_wires, b_wires, min_wires, max_wires)."""
-    gates, nxt, a, b, lt = less_than_for(nbits, instances, resident_jobs)
-    gates = list(gates)
+    gates, nxt, a, b, lt = built_less_than
+    gates, nbits = list(gates), len(a)
     mn = list(range(nxt, nxt + nbits))
     mx = list(range(nxt + nbits, nxt + 2 * nbits))
     for i in range(nbits):
         gates.append(Gate(OPS["MUX"], lt, a[i], b[i], mn[i]))
-        gates.append(Gate(OPS["MUX"], lt, b[i], a[i], mx[i]))
+        gates.append(Gate(OPS["XOR3"], a[i], b[i], mn[i], mx[i]) if xor3_select else Gate(OPS["MUX"], lt, b[i], a[i], mx[i]))
     return gates, nxt + 2 * nbits, a, b, mn, mx
+
+
+def min_max_for(nbits=8, instances=1, resident_jobs=1024):
+    """(min, max) for this many instances, through optimize: every comparator form with both ways of selecting the maximum,
+    the cheapest by netlist_cost -- tree comparator + two MUXes per bit for small batches (8 bits: 59 bootstraps on 5 levels),
+    MAJ chain + MUX + XOR3 per bit for wide ones (32 on 10; with two MUXes 40 on 9).
+    Returns (gates, n_wires, a_wires, b_wires, min_wires, max_wires)."""
+    best = None
+    for build in LESS_THAN_FORMS.values():
+        for xor3_select in (False, True):
+            r = _optimized(min_max_on(build(nbits), xor3_select))
+            key = (netlist_cost(r[0], instances, resident_jobs), sum(_boots(g) for g in r[0]))
+            if best is None or key < best[0]:
+                best = (key, r)
+    return best[1]
 
 
 # ---- plaintext semantics and netlist rewriting -----------------------------------------------------

@@ -277,15 +277,28 @@ end
 function Tfhe.subtractorNetlistFor(nbits, instances)
   return cheapest({ Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist }, nbits, instances, { 4, 5 })
 end
--- min / max on the comparator picked for this many instances: one MUX per output bit behind it
-function Tfhe.minMaxNetlistFor(nbits, instances)
-  local nl, a, b, lt = Tfhe.lessThanNetlistFor(nbits, instances)
+-- (min, max) behind a comparator: min_i = MUX(lt, a_i, b_i) and max_i = MUX(lt, b_i, a_i) -- or, xor3Select,
+-- max_i = XOR3(a_i, b_i, min_i) (min_i XOR max_i = a_i XOR b_i): ONE bootstrap instead of the MUX's two, one level later
+function Tfhe.minMaxNetlistOn(nbits, xor3Select, nl, a, b, lt)
   local mn, mx = {}, {}
   for i = 0, nbits - 1 do
     mn[#mn + 1] = nl.gate(OP.MUX, lt, a + i, b + i)
-    mx[#mx + 1] = nl.gate(OP.MUX, lt, b + i, a + i)
+    if xor3Select then mx[#mx + 1] = nl.gate(OP.XOR3, a + i, b + i, mn[#mn])
+    else mx[#mx + 1] = nl.gate(OP.MUX, lt, b + i, a + i) end
   end
   return nl, a, b, lt, mn, mx
+end
+-- every comparator form with both ways of selecting the maximum, the cheapest for this many instances: tree comparator + two
+-- MUXes per bit for small batches (8 bits: 59 bootstraps on 5 levels after the optimizer), MAJ chain + MUX + XOR3 for wide
+-- ones (32 on 10; with two MUXes 40 on 9)
+function Tfhe.minMaxNetlistFor(nbits, instances)
+  local builders = {}
+  for _, lt in ipairs({ Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist }) do
+    for _, x3 in ipairs({ false, true }) do
+      builders[#builders + 1] = function(n) return Tfhe.minMaxNetlistOn(n, x3, lt(n)) end
+    end
+  end
+  return cheapest(builders, nbits, instances, { 5, 6 })
 end
 -- a * b -> 2 nbits bits, LSB first: nbits^2 AND partial products, nbits - 1 shifted ripple-carry rows
 function Tfhe.multiplierNetlist(nbits)

@@ -68,7 +68,7 @@ for (const inst of [1, 5000]) {
   }
 }
 assert.deepStrictEqual(shape(tfhe.minMaxNetlistFor(8, 1).nl), [29 + 32, 5]);
-assert.deepStrictEqual(shape(tfhe.minMaxNetlistFor(8, 4096).nl), [8 + 32, 9]);
+assert.deepStrictEqual(shape(tfhe.minMaxNetlistFor(8, 4096).nl), [8 + 16 + 8, 10]);   // MAJ chain, min by MUX, max = XOR3(a, b, min)
 // bootstraps / dependent levels of the 8-bit forms (eoc_tfhe_amd/circuits.py states the same numbers)
 assert.deepStrictEqual(shape(tfhe.adderNetlist(8).nl), [37, 15]);
 assert.deepStrictEqual(shape(tfhe.adderNetlist(8, true).nl), [40, 17]);

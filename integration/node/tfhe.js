@@ -264,12 +264,22 @@ Tfhe.adderNetlistFor = (nbits, instances) => cheapest([Tfhe.majAdderNetlist, Tfh
 Tfhe.lessThanNetlistFor = (nbits, instances) => cheapest([Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist], nbits, instances, ['lt']);
 Tfhe.multiplierNetlistFor = (nbits, instances) => cheapest([Tfhe.multiplierNetlist, Tfhe.wallaceMultiplierNetlist], nbits, instances, ['prod']);
 Tfhe.subtractorNetlistFor = (nbits, instances) => cheapest([Tfhe.majSubtractorNetlist, Tfhe.prefixSubtractorNetlist], nbits, instances, ['diff', 'borrow']);
-// min / max on the comparator picked for this many instances: one MUX per output bit behind it
-Tfhe.minMaxNetlistFor = (nbits, instances) => {
-  const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances), min = [], max = [];
-  for (let i = 0; i < nbits; i++) { min.push(nl.gate(OP.MUX, lt, a + i, b + i)); max.push(nl.gate(OP.MUX, lt, b + i, a + i)); }
+// (min, max) behind a comparator: min_i = MUX(lt, a_i, b_i) and max_i = MUX(lt, b_i, a_i) -- or, xor3Select,
+// max_i = XOR3(a_i, b_i, min_i) (min_i XOR max_i = a_i XOR b_i): ONE bootstrap instead of the MUX's two, one level later
+Tfhe.minMaxNetlistOn = ({ nl, a, b, lt }, nbits, xor3Select) => {
+  const min = [], max = [];
+  for (let i = 0; i < nbits; i++) {
+    min.push(nl.gate(OP.MUX, lt, a + i, b + i));
+    max.push(xor3Select ? nl.gate(OP.XOR3, a + i, b + i, min[i]) : nl.gate(OP.MUX, lt, b + i, a + i));
+  }
   return { nl, a, b, lt, min, max };
 };
+// every comparator form with both ways of selecting the maximum, the cheapest for this many instances: tree comparator + two
+// MUXes per bit for small batches (8 bits: 59 bootstraps on 5 levels after the optimizer), MAJ chain + MUX + XOR3 for wide
+// ones (32 on 10; with two MUXes 40 on 9)
+Tfhe.minMaxNetlistFor = (nbits, instances) => cheapest(
+  [Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist].flatMap(lt => [false, true].map(x3 => n => Tfhe.minMaxNetlistOn(lt(n), n, x3))),
+  nbits, instances, ['min', 'max']);
 // a * b in logarithmic depth: partial products in columns by weight, Dadda column compression by full adders (XOR3 + MAJ: the
 // extension gates, one level) and half adders until no column holds more than two wires, then ONE parallel-prefix addition of
 // the two remaining rows; 8 bits: 244 bootstraps on 11 levels against the row-by-row form's 320 on 40

@@ -570,9 +570,11 @@ def test_form_is_picked_by_instance_count():
         # inside libtfhe's gate family the MUX-carry adder and the ripple comparator are the wide-batch forms
         assert c.pick_form({k: v for k, v in c.ADDER_FORMS.items() if k in ("mux", "prefix")}, 8, S)[0] == "mux"
         assert c.pick_form({k: v for k, v in c.LESS_THAN_FORMS.items() if k != "maj"}, 8, S)[0] == "ripple"
-    for S, depth in ((1, 5), (4096, 9)):
+    # min / max: tree comparator + two MUXes per bit for small batches; MAJ chain + MUX + XOR3(a, b, min) for wide ones (one
+    # bootstrap instead of the second MUX's two, one level later); in between the tree with the XOR3 selection
+    for S, shape in ((1, (59, 5)), (64, (51, 6)), (4096, (32, 10))):
         gates, nw, a, b, mn, mx = c.min_max_for(8, S)
-        assert c.bootstrap_depth(gates) == depth
+        assert (circuit_bootstraps(gates), c.bootstrap_depth(gates)) == shape
         rng = np.random.default_rng(S)
         A, B = rng.integers(0, 256, 500), rng.integers(0, 256, 500)
         w = np.zeros((nw, 500), np.uint8)

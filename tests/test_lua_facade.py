@@ -291,7 +291,7 @@ def test_forms_are_picked_by_instance_count(facade):
     assert shape(call(it, tf, "subtractorNetlistFor", 8, 2)[0]) == (48, 5)
     assert shape(call(it, tf, "subtractorNetlistFor", 8, 4096)[0]) == (16, 8)
     assert shape(call(it, tf, "minMaxNetlistFor", 8, 1)[0]) == (29 + 32, 5)
-    assert shape(call(it, tf, "minMaxNetlistFor", 8, 4096)[0]) == (8 + 32, 9)
+    assert shape(call(it, tf, "minMaxNetlistFor", 8, 4096)[0]) == (8 + 16 + 8, 10)      # MAJ chain, min by MUX, max = XOR3(a, b, min)
     A = np.array([200, 13, 255]); B = np.array([100, 250, 255])
     lo, hi, lt = call(it, tf, "minMaxBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)
     assert np.array_equal(value_of(lo, 3), np.minimum(A, B)) and np.array_equal(value_of(hi, 3), np.maximum(A, B))

@@ -32,11 +32,18 @@ OPS = [
     ("lt8", {"ripple": lambda: c.less_than(8), "ripple (optimized)": lambda: opt(c.less_than(8)), "maj": lambda: c.maj_less_than(8),
              "tree": lambda: c.less_than_tree(8), "tree (optimized)": lambda: opt(c.less_than_tree(8))},
      lambda A, B: (A < B).astype(np.int64), 8),
+    # min / max: built[4] = min wires (checked below), built[5] = max wires (checked through CHECK_MAX)
+    ("minmax8", {"chain + 2 MUX as written": lambda: c.min_max(8),
+                 "maj + 2 MUX": lambda: opt(c.min_max_on(c.maj_less_than(8))),
+                 "maj + MUX + XOR3": lambda: opt(c.min_max_on(c.maj_less_than(8), True)),
+                 "tree + 2 MUX": lambda: opt(c.min_max_on(c.less_than_tree(8))),
+                 "tree + MUX + XOR3": lambda: opt(c.min_max_on(c.less_than_tree(8), True))}, lambda A, B: np.minimum(A, B), 8),
     ("mul8", {"rows as written": lambda: c.multiplier(8), "rows (optimized)": lambda: c.MULTIPLIER_FORMS["rows"](8),
               "columns (optimized)": lambda: c.MULTIPLIER_FORMS["wallace"](8)}, lambda A, B: A * B, 8),
 ]
 # the forms the facades choose between (the others are shown for comparison)
 CANDIDATES = {"add8": ("xor3/maj", "prefix (optimized)"), "sub8": ("xor3/maj", "prefix"), "lt8": ("maj", "tree (optimized)"),
+              "minmax8": ("maj + 2 MUX", "maj + MUX + XOR3", "tree + 2 MUX", "tree + MUX + XOR3"),
               "mul8": ("rows (optimized)", "columns (optimized)")}
 worst = 0.0
 agree = total = 0
@@ -64,6 +71,9 @@ for name, forms, truth, nbits in OPS:
             ms = float(np.median(ts[1:])) * 1e3
             got = sum(sk.decrypt_bits(wires[w].cpu().numpy()).astype(np.int64) << i for i, w in enumerate(outw))
             ok = bool(np.array_equal(got, truth(A, B)))
+            if name == "minmax8":
+                top = sum(sk.decrypt_bits(wires[w].cpu().numpy()).astype(np.int64) << i for i, w in enumerate(built[5]))
+                ok = ok and bool(np.array_equal(top, np.maximum(A, B)))
             est = eoc.netlist_cost(gates, S, R) / 10.0
             row[fname] = (ms, est, ok, eoc.circuit_bootstraps(gates), eoc.netlist_levels(gates)[2])
         cand = CANDIDATES[name]
