@@ -109,7 +109,7 @@ def test_every_circuit_form_stays_inside_the_noise_budget():
         forms = [c.ripple_carry_adder(8, carry_in_zero=True), c.mux_carry_adder(8), c.prefix_adder(8), c.prefix_adder(16),
                  c.subtractor(8), c.prefix_subtractor(8), c.less_than(8), c.less_than_tree(8), c.min_max_for(8, 1),
                  c.multiplier(4), c.wallace_multiplier(8), c.wallace_multiplier(8, False), c.string_equal(4),
-                 c.maj_adder(8), c.maj_subtractor(8), c.maj_less_than(8), c.min_max_for(8, 4096), c.multiplier(8)]
+                 c.maj_adder(8), c.maj_subtractor(8), c.maj_less_than(8), c.min_max_for(8, 64), c.min_max_for(8, 4096), c.multiplier(8)]
         worst = []
         for built in forms:
             gates = built[0]
