@@ -17,7 +17,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 TAG = "r06_final"          # the set DESIGN.md section 7 quotes (one box, one collect_profiles.sh call on the final library)
-TAGS = ["r06_final"]
+TAGS = ["r06_final", "r06_last"]   # r06_last: the same collection on the round's LAST tree (another box; bench.py measures its own traffic)
 
 
 def line(name):
@@ -144,3 +144,20 @@ def test_the_driver_line_measures_its_own_traffic():
     assert d["decrypt_ok"] and d["cpu_baseline"]["bit_exact_vs_gpu"] and d["steps"] == 20 and d["warmup"] == 5
     lat = d["secondary"]["latency_8_instances_ms"]
     assert lat["decrypt_ok"] and lat["prefix_over_ripple"] <= 0.4
+
+
+def test_the_last_tree_reproduces_the_quoted_set():
+    """r06_last_* (the round's last tree, another box of the pool) against r06_final_* (the set the documents quote): the
+    headline within the pool's box-to-box spread, the stored PMC byte counts within 1 %, the live figure of the last line
+    within 0.1 % of the separately collected passes of its own call"""
+    a, b = line("r06_final_bench_A.json"), line("r06_last_bench_A.json")
+    assert b["value"] == pytest.approx(a["value"], rel=0.04) and b["roofline"]["frac"] == pytest.approx(a["roofline"]["frac"], rel=0.04)
+    ta, tb = json.load(open(os.path.join(P, "traffic.json"))), json.load(open(os.path.join(P, "r06_last_traffic.json")))
+    for k in ("blind_rotate_A_1024", "blind_rotate_B_1024", "blind_rotate_A_wide_2048"):
+        assert tb[k] == pytest.approx(ta[k], rel=0.01), k
+    assert b["roofline"]["traffic_source"].startswith("measured in this run")
+    assert b["roofline"]["traffic"] == pytest.approx(tb["blind_rotate_A_1024"], rel=1e-3)
+    assert b["secondary"]["nand1024_setB"]["roofline"]["traffic"] == pytest.approx(tb["blind_rotate_B_1024"], rel=0.02)
+    sa, sb = a["secondary"], b["secondary"]
+    for k in ("adder8", "adder8_optimized", "adder8_optimized_boots_gates"):
+        assert sb[k]["pairs_per_s"] == pytest.approx(sa[k]["pairs_per_s"], rel=0.04), k
