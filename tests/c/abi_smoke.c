@@ -96,6 +96,73 @@ int main(int argc, char **argv)
         CHECK(n_maj == 7 && n_xor3 == 7);                                        /* bit 0 folds to XOR + AND */
         CHECK(eoc_netlist_cost(ad_opt, (size_t)no, 4096, 0) == 16 * 4 * 30);
     }
+    {   /* the optimizer on 4000 random single-assignment netlists over every opcode (this block also runs in the ASan /
+         * UBSan build, tools/sanitize_host.sh): each wire's truth table over the 4 circuit inputs as a 16-bit mask, before
+         * and after -- same outputs, never more bootstraps, never more levels, with and without the extension gates */
+        uint32_t seed = 12345u;
+#define RND(m) ((seed = seed * 1664525u + 1013904223u) >> 8) % (uint32_t)(m)
+        for (int trial = 0; trial < 4000; trial++) {
+            enum { NIN = 4, MAXG = 48 };
+            eoc_gate g[MAXG], o[MAXG];
+            const int ng = 1 + (int)(RND(MAXG));
+            for (int k = 0; k < ng; k++) {
+                const int avail = NIN + k, op = (int)(RND(17));
+                g[k] = (eoc_gate){op, (int32_t)(RND(avail)), (int32_t)(RND(avail)), (int32_t)(RND(avail)), NIN + k};
+                if (op != EOC_MUX && op != EOC_MAJ && op != EOC_XOR3 && RND(8) == 0)
+                    g[k].in2 = -7 - (int32_t)(RND(1000));                         /* junk in a slot the gate does not use */
+                if (op == EOC_CONST0 || op == EOC_CONST1) g[k].in0 = -1;
+            }
+            int32_t outs[3];
+            const int no_ = ng < 3 ? ng : 3;
+            for (int k = 0; k < no_; k++) outs[k] = NIN + (int32_t)(RND(ng));
+            for (unsigned flags = 0; flags < 2; flags++) {
+                const int64_t m = eoc_netlist_optimize_ex(g, (size_t)ng, outs, (size_t)no_, o, flags ? EOC_NL_BOOTS_GATES_ONLY : 0);
+                CHECK(m >= 0 && m <= ng);
+                uint16_t ref[NIN + MAXG], got[NIN + MAXG];
+                const uint16_t in_mask[NIN] = {0xAAAA, 0xCCCC, 0xF0F0, 0xFF00};
+                for (int pass = 0; pass < 2; pass++) {
+                    uint16_t *w = pass ? got : ref;
+                    const eoc_gate *nl = pass ? o : g;
+                    const int cnt = pass ? (int)m : ng;
+                    memset(w, 0, sizeof ref);
+                    memcpy(w, in_mask, sizeof in_mask);
+                    for (int k = 0; k < cnt; k++) {
+                        const eoc_gate q = nl[k];
+                        const int three = q.op == EOC_MUX || q.op == EOC_MAJ || q.op == EOC_XOR3, one = q.op == EOC_NOT || q.op == EOC_COPY;
+                        const int zero = q.op == EOC_CONST0 || q.op == EOC_CONST1;
+                        const uint16_t a = zero ? 0 : w[q.in0], b = (zero || one) ? 0 : w[q.in1], c = three ? w[q.in2] : 0;
+                        uint16_t r;
+                        switch (q.op) {
+                        case EOC_NAND: r = (uint16_t)~(a & b); break;
+                        case EOC_AND: r = a & b; break;
+                        case EOC_OR: r = a | b; break;
+                        case EOC_NOR: r = (uint16_t)~(a | b); break;
+                        case EOC_XOR: r = a ^ b; break;
+                        case EOC_XNOR: r = (uint16_t)~(a ^ b); break;
+                        case EOC_ANDNY: r = (uint16_t)(~a & b); break;
+                        case EOC_ANDYN: r = (uint16_t)(a & ~b); break;
+                        case EOC_ORNY: r = (uint16_t)(~a | b); break;
+                        case EOC_ORYN: r = (uint16_t)(a | ~b); break;
+                        case EOC_MUX: r = (uint16_t)((a & b) | (~a & c)); break;
+                        case EOC_NOT: r = (uint16_t)~a; break;
+                        case EOC_COPY: r = a; break;
+                        case EOC_CONST0: r = 0; break;
+                        case EOC_CONST1: r = 0xFFFF; break;
+                        case EOC_MAJ: r = (uint16_t)((a & b) | (a & c) | (b & c)); break;
+                        default: r = a ^ b ^ c; break; /* EOC_XOR3 */
+                        }
+                        w[q.out] = r;
+                    }
+                }
+                for (int k = 0; k < no_; k++) CHECK(ref[outs[k]] == got[outs[k]]);
+                CHECK(eoc_circuit_bootstraps(o, (size_t)m) <= eoc_circuit_bootstraps(g, (size_t)ng));
+                int64_t d_before = 0, d_after = 0;
+                CHECK(eoc_netlist_levels(g, (size_t)ng, NULL, &d_before) >= 0 && eoc_netlist_levels(o, (size_t)m, NULL, &d_after) >= 0);
+                CHECK(d_after <= d_before);
+            }
+        }
+#undef RND
+    }
     /* f2, server side: the cloud key alone as the process-global context (no secret in it) */
     size_t ck_len = eoc_cloud_key_blob_bytes(&p);
     void *ck = malloc(ck_len);
