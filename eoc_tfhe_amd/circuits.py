@@ -876,8 +876,8 @@ def fuse_mux(gates, outputs):
 
 def fuse_carry(gates, outputs, extension_gates=False):
     """The carry of a textbook full adder, OR(AND(a, b), AND(XOR(a, b), c)), is MUX(XOR(a, b), c, a): where the inputs
-    differ the carry-in passes, where they agree either of them is the carry.  The two AND wires must be single-use and
-    not outputs; the XOR wire stays (the sum bit reads it too).  3 bootstraps on 2 dependent levels become 2 bootstraps on
+    differ the carry-in passes, where they agree either of them is the carry.  The wire of AND(XOR(a, b), c) must be
+    single-use and no output; the XOR wire stays (the sum bit reads it too), AND(a, b) stays if something else reads it.  3 bootstraps on 2 dependent levels become 2 bootstraps on
     ONE level: the literal 8-bit ripple-carry adder goes from 40 bootstraps / 17 levels to 32 / 9 (30 / 8 once the
     constant carry-in is folded).  Single-assignment netlists only."""
     _check_ssa(gates)
@@ -892,7 +892,7 @@ def fuse_carry(gates, outputs, extension_gates=False):
             for x, y in ((src[g.in0], src[g.in1]), (src[g.in1], src[g.in0])):      # x = a AND b, y = p AND c
                 if m is not None or x.op != AND or y.op != AND or x.in0 == x.in1:
                     continue
-                if any(uses.get(t.out, 0) != 1 or t.out in keep for t in (x, y)):
+                if uses.get(y.out, 0) != 1 or y.out in keep:       # a AND b may have other readers: it then simply stays
                     continue
                 for p, c in ((y.in0, y.in1), (y.in1, y.in0)):
                     q = src.get(p)
@@ -985,16 +985,24 @@ def optimize(gates, outputs, extension_gates=True):
     With the extension gates (default) a textbook full adder becomes XOR3 + MAJ -- the literal 8-bit ripple-carry adder 40
     bootstraps / 17 levels -> 16 / 8; extension_gates=False stays inside libtfhe's boots* family (carry as MUX: 30 / 8).
     eoc_netlist_optimize(_ex) (csrc/host.cpp) is the native twin: same passes, same order, same result."""
-    cur = _normalized(gates)
-    for _ in range(8):
-        nxt = fold_nots(fold_constants(merge_duplicates(cur, outputs), outputs), outputs)
-        nxt = fuse_carry(fuse_mux(nxt, outputs), outputs, extension_gates)
-        if extension_gates:
-            nxt = fuse_xor3(fuse_maj(nxt, outputs), outputs)
-        if _as_tuples(nxt) == _as_tuples(cur):
-            break
-        cur = nxt
-    return cur
+    # merging repeated gates can take a single-use wire away from a later pattern (two sums sharing one a XOR b): both
+    # pipelines run and the better result is kept -- fewest bootstraps, then fewest levels, then fewest gates; merged on ties
+    best = None
+    for merge in (True, False):
+        cur = _normalized(gates)
+        for _ in range(8):
+            nxt = merge_duplicates(cur, outputs) if merge else cur
+            nxt = fold_nots(fold_constants(nxt, outputs), outputs)
+            nxt = fuse_carry(fuse_mux(nxt, outputs), outputs, extension_gates)
+            if extension_gates:
+                nxt = fuse_xor3(fuse_maj(nxt, outputs), outputs)
+            if _as_tuples(nxt) == _as_tuples(cur):
+                break
+            cur = nxt
+        key = (sum(_boots(g) for g in cur), bootstrap_depth(cur), len(cur))
+        if best is None or key < best[0]:
+            best = (key, cur)
+    return best[1]
 
 
 # ---- levels and the level-cost estimate (what picks a circuit form for an instance count) ------------------------

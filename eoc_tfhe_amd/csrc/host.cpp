@@ -1099,7 +1099,7 @@ Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_
             for (int side = 0; side < 2 && !done; side++) { // x = a AND b, y = p AND c
                 const eoc_gate &x = cur[src[side ? g.in1 : g.in0]], &y = cur[src[side ? g.in0 : g.in1]];
                 if (x.op != EOC_AND || y.op != EOC_AND || x.in0 == x.in1) continue;
-                if (uses[x.out] != 1 || uses[y.out] != 1 || keep[x.out] || keep[y.out]) continue;
+                if (uses[y.out] != 1 || keep[y.out]) continue; // a AND b may have other readers: it then simply stays
                 for (int sw = 0; sw < 2 && !done; sw++) {
                     const int32_t p = sw ? y.in1 : y.in0, c = sw ? y.in0 : y.in1;
                     if (src[p] < 0) continue;
@@ -1282,16 +1282,39 @@ static int64_t netlist_optimize_impl(const eoc_gate *gates, size_t n_gates, cons
     std::vector<char> keep(n_wires, 0);
     for (size_t k = 0; k < n_outputs; k++) keep[outputs[k]] = 1;
 
-    for (int round = 0; round < 8; round++) {
-        Netlist nxt = pass_fold_nots(pass_fold_constants(pass_merge_duplicates(cur, keep, n_wires), keep, n_wires), keep, n_wires);
-        nxt = pass_fuse_carry(pass_fuse_mux(nxt, keep, n_wires), keep, n_wires, ext);
-        if (ext) nxt = pass_fuse_xor3(pass_fuse_maj(nxt, keep, n_wires), keep, n_wires);
-        const bool same = same_netlist(nxt, cur);
-        cur.swap(nxt);
-        if (same) break;
+    // merging repeated gates can take a single-use wire away from a later pattern (two sums sharing one a XOR b): both
+    // pipelines run and the better result is kept -- fewest bootstraps, then fewest levels, then fewest gates; merged on ties
+    const Netlist start = cur;
+    Netlist best;
+    std::array<int64_t, 3> best_key = {0, 0, 0};
+    for (int merge = 1; merge >= 0; merge--) {
+        cur = start;
+        for (int round = 0; round < 8; round++) {
+            Netlist nxt = merge ? pass_merge_duplicates(cur, keep, n_wires) : cur;
+            nxt = pass_fold_nots(pass_fold_constants(nxt, keep, n_wires), keep, n_wires);
+            nxt = pass_fuse_carry(pass_fuse_mux(nxt, keep, n_wires), keep, n_wires, ext);
+            if (ext) nxt = pass_fuse_xor3(pass_fuse_maj(nxt, keep, n_wires), keep, n_wires);
+            const bool same = same_netlist(nxt, cur);
+            cur.swap(nxt);
+            if (same) break;
+        }
+        int64_t boots = 0, depth = 0;
+        std::vector<int> lev(cur.size(), 0);
+        const int nlev = eoc_levelise(cur.data(), cur.size(), n_wires, lev.data());
+        std::vector<char> has(nlev + 1, 0);
+        for (size_t k = 0; k < cur.size(); k++) {
+            boots += cur[k].op == EOC_MUX ? 2 : (nl_free(cur[k].op) ? 0 : 1);
+            if (!nl_free(cur[k].op)) has[lev[k]] = 1;
+        }
+        depth = std::count(has.begin(), has.end(), (char)1);
+        const std::array<int64_t, 3> key = {boots, depth, (int64_t)cur.size()};
+        if (merge || key < best_key) {
+            best_key = key;
+            best.swap(cur);
+        }
     }
-    std::copy(cur.begin(), cur.end(), gates_out);
-    return (int64_t)cur.size();
+    std::copy(best.begin(), best.end(), gates_out);
+    return (int64_t)best.size();
 }
 
 // Levelisation of a netlist exactly as eoc_circuit_run_device evaluates it (a netlist need not be single-assignment to RUN).

@@ -243,7 +243,7 @@ size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
  *   NOT / COPY  folded into their readers (the ten two-input gates are closed under input negation; a negated MUX selector
  *               swaps the branches; NOT(NOT x) = COPY; every reader looks through COPY)
  *   MUX fusion  OR(AND(s, b), ANDNY(s, c)) with single-use inner wires -> MUX(s, b, c)
- *   carry       OR(AND(a, b), AND(XOR(a, b), c)) with single-use AND wires -> MUX(XOR(a, b), c, a): the textbook full adder's
+ *   carry       OR(AND(a, b), AND(XOR(a, b), c)) (the second AND single-use) -> MUX(XOR(a, b), c, a): the textbook full adder's
  *               carry as ONE gate on ONE level (the literal 8-bit ripple-carry adder: 40 bootstraps / 17 levels -> 30 / 8)
  * and gates nobody reads are dropped.  `outputs` are the wires the caller reads afterwards.  Input slots an opcode does not
  * use are ignored whatever they hold (and come back as -1); wire ids must be below 2^24.  Single-assignment netlists

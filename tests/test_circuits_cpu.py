@@ -394,7 +394,7 @@ def test_carry_rewrite_on_the_literal_adder():
         _adder_check(c.optimize(gates, s, extension_gates=False), nw, a, b, s, 4)
         _adder_check(c.fuse_carry(gates, s), nw, a, b, s, 4)
         _adder_check(c.fuse_carry(gates, s, extension_gates=True), nw, a, b, s, 4)
-    # every operand order of the pattern; a shared AND wire blocks it
+    # every operand order of the pattern; a shared a AND b stays for its other reader, a shared p AND c blocks the rewrite
     for g_ab in ((0, 1), (1, 0)):
         for x_ab in ((0, 1), (1, 0)):
             for pc_swap in (0, 1):
@@ -410,7 +410,15 @@ def test_carry_rewrite_on_the_literal_adder():
                     assert np.array_equal(c.evaluate_plain(nl, w)[6], c.evaluate_plain(opt, w)[6])
     shared = [Gate(OPS["XOR"], 0, 1, -1, 3), Gate(OPS["AND"], 0, 1, -1, 4), Gate(OPS["AND"], 3, 2, -1, 5),
               Gate(OPS["OR"], 4, 5, -1, 6), Gate(OPS["XOR"], 4, 2, -1, 7)]
-    assert [c._NAMES[g.op] for g in c.fuse_carry(shared, [6, 7])] == ["XOR", "AND", "AND", "OR", "XOR"]
+    assert [c._NAMES[g.op] for g in c.fuse_carry(shared, [6, 7])] == ["XOR", "AND", "MUX", "XOR"]
+    assert [c._NAMES[g.op] for g in c.fuse_carry(shared, [6, 7], extension_gates=True)] == ["AND", "MAJ", "XOR"]
+    blocked = [Gate(OPS["XOR"], 0, 1, -1, 3), Gate(OPS["AND"], 0, 1, -1, 4), Gate(OPS["AND"], 3, 2, -1, 5),
+               Gate(OPS["OR"], 4, 5, -1, 6), Gate(OPS["XOR"], 5, 2, -1, 7)]
+    assert [c._NAMES[g.op] for g in c.fuse_carry(blocked, [6, 7])] == ["XOR", "AND", "AND", "OR", "XOR"]
+    # two carries over the same a, b written out twice: merge_duplicates shares a AND b, and both still become majorities
+    twice = [Gate(OPS["XOR"], 0, 1, -1, 4), Gate(OPS["AND"], 0, 1, -1, 5), Gate(OPS["AND"], 4, 2, -1, 6), Gate(OPS["OR"], 5, 6, -1, 7),
+             Gate(OPS["AND"], 1, 0, -1, 8), Gate(OPS["AND"], 4, 3, -1, 9), Gate(OPS["OR"], 8, 9, -1, 10)]
+    assert [c._NAMES[g.op] for g in c.optimize(twice, [7, 10])] == ["MAJ", "MAJ"]
 
 
 def _flat(parts):
@@ -513,11 +521,16 @@ def test_repeated_gates_merge_and_one_wire_read_twice_is_no_gate():
         md = c.merge_duplicates(nl, [3])
         assert [c._NAMES[g.op] for g in md] == [want], (name, i0, i1, i2)
         assert np.array_equal(c.evaluate_plain(md, w)[3], c.evaluate_plain(nl, w)[3]), (name, i0, i1, i2)
+    # merging may not cost anything: two sums over the same a, b with a XOR b written twice stay two XOR3 (a shared a XOR b
+    # would be a third bootstrap) -- optimize runs both pipelines and keeps the better result
+    two_sums = [G("XOR", 0, 1, -1, 4), G("XOR", 4, 2, -1, 5), G("XOR", 1, 0, -1, 6), G("XOR", 6, 3, -1, 7)]
+    assert [c._NAMES[g.op] for g in c.optimize(two_sums, [5, 7])] == ["XOR3", "XOR3"]
     # a repeated gate whose wire the caller reads stays as a (free) COPY; one nobody reads disappears
     twice = [G("AND", 0, 1, -1, 3), G("AND", 1, 0, -1, 4), G("XOR", 4, 2, -1, 5)]
     assert [(c._NAMES[g.op], g.in0, g.in1) for g in c.optimize(twice, [5])] == [("AND", 0, 1), ("XOR", 2, 3)] or \
            [(c._NAMES[g.op]) for g in c.optimize(twice, [5])] == ["AND", "XOR"]
-    assert [c._NAMES[g.op] for g in c.optimize(twice, [4, 5])] == ["AND", "COPY", "XOR"]
+    assert [c._NAMES[g.op] for g in c.optimize(twice, [4, 5])] == ["AND", "XOR"]
+    assert [c._NAMES[g.op] for g in c.optimize(twice, [3, 4, 5])] == ["AND", "COPY", "XOR"]
 
 
 def test_constant_folding_every_gate_and_position():
