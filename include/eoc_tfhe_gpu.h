@@ -237,7 +237,9 @@ size_t eoc_circuit_bootstraps(const eoc_gate *gates, size_t n_gates);
 /* Netlist rewriting on the host (no GPU), four passes repeated until nothing changes:
  *   duplicates  a gate that repeats an earlier one (same opcode, same wires, operand order aside where the gate is symmetric)
  *               becomes a COPY of it; a gate that reads one wire twice is no gate (AND(x, x) = x, XOR(x, x) = 0, MUX(s, b, b) = b,
- *               MUX(s, s, c) = OR(s, c), MAJ(x, x, y) = x, ...)
+ *               MUX(s, s, c) = OR(s, c), MAJ(x, x, y) = x, ...).  Sharing a wire can take a single-use wire away from a later
+ *               pattern: the pipeline runs with and without this pass and the better result is returned (fewest bootstraps,
+ *               then levels, then gates)
  *   constants   bootsCONSTANT wires are folded into their readers (AND(x, 0) = 0, XOR(x, 1) = NOT x, MUX(s, 0, c) = ANDNY(s, c),
  *               MUX(s, b, 1) = ORNY(s, b), ...: a MUX with a known branch costs one bootstrap instead of two)
  *   NOT / COPY  folded into their readers (the ten two-input gates are closed under input negation; a negated MUX selector
