@@ -309,7 +309,8 @@ def _prefix_cells(emit, a, b, sub, outs=None, top=None):
             last = final and i == nbits - 1
             # a single bit as the upper operand needs no generate wire: where its inputs differ (P = 0) the carry is a_i,
             # the borrow b_i
-            g_hi = (b[i] if sub else a[i]) if single[i] else G[i]
+            # (the borrow as NOT a_i, a free gate: the optimizer then turns the cell into MAJ(NOT a_i, b_i, G_lo))
+            g_hi = (emit("NOT", a[i], -1) if sub else a[i]) if single[i] else G[i]
             newG[i] = emit("MUX", P[i], G[j], g_hi, out=top if last else None)
             # P of the combined group is read only by a later cell that uses position i (or a higher position of its
             # block) as the upper operand: never once the group starts at bit 0
@@ -447,7 +448,7 @@ def wallace_multiplier(nbits=4, extension_gates=True):
 def less_than_tree(nbits=8):
     """unsigned a < b in logarithmic depth: a balanced tree over (LT, EQ) pairs of bit ranges, upper half first:
     LT = MUX(EQ_hi, LT_lo, LT_hi), EQ = EQ_hi AND EQ_lo (only where a parent still needs it).  A single bit as the upper
-    operand needs no LT wire (MUX(a_i XNOR b_i, LT_lo, b_i)).  1 + ceil(log2 nbits) levels (4 for 8 bits) at 29
+    operand needs no LT wire (MUX(a_i XNOR b_i, LT_lo, NOT a_i): where the bits differ NOT a_i is b_i).  1 + ceil(log2 nbits) levels (4 for 8 bits) at 29
     bootstraps, against less_than's 8 levels at 22.  Returns (gates, n_wires, a_wires, b_wires, out_wire)."""
     a = list(range(nbits))
     b = list(range(nbits, 2 * nbits))
@@ -471,7 +472,9 @@ def less_than_tree(nbits=8):
         up_single = hi - mid == 1
         lt_lo, eq_lo = build(lo, mid, True, need_eq)
         lt_hi, eq_hi = build(mid, hi, not up_single, True)
-        lt = emit("MUX", eq_hi, lt_lo, b[mid] if up_single else lt_hi) if need_lt else None
+        # a single bit as the upper operand: on the branch the MUX takes where a_i != b_i, NOT a_i equals b_i (= a_i < b_i);
+        # NOT is free, and written this way the optimizer turns the cell into MAJ(NOT a_i, b_i, LT_lo): one bootstrap
+        lt = emit("MUX", eq_hi, lt_lo, emit("NOT", a[mid], -1) if up_single else lt_hi) if need_lt else None
         eq = emit("AND", eq_hi, eq_lo) if need_eq else None
         return lt, eq
 
@@ -496,7 +499,7 @@ def _optimized(built):
 def pick_form(forms, nbits, instances, resident_jobs=1024, optimized=False):
     """the form of lowest netlist_cost for this many instances (ties: fewest bootstraps): depth decides below a quarter
     of the resident set, bootstraps decide above it.  optimized: every candidate goes through optimize first and is
-    priced -- and returned -- as rewritten (the prefix adder 48 -> 40 bootstraps, the tree comparator 29 -> 27).
+    priced -- and returned -- as rewritten (the prefix adder 48 -> 40 bootstraps, the tree comparator 29 -> 24).
     Returns (name, builder result)."""
     best = None
     for name, build in forms.items():
@@ -546,7 +549,7 @@ def min_max_on(built_less_than, xor3_select=False):
 
 def min_max_for(nbits=8, instances=1, resident_jobs=1024):
     """(min, max) for this many instances, through optimize: every comparator form with both ways of selecting the maximum,
-    the cheapest by netlist_cost -- tree comparator + two MUXes per bit for small batches (8 bits: 59 bootstraps on 5 levels),
+    the cheapest by netlist_cost -- tree comparator + two MUXes per bit for small batches (8 bits: 56 bootstraps on 5 levels),
     MAJ chain + MUX + XOR3 per bit for wide ones (32 on 10; with two MUXes 40 on 9).
     Returns (gates, n_wires, a_wires, b_wires, min_wires, max_wires)."""
     best = None
@@ -905,10 +908,14 @@ def fuse_carry(gates, outputs, extension_gates=False):
 
 
 def fuse_maj(gates, outputs):
-    """extension gates only: a MUX whose selector is XOR(x, y) or XNOR(x, y) and one of whose branches is x or y is a
-    MAJORITY.  With d the branch taken where x and y differ and o the other one:  o in {x, y}: MAJ(x, y, d) (the carry written
-    as one MUX);  d in {x, y}: MAJ(NOT other, d, o) (a borrow / comparator step, MUX(XNOR(a, b), lt, b) = MAJ(NOT a, b, lt)) --
-    the NOT takes the selector's own wire when this MUX is its only reader and it is no output."""
+    """extension gates only: a MUX whose selector is XOR(x, y) or XNOR(x, y) and one of whose branches is -- or, on that
+    branch, equals -- x or y is a MAJORITY.  With d the branch taken where x and y differ and o the other one:
+      o in {x, y}, or o = AND(x, y) / OR(x, y) (= x where they agree):   MAJ(x, y, d)   (the carry written as one MUX)
+      d = NOT z, z in {x, y} (= the other input where they differ):      MAJ(d, other, o)
+      d in {x, y}:   MAJ(NOT other, d, o) (a borrow / comparator step, MUX(XNOR(a, b), lt, b) = MAJ(NOT a, b, lt)) -- the NOT
+                     takes the selector's own wire when this MUX is its only reader and it is no output
+      d = ANDNY / ORNY(u, v) (= v where they differ) or ANDYN / ORYN(u, v) (= u) over the selector's inputs, read by this MUX
+                     alone and no output (a tree comparator's LT_hi):  MAJ(NOT other, w, o), the NOT on d's own wire"""
     _check_ssa(gates)
     src = {g.out: g for g in gates}
     uses = _uses(gates)
@@ -920,11 +927,20 @@ def fuse_maj(gates, outputs):
         if q is not None and _NAMES[q.op] in ("XOR", "XNOR") and q.in0 != q.in1:
             x, y = q.in0, q.in1
             d, o = (g.in1, g.in2) if _NAMES[q.op] == "XOR" else (g.in2, g.in1)
-            if o in (x, y):
+            hd, ho = src.get(d), src.get(o)
+            dn, on = (_NAMES[hd.op] if hd is not None else None), (_NAMES[ho.op] if ho is not None else None)
+            if o in (x, y) or (on in ("AND", "OR") and {ho.in0, ho.in1} == {x, y}):
                 m = Gate(OPS["MAJ"], x, y, d, g.out)
+            elif dn == "NOT" and hd.in0 in (x, y):
+                m = Gate(OPS["MAJ"], d, y if hd.in0 == x else x, o, g.out)
             elif d in (x, y) and uses.get(q.out, 0) == 1 and q.out not in keep and q.out in pos:
                 out[pos[q.out]] = Gate(OPS["NOT"], y if d == x else x, -1, -1, q.out)
                 m = Gate(OPS["MAJ"], q.out, d, o, g.out)
+            elif dn in ("ANDNY", "ORNY", "ANDYN", "ORYN") and {hd.in0, hd.in1} == {x, y} and uses.get(d, 0) == 1 \
+                    and d not in keep and d in pos:
+                w = hd.in1 if dn in ("ANDNY", "ORNY") else hd.in0
+                out[pos[d]] = Gate(OPS["NOT"], y if w == x else x, -1, -1, d)
+                m = Gate(OPS["MAJ"], d, w, o, g.out)
         out.append(m if m is not None else Gate(g.op, g.in0, g.in1, g.in2, g.out))
         pos[g.out] = len(out) - 1
     return _drop_dead(out, outputs)

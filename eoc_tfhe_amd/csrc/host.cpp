@@ -1118,12 +1118,15 @@ Netlist pass_fuse_carry(const Netlist &cur, const std::vector<char> &keep, size_
     return res;
 }
 
-// extension gates only.  A MUX whose selector is XOR(x, y) or XNOR(x, y) and one of whose branches is x or y is a MAJORITY.
-// Let d be the branch taken where x and y differ, o the other one.
-//   o in {x, y}:  MAJ(x, y, d) -- the carry written as one MUX, MUX(XOR(x, y), c, x): where the inputs agree they are the result
+// extension gates only.  A MUX whose selector is XOR(x, y) or XNOR(x, y) and one of whose branches is -- or, on that branch,
+// equals -- x or y is a MAJORITY.  Let d be the branch taken where x and y differ, o the other one.
+//   o in {x, y}, or o = AND(x, y) / OR(x, y) (= x where they agree):  MAJ(x, y, d) -- the carry written as one MUX
+//   d = NOT z, z in {x, y} (= the other input where they differ):     MAJ(d, other, o)
 //   d in {x, y}:  MAJ(NOT other, d, o) -- a borrow / comparator step, MUX(XNOR(a, b), lt, b) = MAJ(NOT a, b, lt).  The NOT needs
 //                 a wire: the selector's own, when this MUX is its only reader and it is no output (its gate becomes the NOT:
 //                 same wire numbering, one bootstrap less on top of the MUX's)
+//   d = ANDNY / ORNY(u, v) (= v where they differ) or ANDYN / ORYN(u, v) (= u) over the selector's inputs, read by this MUX alone
+//                 and no output (a tree comparator's LT_hi):  MAJ(NOT other, w, o), the NOT on d's own wire
 Netlist pass_fuse_maj(const Netlist &cur, const std::vector<char> &keep, size_t n_wires)
 {
     std::vector<int64_t> src;
@@ -1139,12 +1142,23 @@ Netlist pass_fuse_maj(const Netlist &cur, const std::vector<char> &keep, size_t 
             if ((q.op == EOC_XOR || q.op == EOC_XNOR) && q.in0 != q.in1) {
                 const int32_t x = q.in0, y = q.in1;
                 const int32_t d = q.op == EOC_XOR ? g.in1 : g.in2, o = q.op == EOC_XOR ? g.in2 : g.in1;
-                if (o == x || o == y) {
+                const eoc_gate *hd = src[d] >= 0 ? &cur[src[d]] : nullptr, *ho = src[o] >= 0 ? &cur[src[o]] : nullptr;
+                auto over_xy = [&](const eoc_gate *h) { return (h->in0 == x && h->in1 == y) || (h->in0 == y && h->in1 == x); };
+                if (o == x || o == y || (ho && (ho->op == EOC_AND || ho->op == EOC_OR) && over_xy(ho))) {
                     res.push_back(mk(EOC_MAJ, x, y, d, g.out));
+                    done = true;
+                } else if (hd && hd->op == EOC_NOT && (hd->in0 == x || hd->in0 == y)) {
+                    res.push_back(mk(EOC_MAJ, d, hd->in0 == x ? y : x, o, g.out));
                     done = true;
                 } else if ((d == x || d == y) && uses[q.out] == 1 && !keep[q.out] && pos[q.out] >= 0) {
                     res[pos[q.out]] = mk(EOC_NOT, d == x ? y : x, -1, -1, q.out);
                     res.push_back(mk(EOC_MAJ, q.out, d, o, g.out));
+                    done = true;
+                } else if (hd && (hd->op == EOC_ANDNY || hd->op == EOC_ORNY || hd->op == EOC_ANDYN || hd->op == EOC_ORYN) && over_xy(hd) &&
+                           uses[d] == 1 && !keep[d] && pos[d] >= 0) {
+                    const int32_t w = (hd->op == EOC_ANDNY || hd->op == EOC_ORNY) ? hd->in1 : hd->in0;
+                    res[pos[d]] = mk(EOC_NOT, w == x ? y : x, -1, -1, d);
+                    res.push_back(mk(EOC_MAJ, d, w, o, g.out));
                     done = true;
                 }
             }

@@ -179,7 +179,8 @@ local function prefixCells(nl, a, b, sub)                 -- a, b: 0-based array
         local j = ((i >> k) << k) - 1
         local ghi = G[i]
         if single[i] then
-          if sub then ghi = b[i] else ghi = a[i] end
+          -- (the borrow as NOT a_i, a free gate: the optimizer then turns the cell into MAJ(NOT a_i, b_i, G_lo))
+          if sub then ghi = nl.gate(OP.NOT, a[i]) else ghi = a[i] end
         end
         newG[i] = nl.gate(OP.MUX, P[i], G[j], ghi)
         if i < (1 << (k + 1)) then newP[i] = nil else newP[i] = nl.gate(OP.AND, P[i], P[j]) end
@@ -234,7 +235,9 @@ function Tfhe.lessThanTreeNetlist(nbits)
     local lt, eq = nil, nil
     if needLt then
       local hiv = ltHi
-      if upSingle then hiv = b + mid end
+      -- a single bit as the upper operand: where a_i ~= b_i NOT a_i equals b_i; NOT is free, and written this way the
+      -- optimizer turns the cell into MAJ(NOT a_i, b_i, LT_lo): one bootstrap
+      if upSingle then hiv = nl.gate(OP.NOT, a + mid) end
       lt = nl.gate(OP.MUX, eqHi, ltLo, hiv)
     end
     if needEq then eq = nl.gate(OP.AND, eqHi, eqLo) end
@@ -247,7 +250,7 @@ end
 -- level costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
 -- outPos: positions of the builder's output wires (lists or single wires) in what it returns -- the candidates are priced
 -- AFTER backend.netlistOptimize, the way runNetlist runs them (the row-by-row multiplier shrinks from 320 to 176 bootstraps,
--- the column form to 230, the prefix adder from 48 to 40, the tree comparator from 29 to 27)
+-- the column form to 230, the prefix adder from 48 to 40, the tree comparator from 29 to 24)
 local function cheapest(builders, nbits, instances, outPos)
   local best, bestCost
   for i = 1, #builders do
@@ -289,7 +292,7 @@ function Tfhe.minMaxNetlistOn(nbits, xor3Select, nl, a, b, lt)
   return nl, a, b, lt, mn, mx
 end
 -- every comparator form with both ways of selecting the maximum, the cheapest for this many instances: tree comparator + two
--- MUXes per bit for small batches (8 bits: 59 bootstraps on 5 levels after the optimizer), MAJ chain + MUX + XOR3 for wide
+-- MUXes per bit for small batches (8 bits: 56 bootstraps on 5 levels after the optimizer), MAJ chain + MUX + XOR3 for wide
 -- ones (32 on 10; with two MUXes 40 on 9)
 function Tfhe.minMaxNetlistFor(nbits, instances)
   local builders = {}

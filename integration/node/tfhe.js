@@ -200,7 +200,9 @@ const prefixCells = (nl, a, b, sub) => {               // a, b: arrays of wires,
     for (let i = 0; i < nbits; i++) {
       if (!((i >> k) & 1)) continue;
       const j = ((i >> k) << k) - 1;
-      newG[i] = nl.gate(OP.MUX, P[i], G[j], single[i] ? (sub ? b[i] : a[i]) : G[i]);
+      // (the borrow as NOT a_i, a free gate: the optimizer then turns the cell into MAJ(NOT a_i, b_i, G_lo))
+      const gHi = single[i] ? (sub ? nl.gate(OP.NOT, a[i]) : a[i]) : G[i];
+      newG[i] = nl.gate(OP.MUX, P[i], G[j], gHi);
       newP[i] = i < (1 << (k + 1)) ? null : nl.gate(OP.AND, P[i], P[j]);
       newS[i] = false;
     }
@@ -236,7 +238,9 @@ Tfhe.lessThanTreeNetlist = nbits => {
     const mid = lo + ((hi - lo + 1) >> 1), upSingle = hi - mid === 1;
     const [ltLo, eqLo] = build(lo, mid, true, needEq);
     const [ltHi, eqHi] = build(mid, hi, !upSingle, true);
-    const lt = needLt ? nl.gate(OP.MUX, eqHi, ltLo, upSingle ? b + mid : ltHi) : null;
+    // a single bit as the upper operand: where a_i != b_i NOT a_i equals b_i; NOT is free, and written this way the optimizer
+    // turns the cell into MAJ(NOT a_i, b_i, LT_lo): one bootstrap
+    const lt = needLt ? nl.gate(OP.MUX, eqHi, ltLo, upSingle ? nl.gate(OP.NOT, a + mid) : ltHi) : null;
     const eq = needEq ? nl.gate(OP.AND, eqHi, eqLo) : null;
     return [lt, eq];
   };
@@ -247,7 +251,7 @@ Tfhe.lessThanTreeNetlist = nbits => {
 // costs the same whatever its width, so depth decides for small batches and bootstraps for wide ones)
 // outKeys: the builder's output wires (lists or single wires) -- the candidates are priced AFTER B.netlistOptimize, the way
 // runNetlist runs them (the row-by-row multiplier shrinks from 320 to 176 bootstraps, the column form to 230, the prefix
-// adder from 48 to 40, the tree comparator from 29 to 27)
+// adder from 48 to 40, the tree comparator from 29 to 24)
 const outputsOf = (r, outKeys) => outKeys.flatMap(k => r[k]);
 const cheapest = (builders, nbits, instances, outKeys) => {
   let best = null, bestCost = 0;
@@ -275,7 +279,7 @@ Tfhe.minMaxNetlistOn = ({ nl, a, b, lt }, nbits, xor3Select) => {
   return { nl, a, b, lt, min, max };
 };
 // every comparator form with both ways of selecting the maximum, the cheapest for this many instances: tree comparator + two
-// MUXes per bit for small batches (8 bits: 59 bootstraps on 5 levels after the optimizer), MAJ chain + MUX + XOR3 for wide
+// MUXes per bit for small batches (8 bits: 56 bootstraps on 5 levels after the optimizer), MAJ chain + MUX + XOR3 for wide
 // ones (32 on 10; with two MUXes 40 on 9)
 Tfhe.minMaxNetlistFor = (nbits, instances) => cheapest(
   [Tfhe.majLessThanNetlist, Tfhe.lessThanTreeNetlist].flatMap(lt => [false, true].map(x3 => n => Tfhe.minMaxNetlistOn(lt(n), n, x3))),

@@ -445,11 +445,31 @@ def test_borrow_and_comparison_chains_become_majorities():
     gates, nw, a, b, mn, mx = c.min_max(8)
     o = c.optimize(gates, mn + mx)
     assert (circuit_bootstraps(gates), circuit_bootstraps(o), c.bootstrap_depth(o)) == (54, 40, 9)
-    for build in (c.prefix_adder, c.less_than_tree):
+    # the log-depth forms: a single bit as a cell's upper operand is written as NOT a_i (free; where the bits differ it IS the
+    # borrow / less-than bit b_i), so the cell becomes MAJ(NOT a_i, b_i, lower) whoever else reads the selector
+    for build, want in ((c.prefix_adder, (40, 5)), (c.less_than_tree, (24, 4)), (c.prefix_subtractor, (41, 5))):
         r = build(8)
         outs = _flat(r[4:])
         o = c.optimize(r[0], outs)
-        assert (circuit_bootstraps(o), c.bootstrap_depth(o)) == {c.prefix_adder: (40, 5), c.less_than_tree: (27, 4)}[build]
+        assert (circuit_bootstraps(o), c.bootstrap_depth(o)) == want, build.__name__
+        assert circuit_bootstraps(c.optimize(r[0], outs, extension_gates=False)) == circuit_bootstraps(r[0])
+    # ... and the other shapes of the rule: the branch equals an input of the selector ON that branch
+    w3 = np.zeros((8, 8), np.uint8)
+    for k in range(8):
+        w3[0, k], w3[1, k], w3[2, k] = k & 1, (k >> 1) & 1, (k >> 2) & 1
+    G = lambda name, i0, i1, i2, o_: Gate(OPS[name], i0, i1, i2, o_)
+    for nl, outs, want in (
+            ([G("XOR", 0, 1, -1, 3), G("AND", 0, 1, -1, 4), G("MUX", 3, 2, 4, 5)], [5], ["MAJ"]),            # carry = p ? c : g
+            ([G("XOR", 0, 1, -1, 3), G("OR", 1, 0, -1, 4), G("MUX", 3, 2, 4, 5)], [5], ["MAJ"]),
+            ([G("XNOR", 0, 1, -1, 3), G("ANDNY", 0, 1, -1, 4), G("MUX", 3, 2, 4, 5)], [5, 3], ["XNOR", "NOT", "MAJ"]),  # LT_hi
+            ([G("XNOR", 0, 1, -1, 3), G("ANDYN", 1, 0, -1, 4), G("MUX", 3, 2, 4, 5)], [5, 3], ["XNOR", "NOT", "MAJ"]),
+            ([G("XOR", 0, 1, -1, 3), G("ORYN", 0, 1, -1, 4), G("MUX", 3, 4, 2, 5)], [5, 3], ["XOR", "NOT", "MAJ"]),
+            ([G("XNOR", 0, 1, -1, 3), G("NOT", 0, -1, -1, 4), G("MUX", 3, 2, 4, 5)], [5, 3], ["XNOR", "NOT", "MAJ"]),
+            ([G("XNOR", 0, 1, -1, 3), G("ANDNY", 0, 1, -1, 4), G("MUX", 3, 2, 4, 5)], [5, 3, 4], ["XNOR", "ANDNY", "MUX"])):  # LT_hi is read
+        opt = c.optimize(nl, outs)
+        assert [c._NAMES[g.op] for g in opt] == want, (want, [c._NAMES[g.op] for g in opt])
+        ref, got = c.evaluate_plain(nl, w3), c.evaluate_plain(opt, w3)
+        assert all(np.array_equal(ref[x], got[x]) for x in outs), want
     A, B, S = _words(4)
     for build, value in ((c.subtractor, lambda A, B: (A - B) & 15), (c.less_than, lambda A, B: (A < B) * 1)):
         r = build(4)
@@ -585,7 +605,7 @@ def test_form_is_picked_by_instance_count():
         assert c.pick_form({k: v for k, v in c.LESS_THAN_FORMS.items() if k != "maj"}, 8, S)[0] == "ripple"
     # min / max: tree comparator + two MUXes per bit for small batches; MAJ chain + MUX + XOR3(a, b, min) for wide ones (one
     # bootstrap instead of the second MUX's two, one level later); in between the tree with the XOR3 selection
-    for S, shape in ((1, (59, 5)), (64, (51, 6)), (4096, (32, 10))):
+    for S, shape in ((1, (56, 5)), (64, (48, 6)), (4096, (32, 10))):
         gates, nw, a, b, mn, mx = c.min_max_for(8, S)
         assert (circuit_bootstraps(gates), c.bootstrap_depth(gates)) == shape
         rng = np.random.default_rng(S)
