@@ -27,7 +27,8 @@ OPS = [
               "xor3/maj": lambda: c.maj_adder(8), "prefix": lambda: c.prefix_adder(8),
               "prefix (optimized)": lambda: opt(c.prefix_adder(8))}, lambda A, B: A + B, 8),
     ("sub8", {"ripple": lambda: c.subtractor(8)[:5], "ripple (optimized)": lambda: opt(c.subtractor(8))[:5],
-              "xor3/maj": lambda: c.maj_subtractor(8)[:5], "prefix": lambda: c.prefix_subtractor(8)[:5]},
+              "xor3/maj": lambda: c.maj_subtractor(8)[:5], "prefix": lambda: c.prefix_subtractor(8)[:5],
+              "prefix (optimized)": lambda: opt(c.prefix_subtractor(8))[:5]},
      lambda A, B: (A - B) % 256, 8),
     ("lt8", {"ripple": lambda: c.less_than(8), "ripple (optimized)": lambda: opt(c.less_than(8)), "maj": lambda: c.maj_less_than(8),
              "tree": lambda: c.less_than_tree(8), "tree (optimized)": lambda: opt(c.less_than_tree(8))},
@@ -42,7 +43,7 @@ OPS = [
               "columns (optimized)": lambda: c.MULTIPLIER_FORMS["wallace"](8)}, lambda A, B: A * B, 8),
 ]
 # the forms the facades choose between (the others are shown for comparison)
-CANDIDATES = {"add8": ("xor3/maj", "prefix (optimized)"), "sub8": ("xor3/maj", "prefix"), "lt8": ("maj", "tree (optimized)"),
+CANDIDATES = {"add8": ("xor3/maj", "prefix (optimized)"), "sub8": ("xor3/maj", "prefix (optimized)"), "lt8": ("maj", "tree (optimized)"),
               "minmax8": ("maj + 2 MUX", "maj + MUX + XOR3", "tree + 2 MUX", "tree + MUX + XOR3"),
               "mul8": ("rows (optimized)", "columns (optimized)")}
 worst = 0.0

@@ -108,6 +108,19 @@ def soak(budget_s=120.0, seed=1, kinds=KINDS, max_contexts=None, cases_per_conte
                         if rng.integers(0, 4) == 0:
                             avail.append(out)                      # the selector stays visible: the NOT cannot take its wire
                         continue
+                    if r == 3 and n_gates - len(gates) >= 3:       # a MUX branch that equals a selector input ON that branch
+                        x, y, z = pick(), pick(), pick()
+                        sel = "XOR" if rng.integers(0, 2) else "XNOR"
+                        kind_b = str(rng.choice(["NOT", "ANDNY", "ANDYN", "ORNY", "ORYN", "AND", "OR"]))
+                        if kind_b == "NOT":
+                            gates += [eoc.Gate(eoc.OPS[sel], x, y, -1, out), eoc.Gate(eoc.OPS["NOT"], x, -1, -1, out + 1)]
+                        else:
+                            gates += [eoc.Gate(eoc.OPS[sel], x, y, -1, out), eoc.Gate(eoc.OPS[kind_b], x, y, -1, out + 1)]
+                        on_differ = kind_b not in ("AND", "OR")                         # the branch the stand-in belongs on
+                        br = (out + 1, z) if (sel == "XOR") == on_differ else (z, out + 1)
+                        gates.append(eoc.Gate(eoc.OPS["MUX"], out, br[0], br[1], out + 2))
+                        avail += [out + 2] + ([out] if rng.integers(0, 2) else []) + ([out + 1] if rng.integers(0, 4) == 0 else [])
+                        continue
                     if r == 2 and gates:                           # an earlier gate again, operands swapped where it has two
                         e = gates[int(rng.integers(0, len(gates)))]
                         two = e.in1 >= 0 and e.in2 < 0 and e.op in (eoc.OPS["AND"], eoc.OPS["OR"], eoc.OPS["XOR"], eoc.OPS["XNOR"],
