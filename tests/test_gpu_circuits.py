@@ -215,6 +215,25 @@ def test_string_api_and_host_batch_api(eoc):
         assert np.array_equal(word(T.multiplyBitsBatch(pl4(Av[:5] & 15), pl4(Bv[:5] & 15))), (Av[:5] & 15) * (Bv[:5] & 15))
         mn, mx = T.minMaxBitsBatch(planes(Av[:9]), planes(Bv[:9]))
         assert np.array_equal(word(mn), np.minimum(Av[:9], Bv[:9])) and np.array_equal(word(mx), np.maximum(Av[:9], Bv[:9]))
+        # wide batches take the other forms (MAJ chains; the maximum as XOR3(a, b, min)), and 16-bit words the same builders:
+        # every word-level call at 700 pairs of 8 bits and at 3 and 300 pairs of 16 bits, with ties and the extremes
+        mn, mx = T.minMaxBitsBatch(planes(Av[:700]), planes(Bv[:700]))
+        assert np.array_equal(word(mn), np.minimum(Av[:700], Bv[:700])) and np.array_equal(word(mx), np.maximum(Av[:700], Bv[:700]))
+        diff = T.subtractBitsBatch(planes(Av[:700]), planes(Bv[:700]))
+        assert np.array_equal(word(diff[:8]), (Av[:700] - Bv[:700]) % 256) and np.array_equal(word(diff[8:]), (Av[:700] < Bv[:700]))
+        pl16 = lambda vals: np.stack([eoc.global_encrypt_bits(((vals >> i) & 1).astype(np.uint8)) for i in range(16)])
+        for S in (3, 300):
+            A16, B16 = rng.integers(0, 1 << 16, S), rng.integers(0, 1 << 16, S)
+            A16[0], B16[0] = 0xFFFF, 0xFFFF                                                        # a tie at the maximum
+            A16[1], B16[1] = 0, 0xFFFF
+            pa, pb = pl16(A16), pl16(B16)
+            assert np.array_equal(word(T.addBitsBatch(pa, pb)), A16 + B16)
+            d16 = T.subtractBitsBatch(pa, pb)
+            assert np.array_equal(word(d16[:16]), (A16 - B16) % 65536) and np.array_equal(word(d16[16:]), (A16 < B16))
+            assert np.array_equal(eoc.global_decrypt_bits(T.lessThanBitsBatch(pa, pb)), (A16 < B16).astype(np.uint8))
+            mn, mx = T.minMaxBitsBatch(pa, pb)
+            assert np.array_equal(word(mn), np.minimum(A16, B16)) and np.array_equal(word(mx), np.maximum(A16, B16))
+        assert np.array_equal(word(T.multiplyBitsBatch(planes(Av[:3]), planes(Bv[:3]))), Av[:3] * Bv[:3])     # 8 x 8 -> 16 bits
     finally:
         T.resetGateKey()
 
