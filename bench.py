@@ -21,10 +21,12 @@ Prints ONE JSON line (rank 0).  Keys beyond the driver's contract:
                  blind rotation x jobs per launch / the HIP-event duration measured in this run, against the 78.6
                  TFLOP/s datasheet peak.  Co-bounds in the same block, so that the fraction explains itself:
                  `l2_served` (key-row bytes per launch / launch time against the 16.8-18.8 TB/s the microarch guide
-                 measures for rows served by the XCDs' L2), `lds` (stored PMC: share of wave cycles in which an LDS
+                 measures for rows served by the XCDs' L2), `lds` (PMC: share of wave cycles in which an LDS
                  instruction is ready but the LDS pipe is taken, LDS instructions per wave-step, bank conflicts),
-                 `hbm_measured` (stored PMC bytes of the same launch shape / this run's launch duration, GB/s and
-                 fraction of 8 TB/s); the algorithmic HBM figure is a secondary key (a batch serves BK from L2)
+                 `traffic` / `hbm_measured` (PMC bytes per launch / this run's launch duration, GB/s and fraction of
+                 8 TB/s).  At N = 1 the PMC figures are MEASURED IN THE RUN (live_traffic: the resident steps again as
+                 children under `rocprofv3 --pmc`, one pass per counter group, ~6 s per parameter set; profiles/traffic.json
+                 is the labelled fallback); the algorithmic HBM figure is a secondary key (a batch serves BK from L2)
   wallclock      the same K steps through the host-buffer call (PCIe inclusive): `wallclock_gates_per_s`,
                  `wallclock_ms_per_step`; `pipelined_gates_per_s` = eoc_gate_batch_submit / _wait two deep;
                  `pageable_gates_per_s` = the host-buffer call on ordinary malloc'ed arrays
