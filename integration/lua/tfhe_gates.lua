@@ -531,6 +531,11 @@ function Tfhe.addBitsBatch(A, B, nbits, instances)      -- the form is picked by
   for i = 1, #sum do out[i] = planes(wires, sum[i], 1, instances) end
   return table.concat(out)                                -- [nbits + 1][instances][n+1]
 end
+function Tfhe.lessThanBitsBatch(A, B, nbits, instances)  -- -> [instances][n+1]: 1 iff A < B (unsigned); the form by instance count
+  local nl, a, b, lt = Tfhe.lessThanNetlistFor(nbits, instances)
+  local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances, { lt })
+  return wires and planes(wires, lt, 1, instances)
+end
 function Tfhe.subtractBitsBatch(A, B, nbits, instances)  -- -> [nbits + 1][instances][n+1]: difference bits, then the borrow
   local nl, a, b, diff, borrow = Tfhe.subtractorNetlistFor(nbits, instances)
   local wires = Tfhe.runNetlist(nl, { [a] = A, [b] = B }, instances, joined(diff, { borrow }))

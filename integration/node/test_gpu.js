@@ -76,6 +76,16 @@ assert.strictEqual(tfhe.backend.decryptBits(tfhe.equalStrings(tfhe.encryptString
     for (let i = 0; i < S; i++) tot[i] |= bits[i] << k;
   }
   for (let i = 0; i < S; i++) assert.strictEqual(tot[i], A[i] + Bv[i]);
+  // comparison and min / max over the same 4096 pairs: the wide-batch forms (MAJ chain; the maximum as XOR3(a, b, min))
+  const ltBits = B.decryptBits(tfhe.lessThanBitsBatch(enc(A), enc(Bv), nb, S));
+  for (let i = 0; i < S; i++) assert.strictEqual(ltBits[i], A[i] < Bv[i] ? 1 : 0);
+  const mm = tfhe.minMaxBitsBatch(enc(A), enc(Bv), nb, S);
+  const lo = new Array(S).fill(0), hi = new Array(S).fill(0);
+  for (let k = 0; k < nb; k++) {
+    const bl = B.decryptBits(mm.min.slice(k * plane, (k + 1) * plane)), bh = B.decryptBits(mm.max.slice(k * plane, (k + 1) * plane));
+    for (let i = 0; i < S; i++) { lo[i] |= bl[i] << k; hi[i] |= bh[i] << k; }
+  }
+  for (let i = 0; i < S; i++) { assert.strictEqual(lo[i], Math.min(A[i], Bv[i])); assert.strictEqual(hi[i], Math.max(A[i], Bv[i])); }
   const boots = B.circuitBootstraps(tfhe.adderNetlist(nb).nl.packed()) * S;
   console.log(`node adder8 x ${S}: ${boots} bootstraps in ${dt.toFixed(2)} s (${Math.round(boots / dt)} /s incl. host copies)`);
   // netlistOptimize: NOT(x) feeding an AND becomes one ANDNY

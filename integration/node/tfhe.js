@@ -386,6 +386,11 @@ Tfhe.addBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // the form is picked 
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, sum);
   return wires && Buffer.concat(sum.map(wi => planes(wires, wi, 1, instances)));   // [nbits + 1][instances][n+1]
 };
+Tfhe.lessThanBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [instances][n+1]: 1 iff A < B (unsigned); the form by instance count
+  const { nl, a, b, lt } = Tfhe.lessThanNetlistFor(nbits, instances);
+  const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, [lt]);
+  return wires && planes(wires, lt, 1, instances);
+};
 Tfhe.subtractBitsBatch = (Abuf, Bbuf, nbits, instances) => {   // -> [nbits + 1][instances][n+1]: difference bits, then the borrow
   const { nl, a, b, diff, borrow } = Tfhe.subtractorNetlistFor(nbits, instances);
   const wires = Tfhe.runNetlist(nl, { [a]: Abuf, [b]: Bbuf }, instances, [...diff, borrow]);

@@ -169,7 +169,7 @@ def test_facade_defines_its_functions_and_passes_through(facade):
     for name in ("generateGateKey", "nand", "band", "bor", "bnot", "mux", "adderNetlist", "equalNetlist", "minMaxNetlist",
                  "newCircuit", "muxAdderNetlist", "majAdderNetlist", "majSubtractorNetlist", "majLessThanNetlist", "maj", "xor3", "prefixAdderNetlist", "prefixSubtractorNetlist", "wallaceMultiplierNetlist", "multiplierNetlistFor", "subtractorNetlistFor", "lessThanNetlist", "lessThanTreeNetlist", "adderNetlistFor", "lessThanNetlistFor",
                  "subtractorNetlist", "multiplierNetlist", "runNetlist", "addBitsBatch", "subtractBitsBatch",
-                 "multiplyBitsBatch", "minMaxBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
+                 "multiplyBitsBatch", "minMaxBitsBatch", "lessThanBitsBatch", "equalBits", "equalStrings", "encryptStringBits", "setDevices"):
         assert isinstance(tf.get(name.encode()), ml.LuaFunction), name
     assert call(it, tf, "nand", b"x", b"y") == [b"NAND(x,y)"]
     assert call(it, tf, "setDevices", 0, 1, 2) == [3]                          # varargs travel
@@ -296,6 +296,8 @@ def test_forms_are_picked_by_instance_count(facade):
     lo, hi, lt = call(it, tf, "minMaxBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)
     assert np.array_equal(value_of(lo, 3), np.minimum(A, B)) and np.array_equal(value_of(hi, 3), np.maximum(A, B))
     assert np.array_equal(value_of(lt, 3), (A < B).astype(np.int64))
+    assert np.array_equal(value_of(call(it, tf, "lessThanBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)[0], 3),
+                          (A < B).astype(np.int64))
     out = call(it, tf, "addBitsBatch", planes_of(A, 8, 3), planes_of(B, 8, 3), 8, 3)[0]
     assert np.array_equal(value_of(out, 3), A + B)
     # what runs is the picked form AFTER netlistOptimize (the prefix adder: 48 -> 40 bootstraps on the same 5 levels)
@@ -439,6 +441,7 @@ def test_facade_on_the_real_binding_and_gpu(tmp_path, built_lib):
         lo, hi, lt = call(it, tf, "minMaxBitsBatch", ea, eb, nbits, S)
         assert np.array_equal(dec(lo), np.minimum(A, B)) and np.array_equal(dec(hi), np.maximum(A, B))
         assert np.array_equal(dec(lt), (A < B).astype(np.int64))
+        assert np.array_equal(dec(call(it, tf, "lessThanBitsBatch", ea, eb, nbits, S)[0]), (A < B).astype(np.int64))
         # the adder's bytes against the oracle: the facade's netlist, gate by gate
         # (the form addBitsBatch picked for 6 instances: the XOR3 / MAJ adder at 4 bits)
         nl, a, b, s = call(it, tf, "adderNetlistFor", nbits, S)
